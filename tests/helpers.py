@@ -1,0 +1,45 @@
+"""Shared test helpers (fingerprints matching oracle/gen_golden.py:summary)."""
+import json
+import os
+
+import torch
+
+from oracle import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLD, name + ".json")) as f:
+        return json.load(f)
+
+
+def summary(key, t):
+    t = t.detach().to("cpu", torch.float64).reshape(-1)
+    probe = synth.synth_tensor("probe." + key, t.shape, seed=7).to(torch.float64) / 0.02
+    return {"shape": list(t.shape), "norm": t.norm().item(), "sum": t.sum().item(),
+            "first": t[:8].tolist(), "probe": (t * probe).sum().item()}
+
+
+def check_summary(key, t, gold, rtol, what=""):
+    """Compare a tensor against a golden fingerprint.  ``norm`` is compared relatively; ``first`` and ``probe``
+    (a random projection, i.e. a checksum sensitive to every element) relative to the tensor's norm."""
+    s = summary(key, t)
+    assert s["shape"] == gold["shape"], f"{what}{key}: shape {s['shape']} vs {gold['shape']}"
+    n = max(gold["norm"], 1e-30)
+    assert abs(s["norm"] - gold["norm"]) <= rtol * n, f"{what}{key}: norm {s['norm']} vs {gold['norm']}"
+    numel = 1
+    for d in gold["shape"]:
+        numel *= d
+    # probe ~ N(0,1) entries: |probe . err| ~ ||err||; elementwise first-8 error ~ ||err|| / sqrt(numel)
+    assert abs(s["probe"] - gold["probe"]) <= 4 * rtol * n, f"{what}{key}: probe {s['probe']} vs {gold['probe']}"
+    tol_first = 6 * rtol * n / numel ** 0.5 + 1e-12
+    for a, b in zip(s["first"], gold["first"]):
+        assert abs(a - b) <= tol_first, f"{what}{key}: first {s['first']} vs {gold['first']} (tol {tol_first})"
+    return s
+
+
+def rel_err(a, b):
+    a = a.detach().to("cpu", torch.float64)
+    b = b.detach().to("cpu", torch.float64)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()

@@ -1,0 +1,86 @@
+"""Pins ``oracle/refcpu.py`` against fixtures produced by the IMPORTED REFERENCE (oracle/gen_golden.py).
+
+CPU only.  If these fail the oracle is wrong and no GPU parity claim means anything."""
+import pytest
+import torch
+
+from oracle import refcpu, synth
+from helpers import check_summary, load_golden
+from bioscanclip.model import arch
+from bioscanclip.model.image_encoder import LoRA_ViT_timm
+from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+from bioscanclip.model.language_encoder import LoRA_bert
+
+RT = 2e-5  # fp32 CPU restatement vs fp32 reference: reordering noise only
+
+
+def _leafify(sd, pred):
+    keys = [k for k in sd if pred(k)]
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    return keys
+
+
+@pytest.mark.parametrize("N", [8, 64])
+@pytest.mark.parametrize("nmod", [2, 3])
+@pytest.mark.parametrize("dup", [False, True])
+def test_loss_matches_reference(N, nmod, dup):
+    name = f"N{N}_m{nmod}_{'dup' if dup else 'id'}"
+    g = load_golden("loss")[name]
+    feats = [synth.synth_tensor(f"loss.{name}.{i}", (N, 768), seed=3).requires_grad_(True) for i in range(nmod)]
+    label = torch.tensor(g["label"])
+    loss = refcpu.contrastive_loss(feats[0], feats[1], feats[2] if nmod == 3 else None, label)
+    assert abs(loss.item() - g["loss"]) <= 1e-5 * abs(g["loss"])
+    loss.backward()
+    for i, f in enumerate(feats):
+        check_summary(f"loss.{name}.{i}", f.grad, g["grads"][i], RT)
+
+
+def test_loss_too_few_modalities():
+    with pytest.raises(ValueError, match="Too less element"):
+        refcpu.contrastive_loss(torch.randn(4, 8), None, None, torch.arange(4))
+
+
+@pytest.mark.parametrize("layers", [2, 12])
+def test_dna_encoder_matches_reference(layers):
+    g = load_golden("encoders")[f"dna_L{layers}"]
+    m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=layers)), r=4,
+                          num_classes=768)
+    sd = synth.synth_state_dict({"dna_encoder." + k: v for k, v in synth.shapes_of(m).items()}, seed=11)
+    keys = _leafify(sd, refcpu.is_trainable_key)
+    _, dna, _, _ = synth.synth_batch(2, seed=21)
+    y = refcpu.barcode_bert_encoder(sd, dna)
+    check_summary(f"dna.out.{layers}", y, g["out"], RT)
+    (y * synth.synth_tensor(f"dna.cot.{layers}", y.shape, seed=5)).sum().backward()
+    assert set(keys) == set(g["grads"].keys())
+    for k in keys:
+        check_summary(k, sd[k].grad, g["grads"][k], 5e-5)
+
+
+def test_text_encoder_matches_reference():
+    g = load_golden("encoders")["txt_L4"]
+    m = LoRA_bert(arch.BertModelParams(arch.bert_small_config()), r=4, num_classes=768)
+    sd = synth.synth_state_dict({"language_encoder." + k: v for k, v in synth.shapes_of(m).items()}, seed=12)
+    keys = _leafify(sd, refcpu.is_trainable_key)
+    _, _, text, _ = synth.synth_batch(4, seed=22, with_text=True)
+    y = refcpu.bert_text_encoder(sd, text)
+    check_summary("txt.out", y, g["out"], RT)
+    (y * synth.synth_tensor("txt.cot", y.shape, seed=5)).sum().backward()
+    assert set(keys) == set(g["grads"].keys())
+    for k in keys:
+        check_summary(k, sd[k].grad, g["grads"][k], 5e-5)
+
+
+@pytest.mark.parametrize("depth", [2, 12])
+def test_vit_encoder_matches_reference_wrapper(depth):
+    g = load_golden("encoders")[f"vit_L{depth}"]
+    m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=depth), r=4, num_classes=768)
+    sd = synth.synth_state_dict({"image_encoder." + k: v for k, v in synth.shapes_of(m).items()}, seed=13)
+    keys = _leafify(sd, refcpu.is_trainable_key)
+    image, _, _, _ = synth.synth_batch(2, seed=23)
+    y = refcpu.vit_encoder(sd, image)
+    check_summary(f"vit.out.{depth}", y, g["out"], RT)
+    (y * synth.synth_tensor(f"vit.cot.{depth}", y.shape, seed=5)).sum().backward()
+    assert set(keys) == set(g["grads"].keys())
+    for k in keys:
+        check_summary(k, sd[k].grad, g["grads"][k], 5e-5)
