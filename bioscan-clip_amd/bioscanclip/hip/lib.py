@@ -1,0 +1,83 @@
+"""ctypes binding of ``libbsclip_hip.so`` (C ABI declared in ``include/bsclip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C bioscan-clip_amd/csrc`` into
+``bioscan-clip_amd/lib/``.  There is no fallback: if it is missing, importing a compute op raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libbsclip_hip.so")
+
+EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, EPI_DGELU_BF16, EPI_PATCH_F32 = range(6)
+KPAD = 64
+LORA_COLS = 8
+
+
+class EpiArgs(Structure):
+    _fields_ = [("bias", c_void_p), ("resid", c_void_p), ("ld_resid", c_int), ("aux", c_void_p), ("ld_aux", c_int)]
+
+
+P, I, F, L = c_void_p, c_int, c_float, c_int64
+
+# name -> (restype, argtypes); mirrors include/bsclip.h one to one (tests/test_abi.py checks both directions)
+SIGNATURES = {
+    "bsclip_last_error": (c_char_p, []),
+    "bsclip_abi_version": (I, []),
+    "bsclip_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P]),
+    "bsclip_gemm_set_tile": (I, [I]),
+    "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, P]),
+    "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, P, I, P, P, I, P, P, I, P]),
+    "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, P]),
+    "bsclip_attn_bwd": (I, [P, I, P, P, I, P, I, I, I, P, F, P, I, P]),
+    "bsclip_im2col_patch16": (I, [P, I, P, P]),
+    "bsclip_vit_cls_rows": (I, [P, P, P, I, I, I, P]),
+    "bsclip_bert_embed": (I, [P, P, I, I, I, P, I, P, P, P, P]),
+    "bsclip_softmax_meanpool_fwd": (I, [P, I, I, I, P, P, P]),
+    "bsclip_softmax_meanpool_bwd": (I, [P, P, P, I, I, I, P, I, P]),
+    "bsclip_meanpool_tokens_fwd": (I, [P, I, I, I, P, I, P]),
+    "bsclip_meanpool_tokens_bwd": (I, [P, I, I, I, I, P, P]),
+    "bsclip_l2norm_fwd": (I, [P, I, I, P, P, P]),
+    "bsclip_l2norm_bwd": (I, [P, P, P, I, I, P, P]),
+    "bsclip_infonce_workspace_floats": (L, [I, I]),
+    "bsclip_infonce_fwd_bwd": (I, [POINTER(c_void_p), I, P, I, I, F, I, I, P, POINTER(c_void_p), P, P]),
+    "bsclip_lora_grad": (I, [P, I, P, I, I, I, P, P, P, P, P, P]),
+    "bsclip_colsum": (I, [P, I, I, I, I, P, P]),
+    "bsclip_transpose_bf16": (I, [P, I, I, I, P, I, P]),
+    "bsclip_cast_f32_bf16": (I, [P, L, P, P]),
+    "bsclip_waug_set_lora": (I, [P, I, I, P, P, P]),
+    "bsclip_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, F, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C bioscan-clip_amd/csrc`.  bioscanclip has no non-HIP compute path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI drift between header and library
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().bsclip_last_error().decode()
+
+
+def check(rc):
+    if rc != 0:
+        msg = last_error()
+        if msg.startswith("Too less element"):
+            raise ValueError(msg)  # reference loss_func.py:35-36
+        raise RuntimeError(f"libbsclip_hip: {msg} (rc={rc})")

@@ -1,0 +1,287 @@
+"""Tensor-level wrappers over the C ABI (one function per ``bsclip_*`` entry point).
+
+torch is plumbing here (device memory + the current HIP stream); every function validates shapes, dtypes and
+contiguity on the host before handing raw pointers to the library, because an out-of-bounds access in a
+hand-written kernel can take the whole GPU down.  Nothing in this module computes with torch ops.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _l
+from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_PATCH_F32, EPI_RESID_F32, KPAD, EpiArgs,
+                  check)
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+def _rowmajor(t, name):
+    _req(t.is_cuda, f"{name}: expected a GPU tensor")
+    _req(t.dim() == 2 and t.stride(1) == 1, f"{name}: expected a 2-D tensor with unit inner stride")
+    return t.stride(0)
+
+
+def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, K=None):
+    """out = epilogue(a[:M, :K] @ b[:, :K].T).  a [M, >=K] bf16, b [N, >=K] bf16 (row strides may exceed K)."""
+    lda, ldb, ldc = _rowmajor(a, "a"), _rowmajor(b, "b"), _rowmajor(out, "out")
+    _req(a.dtype == BF16 and b.dtype == BF16, "gemm operands must be bf16")
+    M = a.shape[0] if M is None else M
+    K = min(a.shape[1], b.shape[1]) if K is None else K
+    N = b.shape[0]
+    _req(M <= a.shape[0] and K <= a.shape[1] and K <= b.shape[1], "gemm: M/K exceed operand shapes")
+    want = F32 if epilogue in (EPI_F32, EPI_RESID_F32, EPI_PATCH_F32) else BF16
+    _req(out.dtype == want, f"gemm: out dtype {out.dtype} != {want}")
+    if epilogue == EPI_PATCH_F32:
+        _req(M % 196 == 0 and out.shape[0] >= M // 196 * 197 and out.shape[1] >= N, "gemm(PATCH): out too small")
+    else:
+        _req(out.shape[0] >= M and out.shape[1] >= N, "gemm: out too small")
+    args = EpiArgs()
+    if bias is not None:
+        _req(bias.dtype == F32 and bias.numel() >= N and bias.is_contiguous(), "gemm: bias must be f32 [N]")
+        args.bias = bias.data_ptr()
+    if resid is not None:
+        _req(resid.dtype == F32, "gemm: resid must be f32")
+        need = 197 if epilogue == EPI_PATCH_F32 else M
+        _req(resid.shape[0] >= need and resid.shape[1] >= N, "gemm: resid too small")
+        args.resid = resid.data_ptr()
+        args.ld_resid = _rowmajor(resid, "resid")
+    if aux is not None:
+        _req(aux.dtype == BF16 and aux.shape[0] >= M and aux.shape[1] >= N, "gemm: aux must be bf16 [M, N]")
+        args.aux = aux.data_ptr()
+        args.ld_aux = _rowmajor(aux, "aux")
+    check(_l.load().bsclip_gemm_bf16(_p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, epilogue, ctypes.byref(args),
+                                     _stream()))
+    return out
+
+
+def set_gemm_tile(tile):
+    check(_l.load().bsclip_gemm_set_tile(tile))
+
+
+def layernorm_fwd(x, gamma, beta, eps, y_bf16=None, y_f32=None, lora_a=None, stats=None, M=None):
+    ld_x = _rowmajor(x, "x")
+    H = gamma.numel()
+    M = x.shape[0] if M is None else M
+    _req(x.dtype in (F32, BF16) and x.shape[1] >= H and M <= x.shape[0], "layernorm_fwd: bad x")
+    _req(gamma.dtype == F32 and beta.dtype == F32 and beta.numel() == H, "layernorm_fwd: gamma/beta f32 [H]")
+    ld_y = 0
+    if y_bf16 is not None:
+        ld_y = _rowmajor(y_bf16, "y_bf16")
+        _req(y_bf16.dtype == BF16 and y_bf16.shape[0] >= M and y_bf16.shape[1] >= H + (KPAD if lora_a is not None else 0),
+             "layernorm_fwd: y_bf16 too small")
+    if y_f32 is not None:
+        _req(y_f32.dtype == F32 and y_f32.is_contiguous() and y_f32.shape[0] >= M and y_f32.shape[1] == H,
+             "layernorm_fwd: y_f32 must be contiguous f32 [M, H]")
+    if lora_a is not None:
+        _req(lora_a.dtype == F32 and lora_a.is_contiguous() and tuple(lora_a.shape) == (8, H), "lora_a must be f32 [8,H]")
+    if stats is not None:
+        _req(stats.dtype == F32 and stats.is_contiguous() and stats.numel() >= 2 * M, "stats must be f32 [M,2]")
+    check(_l.load().bsclip_layernorm_fwd(_p(x), ld_x, int(x.dtype == BF16), M, H, _p(gamma), _p(beta), float(eps),
+                                         _p(y_bf16), ld_y, _p(y_f32), _p(lora_a), _p(stats), _stream()))
+
+
+def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lora_a=None, dx_f32=None, dx_bf16=None,
+                  M=None):
+    ld_x = _rowmajor(x, "x")
+    H = gamma.numel()
+    M = x.shape[0] if M is None else M
+    _req(x.dtype in (F32, BF16) and x.shape[1] >= H and M <= x.shape[0], "layernorm_bwd: bad x")
+    _req(stats.dtype == F32 and stats.numel() >= 2 * M, "layernorm_bwd: stats")
+    ld_g = ld_dxb = 0
+    if g_resid is not None:
+        _req(g_resid.dtype == F32 and g_resid.is_contiguous() and g_resid.shape[0] >= M and g_resid.shape[1] == H,
+             "g_resid must be contiguous f32 [M,H]")
+    if g_gemm is not None:
+        ld_g = _rowmajor(g_gemm, "g_gemm")
+        _req(g_gemm.dtype == BF16 and g_gemm.shape[0] >= M and g_gemm.shape[1] >= H, "g_gemm must be bf16 [M,>=H]")
+    if dt is not None:
+        _req(dt.dtype == F32 and dt.is_contiguous() and dt.numel() >= 8 * M, "dt must be f32 [M,8]")
+        _req(lora_a is not None and tuple(lora_a.shape) == (8, H) and lora_a.dtype == F32 and lora_a.is_contiguous(),
+             "lora_a must be f32 [8,H]")
+    if dx_f32 is not None:
+        _req(dx_f32.dtype == F32 and dx_f32.is_contiguous() and dx_f32.shape[0] >= M and dx_f32.shape[1] == H,
+             "dx_f32 must be contiguous f32 [M,H]")
+    if dx_bf16 is not None:
+        ld_dxb = _rowmajor(dx_bf16, "dx_bf16")
+        _req(dx_bf16.dtype == BF16 and dx_bf16.shape[0] >= M and dx_bf16.shape[1] >= H, "dx_bf16 too small")
+    check(_l.load().bsclip_layernorm_bwd(_p(x), ld_x, int(x.dtype == BF16), _p(stats), _p(gamma), M, H, _p(g_resid),
+                                         _p(g_gemm), ld_g, _p(dt), _p(lora_a) if dt is not None else None, int(mode),
+                                         _p(dx_f32), _p(dx_bf16), ld_dxb, _stream()))
+
+
+def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None):
+    ld_qkv, ld_ctx = _rowmajor(qkv, "qkv"), _rowmajor(ctx, "ctx")
+    _req(qkv.dtype == BF16 and ctx.dtype == BF16 and lse.dtype == F32, "attn_fwd dtypes")
+    _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64, "attn_fwd: qkv too small")
+    _req(ctx.shape[0] >= B * S and ctx.shape[1] >= heads * 64 and lse.numel() >= B * heads * S, "attn_fwd: outputs too small")
+    if key_bias is not None:
+        _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
+    check(_l.load().bsclip_attn_fwd(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), ld_ctx, _p(lse),
+                                    _stream()))
+
+
+def attn_bwd(qkv, ctx, dctx, lse, B, S, heads, scale, dqkv, key_bias=None):
+    ld_qkv, ld_ctx, ld_d = _rowmajor(qkv, "qkv"), _rowmajor(ctx, "ctx"), _rowmajor(dqkv, "dqkv")
+    _req(_rowmajor(dctx, "dctx") == ld_ctx, "attn_bwd: ctx and dctx must share a row stride")
+    _req(all(t.dtype == BF16 for t in (qkv, ctx, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
+    _req(min(qkv.shape[0], ctx.shape[0], dctx.shape[0], dqkv.shape[0]) >= B * S, "attn_bwd: rows")
+    _req(qkv.shape[1] >= 3 * heads * 64 and dqkv.shape[1] >= 3 * heads * 64 and ctx.shape[1] >= heads * 64
+         and dctx.shape[1] >= heads * 64 and lse.numel() >= B * heads * S, "attn_bwd: cols")
+    check(_l.load().bsclip_attn_bwd(_p(qkv), ld_qkv, _p(ctx), _p(dctx), ld_ctx, _p(lse), B, S, heads, _p(key_bias),
+                                    float(scale), _p(dqkv), ld_d, _stream()))
+
+
+def im2col_patch16(image, cols):
+    B = image.shape[0]
+    _req(image.dtype == F32 and image.is_contiguous() and tuple(image.shape[1:]) == (3, 224, 224), "image f32 [B,3,224,224]")
+    _req(cols.dtype == BF16 and cols.is_contiguous() and cols.shape[0] >= B * 196 and cols.shape[1] == 768, "cols bf16 [B*196,768]")
+    check(_l.load().bsclip_im2col_patch16(_p(image), B, _p(cols), _stream()))
+
+
+def vit_cls_rows(x, cls_token, pos_embed, B, S, H):
+    _req(x.dtype == F32 and x.is_contiguous() and x.numel() >= B * S * H, "x f32 [B*S,H]")
+    _req(cls_token.numel() == H and pos_embed.numel() >= H and cls_token.dtype == F32 and pos_embed.dtype == F32, "cls/pos")
+    check(_l.load().bsclip_vit_cls_rows(_p(x), _p(cls_token), _p(pos_embed), B, S, H, _stream()))
+
+
+def bert_embed(ids, type_ids, word, pos, typ, out):
+    B, S = ids.shape
+    H = word.shape[1]
+    _req(ids.dtype == torch.int64 and ids.is_contiguous(), "ids int64 [B,S]")
+    if type_ids is not None:
+        _req(type_ids.dtype == torch.int64 and type_ids.is_contiguous() and type_ids.shape == ids.shape, "type_ids")
+    _req(all(t.dtype == F32 and t.is_contiguous() for t in (word, pos, typ, out)), "bert_embed tables f32")
+    _req(pos.shape[0] >= S and pos.shape[1] == H and typ.shape[0] >= 2 and typ.shape[1] == H, "bert_embed: pos/type shapes")
+    _req(out.shape[0] >= B * S and out.shape[1] == H, "bert_embed: out f32 [B*S,H]")
+    check(_l.load().bsclip_bert_embed(_p(ids), _p(type_ids), B, S, H, _p(word), word.shape[0], _p(pos), _p(typ), _p(out),
+                                      _stream()))
+
+
+def softmax_meanpool_fwd(logits, B, S, pooled, stats):
+    C = logits.shape[1]
+    _req(logits.dtype == F32 and logits.is_contiguous() and logits.shape[0] >= B * S, "logits f32 [B*S,C]")
+    _req(pooled.dtype == F32 and pooled.is_contiguous() and pooled.shape[0] >= B and pooled.shape[1] == C, "pooled")
+    _req(stats.dtype == F32 and stats.numel() >= 2 * B * S, "stats")
+    check(_l.load().bsclip_softmax_meanpool_fwd(_p(logits), B, S, C, _p(pooled), _p(stats), _stream()))
+
+
+def softmax_meanpool_bwd(logits, stats, d_pooled, B, S, dlogits):
+    C = logits.shape[1]
+    _req(logits.dtype == F32 and logits.is_contiguous() and d_pooled.dtype == F32 and d_pooled.is_contiguous(), "dtypes")
+    _req(d_pooled.shape[0] >= B and d_pooled.shape[1] == C, "d_pooled f32 [B,C]")
+    _req(dlogits.dtype == BF16 and dlogits.shape[0] >= B * S and dlogits.shape[1] >= C, "dlogits bf16 [B*S,C]")
+    check(_l.load().bsclip_softmax_meanpool_bwd(_p(logits), _p(stats), _p(d_pooled), B, S, C, _p(dlogits),
+                                                _rowmajor(dlogits, "dlogits"), _stream()))
+
+
+def meanpool_tokens_fwd(x, B, S, out):
+    H = x.shape[1]
+    _req(x.dtype == F32 and x.is_contiguous() and x.shape[0] >= B * S, "x f32 [B*S,H]")
+    _req(out.dtype == BF16 and out.shape[0] >= B and out.shape[1] >= H, "out bf16 [B,H]")
+    check(_l.load().bsclip_meanpool_tokens_fwd(_p(x), B, S, H, _p(out), _rowmajor(out, "out"), _stream()))
+
+
+def meanpool_tokens_bwd(d_pooled, B, S, dx):
+    H = dx.shape[1]
+    _req(d_pooled.dtype == F32 and d_pooled.shape[0] >= B and d_pooled.shape[1] >= H, "d_pooled f32 [B,>=H]")
+    _req(dx.dtype == F32 and dx.is_contiguous() and dx.shape[0] >= B * S, "dx f32 [B*S,H]")
+    check(_l.load().bsclip_meanpool_tokens_bwd(_p(d_pooled), _rowmajor(d_pooled, "d_pooled"), B, S, H, _p(dx), _stream()))
+
+
+def l2norm_fwd(x, y, inv_norm):
+    M, D = x.shape
+    _req(all(t.dtype == F32 and t.is_contiguous() for t in (x, y, inv_norm)), "l2norm_fwd f32 contiguous")
+    _req(y.shape == x.shape and inv_norm.numel() >= M, "l2norm_fwd shapes")
+    check(_l.load().bsclip_l2norm_fwd(_p(x), M, D, _p(y), _p(inv_norm), _stream()))
+
+
+def l2norm_bwd(y, inv_norm, dy, dx):
+    M, D = y.shape
+    _req(all(t.dtype == F32 and t.is_contiguous() for t in (y, inv_norm, dy, dx)), "l2norm_bwd f32 contiguous")
+    _req(dy.shape == y.shape and dx.shape == y.shape and inv_norm.numel() >= M, "l2norm_bwd shapes")
+    check(_l.load().bsclip_l2norm_bwd(_p(y), _p(inv_norm), _p(dy), M, D, _p(dx), _stream()))
+
+
+def infonce_workspace_floats(N, nmod):
+    n = _l.load().bsclip_infonce_workspace_floats(N, nmod)
+    if n < 0:
+        raise ValueError("Too less element for calculating the contrastive loss." if nmod < 2 else "bad N/nmod")
+    return n
+
+
+def infonce_fwd_bwd(zs, labels, scale, loss_out, dzs=None, row0=0, n_local=None, workspace=None):
+    """zs: list of 2-3 f32 [N, 768]; dzs: list of f32 [n_local, 768] (or None for loss only)."""
+    nmod = len(zs)
+    if nmod < 2:
+        raise ValueError("Too less element for calculating the contrastive loss.")
+    N, D = zs[0].shape
+    n_local = N if n_local is None else n_local
+    _req(all(z.dtype == F32 and z.is_contiguous() and tuple(z.shape) == (N, D) for z in zs), "zs f32 [N,D]")
+    _req(labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == N, "labels int64 [N]")
+    _req(loss_out.dtype == F32 and loss_out.numel() >= 1, "loss_out f32 [1]")
+    need = infonce_workspace_floats(N, nmod)
+    _req(workspace is not None and workspace.dtype == F32 and workspace.numel() >= need and workspace.is_contiguous(),
+         f"workspace must be f32 with >= {need} elements")
+    zp = (ctypes.c_void_p * nmod)(*[z.data_ptr() for z in zs])
+    dzp = None
+    if dzs is not None:
+        _req(len(dzs) == nmod and all(d.dtype == F32 and d.is_contiguous() and tuple(d.shape) == (n_local, D) for d in dzs),
+             "dzs f32 [n_local, D]")
+        dzp = (ctypes.c_void_p * nmod)(*[d.data_ptr() for d in dzs])
+    check(_l.load().bsclip_infonce_fwd_bwd(zp, nmod, _p(labels), N, D, float(scale), row0, n_local, _p(loss_out), dzp,
+                                           _p(workspace), _stream()))
+
+
+def lora_grad(dqkv, h_aug, M, H, lora_b, dt, dA, dBq, dBv):
+    _req(dqkv.dtype == BF16 and h_aug.dtype == BF16, "lora_grad: bf16 inputs")
+    _req(dqkv.shape[0] >= M and dqkv.shape[1] >= 3 * H and h_aug.shape[0] >= M and h_aug.shape[1] >= H + 8, "lora_grad shapes")
+    _req(lora_b.dtype == F32 and lora_b.is_contiguous() and tuple(lora_b.shape) == (2, H, 4), "lora_b f32 [2,H,4]")
+    _req(dt.dtype == F32 and dt.is_contiguous() and dt.numel() >= 8 * M, "dt f32 [M,8]")
+    _req(dA.dtype == F32 and dA.is_contiguous() and tuple(dA.shape) == (8, H), "dA f32 [8,H]")
+    _req(all(t.dtype == F32 and t.is_contiguous() and tuple(t.shape) == (H, 4) for t in (dBq, dBv)), "dB f32 [H,4]")
+    check(_l.load().bsclip_lora_grad(_p(dqkv), _rowmajor(dqkv, "dqkv"), _p(h_aug), _rowmajor(h_aug, "h_aug"), M, H,
+                                     _p(lora_b), _p(dt), _p(dA), _p(dBq), _p(dBv), _stream()))
+
+
+def colsum(g, M, N, out):
+    _req(g.dtype in (BF16, F32) and g.shape[0] >= M and g.shape[1] >= N, "colsum: g")
+    _req(out.dtype == F32 and out.is_contiguous() and out.numel() >= N, "colsum: out f32 [N]")
+    check(_l.load().bsclip_colsum(_p(g), _rowmajor(g, "g"), int(g.dtype == BF16), M, N, _p(out), _stream()))
+
+
+def transpose_bf16(src, R, C, dst):
+    _req(src.dtype == BF16 and dst.dtype == BF16, "transpose_bf16 dtypes")
+    _req(src.shape[0] >= R and src.shape[1] >= C and dst.shape[0] >= C and dst.shape[1] >= R, "transpose_bf16 shapes")
+    check(_l.load().bsclip_transpose_bf16(_p(src), _rowmajor(src, "src"), R, C, _p(dst), _rowmajor(dst, "dst"), _stream()))
+
+
+def cast_f32_bf16(src, dst):
+    _req(src.dtype == F32 and dst.dtype == BF16 and src.is_contiguous() and dst.is_contiguous()
+         and dst.numel() >= src.numel(), "cast_f32_bf16")
+    check(_l.load().bsclip_cast_f32_bf16(_p(src), src.numel(), _p(dst), _stream()))
+
+
+def waug_set_lora(w_aug, H, bq, bv):
+    _req(w_aug.dtype == BF16 and w_aug.shape[0] >= 3 * H and w_aug.shape[1] >= H + KPAD, "w_aug bf16 [3H, H+KPAD]")
+    _req(all(t.dtype == F32 and t.is_contiguous() and tuple(t.shape) == (H, 4) for t in (bq, bv)), "bq/bv f32 [H,4]")
+    check(_l.load().bsclip_waug_set_lora(_p(w_aug), _rowmajor(w_aug, "w_aug"), H, _p(bq), _p(bv), _stream()))
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _req(all(t.dtype == F32 and t.is_contiguous() and t.numel() == p.numel() for t in (p, g, m, v)), "adamw: flat f32 buffers")
+    check(_l.load().bsclip_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                      float(eps), float(weight_decay), int(step), float(grad_scale), _stream()))

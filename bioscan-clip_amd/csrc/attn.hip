@@ -1,0 +1,380 @@
+// Self-attention forward / backward for short sequences (S <= 224, head_dim 64) on gfx950.
+//
+// Replaces timm Attention.forward (softmax(q k^T * 64^-0.5) v; reached from image_encoder.py:108-109) and HF
+// BertSelfAttention (same, plus the additive key mask used by the text tower, language_encoder.py:89).
+//
+// One workgroup per (batch, head); the whole K / V (or Q / dO) of that head lives in LDS, one 64-lane wave per
+// 32-row block.  All five/seven products run on v_mfma_f32_32x32x16_bf16.  Score tiles are computed TRANSPOSED
+// (key on the accumulator rows, query on the lane) so that
+//   * the softmax reduction over keys is in-lane (16 registers per tile) plus one xor-32 shuffle, and
+//   * the probability tile feeds the next MFMA straight from the accumulator registers ("accumulator tile as the
+//     next MFMA's operand", cdna_hip_programming.md 3): P^T never goes through LDS.
+// The operand that must be k-strided for that second product (V^T, Q^T, dO^T, K^T) is staged once per workgroup as a
+// transposed LDS image with rows padded by 8 B, which makes the paired ds_read_b64 fragment reads conflict-free.
+// Backward runs two phases in one launch: key-owner waves produce dK/dV, then query-owner waves produce dQ, so
+// nothing is accumulated across waves (no atomics, bitwise reproducible).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// registers [8*s2, 8*s2+8) of an accumulator tile -> bf16x8 operand fragment (element j = register 8*s2 + j)
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
+    u32x4 u;
+    u[0] = pack_bf2(x[8 * s2 + 0], x[8 * s2 + 1]);
+    u[1] = pack_bf2(x[8 * s2 + 2], x[8 * s2 + 3]);
+    u[2] = pack_bf2(x[8 * s2 + 4], x[8 * s2 + 5]);
+    u[3] = pack_bf2(x[8 * s2 + 6], x[8 * s2 + 7]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+constexpr int ROWB = 128;  // bytes per row of a row-major [rows][64] bf16 tile
+__host__ __device__ constexpr int tstride(int SP) { return SP * 2 + 8; }  // bytes per row of a transposed [64][SP] tile
+
+// Row-major tile, 16-B chunk index XOR-swizzled with (row>>1)&7: conflict-free ds_read_b128 for the 32x32x16 A operand.
+__device__ __forceinline__ int rm_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Stage rows [0,S) of a [S][64] bf16 matrix (row stride ld elements) into LDS: row-major (dst_rm, nullable) and/or
+// transposed (dst_t, nullable).  Rows >= S are zero-filled.
+template <int SP>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int S, char* dst_rm, char* dst_t,
+                                           int tid, int nthreads) {
+    for (int it = tid; it < SP * 8; it += nthreads) {
+        const int row = it >> 3, c = it & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < S) v = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + c * 8);
+        if (dst_rm) *reinterpret_cast<u32x4*>(dst_rm + rm_off(row, c)) = v;
+        if (dst_t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<bf16_t*>(dst_t + (c * 8 + 2 * i) * tstride(SP) + row * 2) = (bf16_t)(v[i] & 0xffff);
+                *reinterpret_cast<bf16_t*>(dst_t + (c * 8 + 2 * i + 1) * tstride(SP) + row * 2) = (bf16_t)(v[i] >> 16);
+            }
+        }
+    }
+}
+
+// A-operand fragment of a row-major tile: rows r0 + (lane&31), k = 16*ks + 8*(lane>>5) + j
+__device__ __forceinline__ bf16x8 frag_rm(const char* tile, int r0, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + rm_off(r0 + (lane & 31), 2 * ks + (lane >> 5)));
+}
+// A-operand fragment of a transposed tile for the accumulator-as-B product: rows d0 + (lane&31); element j is column
+// c0 + 8*(j>>2) + 4*(lane>>5) + (j&3)  (matches the k order of pack8()).
+template <int SP>
+__device__ __forceinline__ bf16x8 frag_t(const char* tile, int d0, int c0, int lane) {
+    const char* p = tile + (d0 + (lane & 31)) * tstride(SP) + (c0 + 4 * (lane >> 5)) * 2;
+    const uint2 lo = *reinterpret_cast<const uint2*>(p);
+    const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+    u32x4 u = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(bf16x8, u);
+}
+// B-operand fragment straight from global: row (clamped) of a [S][64] matrix, k = 16*ks + 8*(lane>>5) + j
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, int ld, int row, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + ks * 16 + 8 * (lane >> 5));
+}
+// accumulator row index of register r for lane half h (C/D map of the 32x32 MFMA)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// store a [64 (d) x 32 (token on lane)] result held as 2 accumulator tiles into out[token][col0 + d]
+__device__ __forceinline__ void store_dt(const f32x16 (&acc)[2], float mul, bf16_t* out_row, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 o;
+            o.x = pack_bf2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
+            o.y = pack_bf2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+            *reinterpret_cast<uint2*>(out_row + 32 * dt + 8 * g + 4 * h) = o;
+        }
+}
+
+template <int NB>
+__global__ __launch_bounds__(NB * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S, int heads,
+                                                            const float* __restrict__ key_bias, float scale,
+                                                            bf16_t* __restrict__ ctx, int ld_ctx,
+                                                            float* __restrict__ lse) {
+    constexpr int SP = NB * 32;
+    __shared__ __attribute__((aligned(16))) char smem[SP * ROWB + 64 * tstride(SP) + SP * 4];
+    char* sK = smem;
+    char* sVt = smem + SP * ROWB;
+    float* sBias = reinterpret_cast<float*>(smem + SP * ROWB + 64 * tstride(SP));
+
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = heads * 64;
+    const bf16_t* qb = qkv + (size_t)b * S * ld + hd * 64;
+    const bf16_t* kb = qb + HW;
+    const bf16_t* vb = kb + HW;
+
+    stage_tile<SP>(kb, ld, S, sK, nullptr, tid, NB * 64);
+    stage_tile<SP>(vb, ld, S, nullptr, sVt, tid, NB * 64);
+    for (int k = tid; k < SP; k += NB * 64)
+        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
+
+    const int q0 = wave * 32;
+    const int qrow = min(q0 + (lane & 31), S - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qb, ld, qrow, ks, lane);
+    __syncthreads();
+
+    // S^T tiles: rows = keys, lane = query
+    f32x16 p[NB];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NB; ++kt) {
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = mfma32(frag_rm(sK, 32 * kt, ks, lane), qf[ks], acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s = acc[4 * g + i] * scale + bias[i];
+                acc[4 * g + i] = s;
+                m = fmaxf(m, s);
+            }
+        }
+        p[kt] = acc;
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NB; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __expf(p[kt][r] - m);
+            p[kt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+
+    // O^T[d, query] = sum_key V^T[d, key] P^T[key, query]
+    f32x16 o[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kt = 0; kt < NB; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = pack8(p[kt], s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_t<SP>(sVt, 32 * dt, 32 * kt + 16 * s2, lane), pb, o[dt]);
+        }
+
+    const int q = q0 + (lane & 31);
+    if (q < S) {
+        store_dt(o, 1.0f / sum, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
+        if (h == 0) lse[((size_t)b * heads + hd) * S + q] = m + __logf(sum);
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
+                                                            const bf16_t* __restrict__ ctx,
+                                                            const bf16_t* __restrict__ dctx, int ld_ctx,
+                                                            const float* __restrict__ lse, int S, int heads,
+                                                            const float* __restrict__ key_bias, float scale,
+                                                            bf16_t* __restrict__ dqkv, int ld_d) {
+    constexpr int SP = NB * 32;
+    constexpr int RM = SP * ROWB, TR = 64 * tstride(SP);
+    __shared__ __attribute__((aligned(16))) char smem[2 * RM + 2 * TR + 3 * SP * 4];
+    char* sR0 = smem;            // phase A: Q   | phase B: K
+    char* sR1 = smem + RM;       // phase A: dO  | phase B: V
+    char* sT0 = smem + 2 * RM;   // phase A: Q^T | phase B: K^T
+    char* sT1 = sT0 + TR;        // phase A: dO^T
+    float* sLse = reinterpret_cast<float*>(sT1 + TR);
+    float* sDelta = sLse + SP;
+    float* sBias = sDelta + SP;
+
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NT = NB * 64;
+    const int HW = heads * 64;
+    const bf16_t* qb = qkv + (size_t)b * S * ld + hd * 64;
+    const bf16_t* kb = qb + HW;
+    const bf16_t* vb = kb + HW;
+    const bf16_t* ob = ctx + (size_t)b * S * ld_ctx + hd * 64;
+    const bf16_t* dob = dctx + (size_t)b * S * ld_ctx + hd * 64;
+    bf16_t* dqb = dqkv + (size_t)b * S * ld_d + hd * 64;
+
+    // ---------------- phase A staging: Q, dO (row-major + transposed), lse, delta, bias ----------------
+    stage_tile<SP>(qb, ld, S, sR0, sT0, tid, NT);
+    stage_tile<SP>(dob, ld_ctx, S, sR1, sT1, tid, NT);
+    for (int it = tid; it < SP * 8; it += NT) {  // delta[q] = sum_d dO[q,d] O[q,d]; 8 consecutive lanes share a row
+        const int row = it >> 3, c = it & 7;
+        float d = 0.f;
+        if (row < S) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(dob + (size_t)row * ld_ctx + c * 8);
+            const u32x4 o = *reinterpret_cast<const u32x4*>(ob + (size_t)row * ld_ctx + c * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                d += bf2f(a[i] & 0xffff) * bf2f(o[i] & 0xffff) + bf2f(a[i] >> 16) * bf2f(o[i] >> 16);
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (c == 0) sDelta[row] = d;
+    }
+    for (int k = tid; k < SP; k += NT) {
+        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
+        sLse[k] = (k < S) ? lse[((size_t)b * heads + hd) * S + k] : INFINITY;  // padded queries -> p = 0
+    }
+    {
+        // ---------------- phase A: this wave owns keys [k0, k0+32): dV, dK ----------------
+        const int k0 = wave * 32;
+        const int krow = min(k0 + (lane & 31), S - 1);
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = frag_global(kb, ld, krow, ks, lane);
+            vf[ks] = frag_global(vb, ld, krow, ks, lane);
+        }
+        __syncthreads();
+        const float bias_k = sBias[k0 + (lane & 31)];
+        f32x16 dv[2] = {zero16(), zero16()}, dk[2] = {zero16(), zero16()};
+#pragma unroll 1
+        for (int qt = 0; qt < NB; ++qt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(frag_rm(sR0, 32 * qt, ks, lane), kf[ks], s);    // S[q, key]
+                dp = mfma32(frag_rm(sR1, 32 * qt, ks, lane), vf[ks], dp);  // dP[q, key]
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * g + 4 * h);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + 32 * qt + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pr = __expf(s[4 * g + i] * scale + bias_k - l4[i]);
+                    s[4 * g + i] = pr;                                        // P
+                    dp[4 * g + i] = pr * (dp[4 * g + i] - d4[i]) * scale;     // dS (scaled)
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = pack8(s, s2), dsb = pack8(dp, s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = mfma32(frag_t<SP>(sT1, 32 * dt, 32 * qt + 16 * s2, lane), pb, dv[dt]);   // dO^T P
+                    dk[dt] = mfma32(frag_t<SP>(sT0, 32 * dt, 32 * qt + 16 * s2, lane), dsb, dk[dt]);  // Q^T dS
+                }
+            }
+        }
+        const int key = k0 + (lane & 31);
+        if (key < S) {
+            store_dt(dk, 1.0f, dqb + (size_t)key * ld_d + HW, lane);
+            store_dt(dv, 1.0f, dqb + (size_t)key * ld_d + 2 * HW, lane);
+        }
+    }
+    __syncthreads();
+    // ---------------- phase B staging: K, V row-major, K^T ----------------
+    stage_tile<SP>(kb, ld, S, sR0, sT0, tid, NT);
+    stage_tile<SP>(vb, ld, S, sR1, nullptr, tid, NT);
+    {
+        // ---------------- phase B: this wave owns queries [q0, q0+32): dQ ----------------
+        const int q0 = wave * 32;
+        const int qrow = min(q0 + (lane & 31), S - 1);
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = frag_global(qb, ld, qrow, ks, lane);
+            dof[ks] = frag_global(dob, ld_ctx, qrow, ks, lane);
+        }
+        __syncthreads();
+        const float lse_q = sLse[q0 + (lane & 31)];
+        const float delta_q = sDelta[q0 + (lane & 31)];
+        f32x16 dq[2] = {zero16(), zero16()};
+#pragma unroll 1
+        for (int kt = 0; kt < NB; ++kt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);     // S^T[key, q]
+                dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);  // dP^T[key, q]
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pr = __expf(s[4 * g + i] * scale + b4[i] - lse_q);
+                    dp[4 * g + i] = pr * (dp[4 * g + i] - delta_q) * scale;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 dsb = pack8(dp, s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = mfma32(frag_t<SP>(sT0, 32 * dt, 32 * kt + 16 * s2, lane), dsb, dq[dt]);  // K^T dS^T
+            }
+        }
+        const int q = q0 + (lane & 31);
+        if (q < S) store_dt(dq, 1.0f, dqb + (size_t)q * ld_d, lane);
+    }
+}
+
+}  // namespace
+
+#define ATTN_FWD_CASE(NBV)                                                                                      \
+    case NBV:                                                                                                   \
+        hipLaunchKernelGGL((attn_fwd_kernel<NBV>), dim3(B * heads), dim3(NBV * 64), 0, s,                       \
+                           static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,                  \
+                           static_cast<bf16_t*>(ctx), ld_ctx, lse);                                             \
+        break;
+
+extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias,
+                               float scale, void* ctx, int ld_ctx, float* lse, void* stream) {
+    BSCLIP_REQUIRE(qkv && ctx && lse, "bsclip_attn_fwd: null pointer");
+    BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_fwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
+    BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_ctx >= heads * 64 && ld_ctx % 4 == 0,
+                   "bsclip_attn_fwd: ld_qkv=%d ld_ctx=%d", ld_qkv, ld_ctx);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch ((S + 31) / 32) {
+        ATTN_FWD_CASE(1) ATTN_FWD_CASE(2) ATTN_FWD_CASE(3) ATTN_FWD_CASE(4) ATTN_FWD_CASE(5) ATTN_FWD_CASE(6)
+        ATTN_FWD_CASE(7)
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+#define ATTN_BWD_CASE(NBV)                                                                                       \
+    case NBV:                                                                                                    \
+        hipLaunchKernelGGL((attn_bwd_kernel<NBV>), dim3(B * heads), dim3(NBV * 64), 0, s,                        \
+                           static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(ctx),             \
+                           static_cast<const bf16_t*>(dctx), ld_ctx, lse, S, heads, key_bias, scale,             \
+                           static_cast<bf16_t*>(dqkv), ld_dqkv);                                                 \
+        break;
+
+extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* ctx, const void* dctx, int ld_ctx,
+                               const float* lse, int B, int S, int heads, const float* key_bias, float scale,
+                               void* dqkv, int ld_dqkv, void* stream) {
+    BSCLIP_REQUIRE(qkv && ctx && dctx && lse && dqkv, "bsclip_attn_bwd: null pointer");
+    BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_bwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
+    BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_dqkv >= 3 * heads * 64 && ld_dqkv % 4 == 0 &&
+                       ld_ctx >= heads * 64 && ld_ctx % 8 == 0,
+                   "bsclip_attn_bwd: ld_qkv=%d ld_dqkv=%d ld_ctx=%d", ld_qkv, ld_dqkv, ld_ctx);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch ((S + 31) / 32) {
+        ATTN_BWD_CASE(1) ATTN_BWD_CASE(2) ATTN_BWD_CASE(3) ATTN_BWD_CASE(4) ATTN_BWD_CASE(5) ATTN_BWD_CASE(6)
+        ATTN_BWD_CASE(7)
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}

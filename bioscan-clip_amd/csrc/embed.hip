@@ -1,0 +1,174 @@
+// HBM-bound data-movement kernels around the encoders (gfx950): patch im2col, cls rows, BERT embedding sums,
+// bf16 transpose, f32->bf16 cast, LoRA-B refresh of the augmented QKV weight.  16-B accesses, coalesced on the
+// write side.  Reference sites: timm PatchEmbed / cls_token / pos_embed (via image_encoder.py:108-109), HF
+// BertEmbeddings (via dna_encoder.py:105, language_encoder.py:89).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// out[(b*196 + py*14 + px), c*256 + ky*16 + kx] = image[b, c, py*16+ky, px*16+kx]; one thread = 8 output columns
+__global__ __launch_bounds__(256) void im2col_patch16_kernel(const float* __restrict__ img, int B,
+                                                              bf16_t* __restrict__ out) {
+    const long total = (long)B * 196 * 96;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const int chunk = (int)(it % 96);
+        const long row = it / 96;
+        const int b = (int)(row / 196), p = (int)(row % 196);
+        const int py = p / 14, px = p % 14;
+        const int col = chunk * 8;
+        const int c = col >> 8, ky = (col >> 4) & 15, kx0 = col & 15;
+        const float* src = img + (((size_t)b * 3 + c) * 224 + (py * 16 + ky)) * 224 + px * 16 + kx0;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(src + 4);
+        u32x4 o;
+        o[0] = pack_bf2(a[0], a[1]);
+        o[1] = pack_bf2(a[2], a[3]);
+        o[2] = pack_bf2(d[0], d[1]);
+        o[3] = pack_bf2(d[2], d[3]);
+        *reinterpret_cast<u32x4*>(out + (size_t)row * 768 + col) = o;
+    }
+}
+
+__global__ void vit_cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                    const float* __restrict__ pos, int B, int S, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, c = i % H;
+    x[(size_t)b * S * H + c] = cls[c] + pos[c];
+}
+
+// one wave per token row
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids,
+                                                          const int64_t* __restrict__ type_ids, int M, int S, int H,
+                                                          const float* __restrict__ word, int vocab,
+                                                          const float* __restrict__ pos, const float* __restrict__ type,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (row >= M) return;
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // never read outside the table
+    const int t = row % S;
+    const long tt = type_ids ? type_ids[row] : 0;
+    const float* w = word + (size_t)id * H;
+    const float* p = pos + (size_t)t * H;
+    const float* ty = type + (size_t)(tt ? 1 : 0) * H;
+    for (int c = lane * 4; c < H; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + c) + *reinterpret_cast<const f32x4*>(p + c) +
+                        *reinterpret_cast<const f32x4*>(ty + c);
+        *reinterpret_cast<f32x4*>(out + (size_t)row * H + c) = v;
+    }
+}
+
+// out[C,R] = in[R,C]^T through a 64x64 LDS tile (+1 pad column against bank conflicts)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int ld_in, int R, int C,
+                                                              bf16_t* __restrict__ out, int ld_out) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, long n,
+                                                             bf16_t* __restrict__ out) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + 4 * i);
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(out + 4 * i) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        out[i] = f2bf(in[i]);
+    }
+}
+
+// W_aug rows [0,H): cols [H,H+4) = B_q[n,:]; rows [2H,3H): cols [H+4,H+8) = B_v[n,:]
+__global__ void waug_set_lora_kernel(bf16_t* __restrict__ w, int ld_w, int H, const float* __restrict__ bq,
+                                     const float* __restrict__ bv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * H) return;
+    const bool is_v = i >= H;
+    const int n = is_v ? i - H : i;
+    const f32x4 v = *reinterpret_cast<const f32x4*>((is_v ? bv : bq) + (size_t)n * 4);
+    uint2 o;
+    o.x = pack_bf2(v[0], v[1]);
+    o.y = pack_bf2(v[2], v[3]);
+    bf16_t* dst = w + (size_t)(is_v ? 2 * H + n : n) * ld_w + H + (is_v ? 4 : 0);
+    *reinterpret_cast<uint2*>(dst) = o;
+}
+
+}  // namespace
+
+extern "C" int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16, void* stream) {
+    BSCLIP_REQUIRE(image && cols_bf16 && B > 0, "bsclip_im2col_patch16: bad args");
+    const long total = (long)B * 196 * 96;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(im2col_patch16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       image, B, static_cast<bf16_t*>(cols_bf16));
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_vit_cls_rows(float* x, const float* cls_token, const float* pos_embed, int B, int S, int H,
+                                   void* stream) {
+    BSCLIP_REQUIRE(x && cls_token && pos_embed && B > 0, "bsclip_vit_cls_rows: bad args");
+    hipLaunchKernelGGL(vit_cls_rows_kernel, dim3(ceil_div(B * H, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, cls_token, pos_embed, B, S, H);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_bert_embed(const int64_t* ids, const int64_t* type_ids, int B, int S, int H, const float* word,
+                                 int vocab, const float* pos, const float* type, float* out, void* stream) {
+    BSCLIP_REQUIRE(ids && word && pos && type && out && B > 0 && S > 0 && H % 4 == 0 && vocab > 0,
+                   "bsclip_bert_embed: bad args");
+    const int M = B * S;
+    hipLaunchKernelGGL(bert_embed_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), ids,
+                       type_ids, M, S, H, word, vocab, pos, type, out);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream) {
+    BSCLIP_REQUIRE(in && out && R > 0 && C > 0 && ld_in >= C && ld_out >= R, "bsclip_transpose_bf16: bad args");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(C, 64), ceil_div(R, 64)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(in), ld_in, R, C,
+                       static_cast<bf16_t*>(out), ld_out);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_cast_f32_bf16(const float* in, int64_t n, void* out, void* stream) {
+    BSCLIP_REQUIRE(in && out && n > 0, "bsclip_cast_f32_bf16: bad args");
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                       (long)n, static_cast<bf16_t*>(out));
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_waug_set_lora(void* w_aug, int ld_w, int H, const float* lora_bq, const float* lora_bv,
+                                    void* stream) {
+    BSCLIP_REQUIRE(w_aug && lora_bq && lora_bv && ld_w >= H + BSCLIP_KPAD && ld_w % 4 == 0 && H % 4 == 0,
+                   "bsclip_waug_set_lora: bad args");
+    hipLaunchKernelGGL(waug_set_lora_kernel, dim3(ceil_div(2 * H, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<bf16_t*>(w_aug), ld_w, H, lora_bq, lora_bv);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}

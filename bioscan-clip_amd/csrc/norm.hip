@@ -1,0 +1,358 @@
+// LayerNorm forward/backward and L2-normalise for gfx950.  HBM-bound row kernels: one 64-lane wave per row,
+// 16-B coalesced loads, statistics in f32 via wavefront shuffles, everything a consumer needs fused in:
+//   fwd: bf16 GEMM operand, optional f32 residual copy, (mean,rstd), and the rank-8 LoRA projection t = y A^T
+//        written into the K-augmentation columns of the operand (so the LoRA branch costs no extra pass);
+//   bwd: gradient assembly (f32 residual grad + bf16 GEMM grad + dt . A), dx in f32 and as the next bf16 operand.
+// Reference arithmetic replaced: timm norm1/norm2/norm (eps 1e-6) reached from image_encoder.py:108-109; HF
+// BertLayerNorm (eps 1e-12) reached from dna_encoder.py:105 / language_encoder.py:89; F.normalize at
+// simple_clip.py:34,47,49.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_BLOCK = 256;  // 4 waves = 4 rows in flight per workgroup
+
+template <int H>
+struct RowVec {
+    static constexpr int NV = H / 256;  // float4 chunks per lane (768 -> 3, 512 -> 2)
+};
+
+// Reduce 8 per-lane partial sums over the 64 lanes with 10 shuffles (halving the live set each step).
+// On return every lane holds, in its return value, the total of index r = ((lane>>5)&1)*4 + ((lane>>4)&1)*2 + ((lane>>3)&1).
+__device__ __forceinline__ float reduce8(float (&p)[8], int lane) {
+    float q[4];
+    const bool hi5 = lane & 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float send = hi5 ? p[i] : p[i + 4];
+        const float keep = hi5 ? p[i + 4] : p[i];
+        q[i] = keep + __shfl_xor(send, 32, 64);
+    }
+    float r2[2];
+    const bool hi4 = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float send = hi4 ? q[i] : q[i + 2];
+        const float keep = hi4 ? q[i + 2] : q[i];
+        r2[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    const bool hi3 = lane & 8;
+    float v = (hi3 ? r2[1] : r2[0]) + __shfl_xor(hi3 ? r2[0] : r2[1], 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+template <int H, bool X_BF16>
+__device__ __forceinline__ void load_row(const void* x, int ld_x, int row, int lane, f32x4 (&v)[H / 256]) {
+    constexpr int NV = H / 256;
+    if constexpr (X_BF16) {
+        const bf16_t* p = static_cast<const bf16_t*>(x) + (size_t)row * ld_x;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const uint2 u = *reinterpret_cast<const uint2*>(p + j * 256 + lane * 4);
+            v[j] = f32x4{bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
+        }
+    } else {
+        const float* p = static_cast<const float*>(x) + (size_t)row * ld_x;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + j * 256 + lane * 4);
+    }
+}
+
+template <int H, bool X_BF16, bool LORA>
+__global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __restrict__ x, int ld_x, int M,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps,
+                                                                  bf16_t* __restrict__ y_bf16, int ld_y,
+                                                                  float* __restrict__ y_f32,
+                                                                  const float* __restrict__ lora_a,
+                                                                  float* __restrict__ stats) {
+    constexpr int NV = H / 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * LN_BLOCK) >> 6;
+
+    f32x4 g[NV], b[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        g[j] = *reinterpret_cast<const f32x4*>(gamma + j * 256 + lane * 4);
+        b[j] = *reinterpret_cast<const f32x4*>(beta + j * 256 + lane * 4);
+    }
+    f32x4 a[LORA ? 8 : 1][NV];
+    if constexpr (LORA) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) a[r][j] = *reinterpret_cast<const f32x4*>(lora_a + r * H + j * 256 + lane * 4);
+    }
+
+    for (int row = wave; row < M; row += nwaves) {
+        f32x4 v[NV];
+        load_row<H, X_BF16>(x, ld_x, row, lane, v);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        const float mean = wave_sum(s) * (1.0f / H);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] -= mean;
+            ss += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+        }
+        const float var = wave_sum(ss) * (1.0f / H);
+        const float rstd = rsqrtf(var + eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = v[j] * rstd * g[j] + b[j];
+
+        if (stats && lane == 0) {
+            stats[2 * (size_t)row] = mean;
+            stats[2 * (size_t)row + 1] = rstd;
+        }
+        if (y_f32) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                *reinterpret_cast<f32x4*>(y_f32 + (size_t)row * H + j * 256 + lane * 4) = v[j];
+        }
+        if (y_bf16) {
+            bf16_t* yr = y_bf16 + (size_t)row * ld_y;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                uint2 o;
+                o.x = pack_bf2(v[j][0], v[j][1]);
+                o.y = pack_bf2(v[j][2], v[j][3]);
+                *reinterpret_cast<uint2*>(yr + j * 256 + lane * 4) = o;
+            }
+            if constexpr (LORA) {
+                float p[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+                        d += (v[j][0] * a[r][j][0] + v[j][1] * a[r][j][1]) + (v[j][2] * a[r][j][2] + v[j][3] * a[r][j][3]);
+                    p[r] = d;
+                }
+                const float t = reduce8(p, lane);  // lane group (bits 5,4,3) owns r
+                // lane l in [0,8): fetch t[l] from lane with bits (5,4,3) = (l>>2&1, l>>1&1, l&1)
+                const int src = ((lane >> 2) & 1) * 32 + ((lane >> 1) & 1) * 16 + (lane & 1) * 8;
+                const float tl = __shfl(t, src, 64);
+                // K-augmentation block: cols [H, H+8) = t, [H+8, H+64) = 0
+                yr[H + lane] = (lane < 8) ? f2bf(tl) : (bf16_t)0;
+            }
+        }
+    }
+}
+
+template <int H, bool X_BF16, bool LORA>
+__global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __restrict__ x, int ld_x,
+                                                                  const float* __restrict__ stats,
+                                                                  const float* __restrict__ gamma, int M,
+                                                                  const float* __restrict__ g_resid,
+                                                                  const bf16_t* __restrict__ g_gemm, int ld_g,
+                                                                  const float* __restrict__ dt,
+                                                                  const float* __restrict__ lora_a, int mode,
+                                                                  float* __restrict__ dx_f32,
+                                                                  bf16_t* __restrict__ dx_bf16, int ld_dxb) {
+    constexpr int NV = H / 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * LN_BLOCK) >> 6;
+
+    f32x4 g[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) g[j] = *reinterpret_cast<const f32x4*>(gamma + j * 256 + lane * 4);
+    f32x4 a[LORA ? 8 : 1][NV];
+    if constexpr (LORA) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) a[r][j] = *reinterpret_cast<const f32x4*>(lora_a + r * H + j * 256 + lane * 4);
+    }
+
+    for (int row = wave; row < M; row += nwaves) {
+        f32x4 v[NV], dy[NV], res[NV];
+        load_row<H, X_BF16>(x, ld_x, row, lane, v);
+        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            dy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (g_resid) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                res[j] = *reinterpret_cast<const f32x4*>(g_resid + (size_t)row * H + j * 256 + lane * 4);
+        }
+        if (g_gemm) {
+            const bf16_t* p = g_gemm + (size_t)row * ld_g;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const uint2 u = *reinterpret_cast<const uint2*>(p + j * 256 + lane * 4);
+                dy[j] = f32x4{bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
+            }
+        }
+        if constexpr (LORA) {
+            // dy += dt[row, 0:8] . A   (gradient of the LoRA-A projection folded into this LN's output)
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                dy[j] += d0[0] * a[0][j] + d0[1] * a[1][j] + d0[2] * a[2][j] + d0[3] * a[3][j];
+                dy[j] += d1[0] * a[4][j] + d1[1] * a[5][j] + d1[2] * a[6][j] + d1[3] * a[7][j];
+            }
+        }
+        if (mode == 1) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) dy[j] += res[j];
+        }
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = (v[j] - mean) * rstd;  // xhat
+            dy[j] *= g[j];                // dL/dxhat
+            c1 += (dy[j][0] + dy[j][1]) + (dy[j][2] + dy[j][3]);
+            c2 += (dy[j][0] * v[j][0] + dy[j][1] * v[j][1]) + (dy[j][2] * v[j][2] + dy[j][3] * v[j][3]);
+        }
+        c1 = wave_sum(c1) * (1.0f / H);
+        c2 = wave_sum(c2) * (1.0f / H);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            f32x4 d = (dy[j] - c1 - v[j] * c2) * rstd;
+            if (mode == 0) d += res[j];
+            if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + (size_t)row * H + j * 256 + lane * 4) = d;
+            if (dx_bf16) {
+                uint2 o;
+                o.x = pack_bf2(d[0], d[1]);
+                o.y = pack_bf2(d[2], d[3]);
+                *reinterpret_cast<uint2*>(dx_bf16 + (size_t)row * ld_dxb + j * 256 + lane * 4) = o;
+            }
+        }
+    }
+}
+
+// F.normalize(p=2, dim=-1, eps=1e-12): y = x / max(||x||, eps).  D = 768, one wave per row.
+__global__ __launch_bounds__(LN_BLOCK) void l2norm_fwd_kernel(const float* __restrict__ x, int M, int D,
+                                                               float* __restrict__ y, float* __restrict__ inv_norm) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float ss = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    if (inv_norm && lane == 0) inv_norm[row] = inv;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        *reinterpret_cast<f32x4*>(y + (size_t)row * D + c) = v * inv;
+    }
+}
+
+// dx = inv * (dy - y (y . dy))   (exact for ||x|| > eps, which holds for every non-degenerate embedding)
+__global__ __launch_bounds__(LN_BLOCK) void l2norm_bwd_kernel(const float* __restrict__ y,
+                                                               const float* __restrict__ inv_norm,
+                                                               const float* __restrict__ dy, int M, int D,
+                                                               float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;
+    if (row >= M) return;
+    const float* yr = y + (size_t)row * D;
+    const float* gr = dy + (size_t)row * D;
+    float dot = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(yr + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gr + c);
+        dot += (a[0] * g[0] + a[1] * g[1]) + (a[2] * g[2] + a[3] * g[3]);
+    }
+    dot = wave_sum(dot);
+    const float inv = inv_norm[row];
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(yr + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gr + c);
+        *reinterpret_cast<f32x4*>(dx + (size_t)row * D + c) = (g - a * dot) * inv;
+    }
+}
+
+int ln_grid(int M) {
+    const int blocks = ceil_div(M, LN_BLOCK / 64);
+    return blocks < 2048 ? blocks : 2048;  // grid-stride beyond 8 workgroups per CU
+}
+
+}  // namespace
+
+#define LN_FWD_LAUNCH(HH, XB, LO)                                                                              \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<HH, XB, LO>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, M, \
+                       gamma, beta, eps, static_cast<bf16_t*>(y_bf16), ld_y, y_f32, lora_a, stats)
+
+extern "C" int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma,
+                                    const float* beta, float eps, void* y_bf16, int ld_y, float* y_f32,
+                                    const float* lora_a, float* stats, void* stream) {
+    BSCLIP_REQUIRE(x && gamma && beta && M > 0, "bsclip_layernorm_fwd: null/empty input");
+    BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_fwd: H=%d (supported: 768, 512)", H);
+    BSCLIP_REQUIRE(ld_x >= H && ld_x % 4 == 0, "bsclip_layernorm_fwd: ld_x=%d", ld_x);
+    BSCLIP_REQUIRE(!y_bf16 || (ld_y % 4 == 0 && ld_y >= H + (lora_a ? BSCLIP_KPAD : 0)),
+                   "bsclip_layernorm_fwd: ld_y=%d too small for H=%d%s", ld_y, H, lora_a ? "+KPAD" : "");
+    BSCLIP_REQUIRE(!lora_a || y_bf16, "bsclip_layernorm_fwd: lora_a needs y_bf16");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool lo = lora_a != nullptr;
+    if (H == 768) {
+        if (x_bf16) { if (lo) LN_FWD_LAUNCH(768, true, true); else LN_FWD_LAUNCH(768, true, false); }
+        else        { if (lo) LN_FWD_LAUNCH(768, false, true); else LN_FWD_LAUNCH(768, false, false); }
+    } else {
+        if (x_bf16) { if (lo) LN_FWD_LAUNCH(512, true, true); else LN_FWD_LAUNCH(512, true, false); }
+        else        { if (lo) LN_FWD_LAUNCH(512, false, true); else LN_FWD_LAUNCH(512, false, false); }
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+#define LN_BWD_LAUNCH(HH, XB, LO)                                                                                \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<HH, XB, LO>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, stats, \
+                       gamma, M, g_resid, static_cast<const bf16_t*>(g_gemm), ld_g, dt, lora_a, mode, dx_f32,      \
+                       static_cast<bf16_t*>(dx_bf16), ld_dxb)
+
+extern "C" int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M,
+                                    int H, const float* g_resid, const void* g_gemm, int ld_g, const float* dt,
+                                    const float* lora_a, int mode, float* dx_f32, void* dx_bf16, int ld_dxb,
+                                    void* stream) {
+    BSCLIP_REQUIRE(x && stats && gamma && M > 0, "bsclip_layernorm_bwd: null/empty input");
+    BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_bwd: H=%d (supported: 768, 512)", H);
+    BSCLIP_REQUIRE(g_resid || g_gemm, "bsclip_layernorm_bwd: no incoming gradient");
+    BSCLIP_REQUIRE(mode == 0 || mode == 1, "bsclip_layernorm_bwd: mode=%d", mode);
+    BSCLIP_REQUIRE((dt == nullptr) == (lora_a == nullptr), "bsclip_layernorm_bwd: dt and lora_a go together");
+    BSCLIP_REQUIRE(!g_gemm || (ld_g >= H && ld_g % 4 == 0), "bsclip_layernorm_bwd: ld_g=%d", ld_g);
+    BSCLIP_REQUIRE(!dx_bf16 || (ld_dxb >= H && ld_dxb % 4 == 0), "bsclip_layernorm_bwd: ld_dxb=%d", ld_dxb);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool lo = lora_a != nullptr;
+    if (H == 768) {
+        if (x_bf16) { if (lo) LN_BWD_LAUNCH(768, true, true); else LN_BWD_LAUNCH(768, true, false); }
+        else        { if (lo) LN_BWD_LAUNCH(768, false, true); else LN_BWD_LAUNCH(768, false, false); }
+    } else {
+        if (x_bf16) { if (lo) LN_BWD_LAUNCH(512, true, true); else LN_BWD_LAUNCH(512, true, false); }
+        else        { if (lo) LN_BWD_LAUNCH(512, false, true); else LN_BWD_LAUNCH(512, false, false); }
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_l2norm_fwd(const float* x, int M, int D, float* y, float* inv_norm, void* stream) {
+    BSCLIP_REQUIRE(x && y && M > 0 && D % 4 == 0, "bsclip_l2norm_fwd: bad args (M=%d D=%d)", M, D);
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(ceil_div(M, LN_BLOCK / 64)), dim3(LN_BLOCK), 0,
+                       static_cast<hipStream_t>(stream), x, M, D, y, inv_norm);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, int M, int D, float* dx,
+                                 void* stream) {
+    BSCLIP_REQUIRE(y && inv_norm && dy && dx && M > 0 && D % 4 == 0, "bsclip_l2norm_bwd: bad args (M=%d D=%d)", M, D);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ceil_div(M, LN_BLOCK / 64)), dim3(LN_BLOCK), 0,
+                       static_cast<hipStream_t>(stream), y, inv_norm, dy, M, D, dx);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}

@@ -1,0 +1,250 @@
+// Trainable-parameter gradients that are not GEMM-shaped, and the optimiser (gfx950).
+//   lora_grad : autograd of the rank-4 LoRA branches (image_encoder.py:44-47, dna_encoder.py:47-49) -- skinny
+//               reductions over all M tokens, HBM-bound: one pass over dq/dv/t (dt + dB), one over y (dA).
+//   colsum    : bias gradients of the trainable heads.
+//   adamw     : torch.optim.AdamW defaults (scripts/train_cl.py:158), one launch over the flat trainable buffer.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ f32x4 ld_bf4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return f32x4{bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
+}
+
+// same 8-way transpose-reduce as norm.hip (lane group bits (5,4,3) ends up owning index r)
+__device__ __forceinline__ float reduce8(float (&p)[8], int lane) {
+    float q[4];
+    const bool hi5 = lane & 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float send = hi5 ? p[i] : p[i + 4];
+        const float keep = hi5 ? p[i + 4] : p[i];
+        q[i] = keep + __shfl_xor(send, 32, 64);
+    }
+    float r2[2];
+    const bool hi4 = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float send = hi4 ? q[i] : q[i + 2];
+        const float keep = hi4 ? q[i + 2] : q[i];
+        r2[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    const bool hi3 = lane & 8;
+    float v = (hi3 ? r2[1] : r2[0]) + __shfl_xor(hi3 ? r2[0] : r2[1], 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+constexpr int LG_BLOCK = 256;
+
+// pass 1: dt[M,8] = [dq.B_q | dv.B_v];  dBq[H,4] += dq^T t_q;  dBv[H,4] += dv^T t_v
+template <int H>
+__global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t* __restrict__ dqkv, int ld,
+                                                                    const bf16_t* __restrict__ haug, int ld_h, int M,
+                                                                    const float* __restrict__ lora_b,
+                                                                    float* __restrict__ dt, float* __restrict__ dBq,
+                                                                    float* __restrict__ dBv) {
+    constexpr int NV = H / 256;
+    __shared__ float red[2 * NV * 16 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LG_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * LG_BLOCK) >> 6;
+    for (int i = threadIdx.x; i < 2 * NV * 16 * 64; i += LG_BLOCK) red[i] = 0.f;
+
+    f32x4 bq[NV][4], bv[NV][4];  // [chunk][column-in-chunk] -> 4 ranks
+    f32x4 aq[NV][4], av[NV][4];  // accumulators, same indexing
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = j * 256 + lane * 4 + i;
+            bq[j][i] = *reinterpret_cast<const f32x4*>(lora_b + (size_t)c * 4);
+            bv[j][i] = *reinterpret_cast<const f32x4*>(lora_b + (size_t)(H + c) * 4);
+            aq[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            av[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    for (int row = wave; row < M; row += nwaves) {
+        const bf16_t* g = dqkv + (size_t)row * ld;
+        f32x4 dq[NV], dv[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            dq[j] = ld_bf4(g + j * 256 + lane * 4);
+            dv[j] = ld_bf4(g + 2 * H + j * 256 + lane * 4);
+        }
+        const u32x4 tu = *reinterpret_cast<const u32x4*>(haug + (size_t)row * ld_h + H);  // t_q(4) t_v(4), broadcast
+        const f32x4 tq = {bf2f(tu[0] & 0xffff), bf2f(tu[0] >> 16), bf2f(tu[1] & 0xffff), bf2f(tu[1] >> 16)};
+        const f32x4 tv = {bf2f(tu[2] & 0xffff), bf2f(tu[2] >> 16), bf2f(tu[3] & 0xffff), bf2f(tu[3] >> 16)};
+        f32x4 pq = {0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pq += dq[j][i] * bq[j][i];
+                pv += dv[j][i] * bv[j][i];
+                aq[j][i] += dq[j][i] * tq;
+                av[j][i] += dv[j][i] * tv;
+            }
+        float p[8] = {pq[0], pq[1], pq[2], pq[3], pv[0], pv[1], pv[2], pv[3]};
+        const float tot = reduce8(p, lane);
+        const int src = ((lane >> 2) & 1) * 32 + ((lane >> 1) & 1) * 16 + (lane & 1) * 8;
+        const float tl = __shfl(tot, src, 64);
+        if (lane < 8) dt[(size_t)row * 8 + lane] = tl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                atomicAdd(&red[((j * 16 + i * 4 + r) * 64) + lane], aq[j][i][r]);
+                atomicAdd(&red[((NV * 16 + j * 16 + i * 4 + r) * 64) + lane], av[j][i][r]);
+            }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * NV * 16 * 64; idx += LG_BLOCK) {
+        const int l = idx & 63, k = idx >> 6;
+        const bool is_v = k >= NV * 16;
+        const int kk = is_v ? k - NV * 16 : k;
+        const int j = kk >> 4, i = (kk >> 2) & 3, r = kk & 3;
+        const int c = j * 256 + l * 4 + i;
+        atomicAdd((is_v ? dBv : dBq) + (size_t)c * 4 + r, red[idx]);
+    }
+}
+
+// pass 2: dA[8,H] += dt^T y
+template <int H>
+__global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __restrict__ haug, int ld_h, int M,
+                                                                 const float* __restrict__ dt, float* __restrict__ dA) {
+    constexpr int NV = H / 256;
+    __shared__ float red[8 * NV * 4 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LG_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * LG_BLOCK) >> 6;
+    for (int i = threadIdx.x; i < 8 * NV * 4 * 64; i += LG_BLOCK) red[i] = 0.f;
+    f32x4 acc[8][NV];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int row = wave; row < M; row += nwaves) {
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const f32x4 y = ld_bf4(haug + (size_t)row * ld_h + j * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r][j] += d0[r] * y;
+                acc[4 + r][j] += d1[r] * y;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(&red[(((r * NV + j) * 4 + i) * 64) + lane], acc[r][j][i]);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 8 * NV * 4 * 64; idx += LG_BLOCK) {
+        const int l = idx & 63, k = idx >> 6;
+        const int i = k & 3, j = (k >> 2) % NV, r = (k >> 2) / NV;
+        atomicAdd(dA + (size_t)r * H + j * 256 + l * 4 + i, red[idx]);
+    }
+}
+
+// out[n] += sum over a stripe of rows; thread per column
+template <bool BF16>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ g, int ld, int M, int N, int rows_per,
+                                                      float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        if constexpr (BF16) s += bf2f(static_cast<const bf16_t*>(g)[(size_t)r * ld + n]);
+        else s += static_cast<const float*>(g)[(size_t)r * ld + n];
+    }
+    atomicAdd(out + n, s);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                     float beta1, float beta2, float eps, float wd, float inv_bc1,
+                                                     float inv_sqrt_bc2, float grad_scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        pi -= (lr * inv_bc1) * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+}  // namespace
+
+extern "C" int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, int ld_h, int M, int H,
+                                const float* lora_b, float* dt, float* dA, float* dBq, float* dBv, void* stream) {
+    BSCLIP_REQUIRE(dqkv && h && lora_b && dt && dA && dBq && dBv && M > 0, "bsclip_lora_grad: null/empty input");
+    BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_lora_grad: H=%d (supported: 768, 512)", H);
+    BSCLIP_REQUIRE(ld_dqkv >= 3 * H && ld_dqkv % 4 == 0 && ld_h >= H + 8 && ld_h % 8 == 0,
+                   "bsclip_lora_grad: ld_dqkv=%d ld_h=%d", ld_dqkv, ld_h);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int blocks = ceil_div(M, 4 * 8);  // >= 8 rows per wave
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    const bf16_t* g = static_cast<const bf16_t*>(dqkv);
+    const bf16_t* hh = static_cast<const bf16_t*>(h);
+    if (H == 768) {
+        hipLaunchKernelGGL((lora_grad_dt_db_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, g, ld_dqkv, hh, ld_h, M,
+                           lora_b, dt, dBq, dBv);
+        hipLaunchKernelGGL((lora_grad_da_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, dA);
+    } else {
+        hipLaunchKernelGGL((lora_grad_dt_db_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, g, ld_dqkv, hh, ld_h, M,
+                           lora_b, dt, dBq, dBv);
+        hipLaunchKernelGGL((lora_grad_da_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, dA);
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_colsum(const void* g, int ld_g, int g_is_bf16, int M, int N, float* out, void* stream) {
+    BSCLIP_REQUIRE(g && out && M > 0 && N > 0 && ld_g >= N, "bsclip_colsum: bad args");
+    int stripes = ceil_div(M, 256);
+    if (stripes > 256) stripes = 256;
+    const int rows_per = ceil_div(M, stripes);
+    const dim3 grid(ceil_div(N, 256), ceil_div(M, rows_per));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g_is_bf16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, s, g, ld_g, M, N, rows_per, out);
+    else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, s, g, ld_g, M, N, rows_per, out);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                 void* stream) {
+    BSCLIP_REQUIRE(p && g && m && v && n > 0 && step >= 1, "bsclip_adamw_step: bad args (n=%ld step=%d)", (long)n, step);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
+                       (long)n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
+                       grad_scale);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}

@@ -1,0 +1,152 @@
+/* libbsclip_hip.so -- C ABI of the MI355X (gfx950) BIOSCAN-CLIP contrastive-training-step kernels.
+ *
+ * The reference (bioscan-ml/bioscan-clip) has no FFI: its boundary for this path is the Python surface of
+ * bioscanclip.model.* (SURVEY.md 8b).  Every arithmetic op that surface performs through torch/cuDNN/cuBLAS is
+ * replaced by one entry point below; the comment on each names the reference site (file:line under
+ * /root/reference) whose arithmetic it takes over.  bioscan-clip_amd/bioscanclip/hip/lib.py binds these with
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory unless named host_*.
+ *   - bf16 tensors are raw uint16 bit patterns; "f32" = float; ids/labels are int64.
+ *   - row-major; ld* = leading dimension in ELEMENTS.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  No entry point allocates,
+ *     synchronises or touches the host; all are capturable into a hipGraph.
+ *   - return 0 on success, <0 on error; bsclip_last_error() describes the last failure of the calling thread.
+ */
+#ifndef BSCLIP_H
+#define BSCLIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSCLIP_OK 0
+#define BSCLIP_ERR_INVALID (-1)
+#define BSCLIP_ERR_LAUNCH (-2)
+
+#define BSCLIP_LORA_COLS 8 /* r=4 for Q plus r=4 for V */
+#define BSCLIP_KPAD 64     /* K-augmentation block appended to LN outputs: [t_q(4) t_v(4) 0...] */
+
+const char* bsclip_last_error(void);
+int bsclip_abi_version(void);
+
+/* ---- GEMM family: C = epilogue(A[M,K] * B[N,K]^T), bf16 operands, f32 accumulate (MFMA 16x16x32) -------------
+ * Replaces every torch.nn.Linear on the path: timm Attention.qkv/proj, Mlp.fc1/fc2 (via
+ * bioscanclip/model/image_encoder.py:108-109), HF BertSelfAttention q/k/v, BertSelfOutput.dense,
+ * BertIntermediate.dense, BertOutput.dense, cls.predictions.{transform.dense,decoder}
+ * (bioscanclip/model/dna_encoder.py:105), LoRA_bert.proj (language_encoder.py:89) and their autograd dX passes.
+ * The LoRA side branch (image_encoder.py:42-48, dna_encoder.py:47-49) rides in the K dimension: A carries
+ * BSCLIP_KPAD extra columns holding t = x A_lora^T and B carries the matching LoRA-B columns.
+ * Requirements: K % 64 == 0, N % 128 == 0, lda/ldb % 8 == 0, 16-byte aligned bases. M is arbitrary. */
+enum bsclip_epilogue {
+    BSCLIP_EPI_BF16 = 0,       /* C bf16 = acc + bias                                               */
+    BSCLIP_EPI_F32 = 1,        /* C f32  = acc + bias                                               */
+    BSCLIP_EPI_GELU_BF16 = 2,  /* C bf16 = gelu(acc + bias); aux (bf16, optional) = acc + bias      */
+    BSCLIP_EPI_RESID_F32 = 3,  /* C f32  = acc + bias + resid                                       */
+    BSCLIP_EPI_DGELU_BF16 = 4, /* C bf16 = acc * gelu'(aux)   (aux bf16 = saved pre-activation)     */
+    BSCLIP_EPI_PATCH_F32 = 5   /* C f32 row (b*197+1+p) = acc + bias + pos[1+p], input row b*196+p  */
+};
+typedef struct bsclip_epi_args {
+    const float* bias;  /* [N] or NULL */
+    const float* resid; /* RESID: f32 [M, ld_resid]; PATCH: pos_embed f32 [197, N] */
+    int ld_resid;
+    void* aux; /* GELU: bf16 out (nullable); DGELU: bf16 in */
+    int ld_aux;
+} bsclip_epi_args;
+int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     int epilogue, const bsclip_epi_args* args, void* stream);
+/* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 */
+int bsclip_gemm_set_tile(int tile);
+
+/* ---- LayerNorm (timm norm1/norm2/norm eps 1e-6; HF BertLayerNorm eps 1e-12) ------------------------------------
+ * fwd: y = LN(x) * gamma + beta for f32 rows x[M,H] (H = 768 or 512).
+ *   y_bf16 [M, ld_y]  (nullable): bf16(y) in cols [0,H); if lora_a != NULL cols [H,H+8) = bf16(y . lora_a^T) and
+ *                     cols [H+8, H+BSCLIP_KPAD) = 0 (the K-augmentation block consumed by the QKV GEMM).
+ *   y_f32  [M, H]     (nullable): f32 copy (post-LN residual stream of BERT).
+ *   stats  [M, 2]     (nullable): (mean, rstd) saved for backward.
+ *   x_bf16 != 0: x is bf16 [M, ld_x] instead of f32 (MLM transform LN after GELU).
+ * bwd (gamma/beta frozen -> only dx): dy = g_resid(f32, nullable) + g_gemm(bf16, nullable) + dt[M,8] . lora_a
+ *   mode 0 (pre-LN, ViT):  dx = g_resid + LNbwd(g_gemm + dt.lora_a)
+ *   mode 1 (post-LN, BERT): dx = LNbwd(g_resid + g_gemm + dt.lora_a)
+ *   writes dx_f32 [M,H] (nullable) and dx_bf16 [M, ld_dxb] (nullable). */
+int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma, const float* beta,
+                         float eps, void* y_bf16, int ld_y, float* y_f32, const float* lora_a, float* stats,
+                         void* stream);
+int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M, int H,
+                         const float* g_resid, const void* g_gemm, int ld_g, const float* dt, const float* lora_a,
+                         int mode, float* dx_f32, void* dx_bf16, int ld_dxb, void* stream);
+
+/* ---- self-attention (timm Attention.forward; HF BertSelfAttention) ---------------------------------------------
+ * qkv bf16 [B*S, ld_qkv] with columns [q | k | v], each heads*64 wide; ctx bf16 [B*S, ld_ctx];
+ * key_bias f32 [B,S] additive per key (HF extended attention mask, language_encoder.py:89) or NULL;
+ * lse f32 [B, heads, S] = log-sum-exp of the scaled scores (saved for backward).  head_dim is 64.
+ * S <= 224.  bwd consumes dctx/ctx and writes dqkv in the same layout as qkv. */
+int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale,
+                    void* ctx, int ld_ctx, float* lse, void* stream);
+int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* ctx, const void* dctx, int ld_ctx, const float* lse,
+                    int B, int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
+                    void* stream);
+
+/* ---- embeddings ------------------------------------------------------------------------------------------------
+ * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column
+ * order (c, ky, kx) = conv weight.flatten(1).  cls rows: x[b*197] = cls + pos[0].
+ * bert_embed: word[id] + pos[t] + type[tt] -> f32 [B*S, H] (HF BertEmbeddings before LayerNorm). */
+int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16, void* stream);
+int bsclip_vit_cls_rows(float* x, const float* cls_token, const float* pos_embed, int B, int S, int H, void* stream);
+int bsclip_bert_embed(const int64_t* ids, const int64_t* type_ids, int B, int S, int H, const float* word,
+                      int vocab, const float* pos, const float* type, float* out, void* stream);
+
+/* ---- heads -----------------------------------------------------------------------------------------------------
+ * softmax_meanpool: LoRA_barcode_bert.forward `logits.softmax(-1).mean(1)` (dna_encoder.py:105):
+ *   logits f32 [B*S, C] -> pooled f32 [B, C]; stats [B*S, 2] = (row max, sum exp) for backward.
+ *   bwd: d_pooled f32 [B,C] -> dlogits bf16 [B*S, ld_d].
+ * meanpool_tokens: LoRA_bert.forward `last_hidden_state.mean(1)` (language_encoder.py:89): f32 [B,S,H] -> bf16 [B,H].
+ * l2norm: F.normalize(p=2, dim=-1, eps=1e-12) (simple_clip.py:34,47,49). */
+int bsclip_softmax_meanpool_fwd(const float* logits, int B, int S, int C, float* pooled, float* stats, void* stream);
+int bsclip_softmax_meanpool_bwd(const float* logits, const float* stats, const float* d_pooled, int B, int S, int C,
+                                void* dlogits_bf16, int ld_d, void* stream);
+int bsclip_meanpool_tokens_fwd(const float* x, int B, int S, int H, void* out_bf16, int ld_out, void* stream);
+/* autograd of the mean: dx[b,t,:] = d_pooled[b,:] / S  (f32 [B*S, H]) */
+int bsclip_meanpool_tokens_bwd(const float* d_pooled, int ld_d, int B, int S, int H, float* dx, void* stream);
+int bsclip_l2norm_fwd(const float* x, int M, int D, float* y, float* inv_norm, void* stream);
+int bsclip_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, int M, int D, float* dx, void* stream);
+
+/* ---- contrastive loss ------------------------------------------------------------------------------------------
+ * ContrastiveLoss.forward (bioscanclip/model/loss_func.py:29-54) with construct_label_metrix (:18-21) for
+ * nmod = 2 or 3 modalities z[i] f32 [N, D] (D = 768).  The second F.normalize (:43-44) is applied inside
+ * (forward and backward).  loss_out[0] = mean over all 2*nmod*(nmod-1) CE terms.
+ * dz[i] f32 [n_local, D] receives dLoss/dz[i] for rows [row0, row0 + n_local) only (the rank's own slice of an
+ * all-gathered batch); pass row0 = 0, n_local = N for the local-batch loss.
+ * workspace: f32, at least bsclip_infonce_workspace_floats(N, nmod) elements. */
+int64_t bsclip_infonce_workspace_floats(int N, int nmod);
+int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int64_t* labels, int N, int D, float scale,
+                           int row0, int n_local, float* loss_out, float* const* dz, float* workspace,
+                           void* stream);
+
+/* ---- LoRA / head gradients -------------------------------------------------------------------------------------
+ * lora_grad: for one layer, from dqkv (bf16 [M, ld_dqkv], q cols [0,H), v cols [2H,3H)) and the augmented LN
+ *   output h (bf16 [M, ld_h]: cols [0,H) = y, [H,H+4) = t_q, [H+4,H+8) = t_v):
+ *     dt[M,8]   = [dq . B_q | dv . B_v]                     (f32 out, feeds layernorm_bwd)
+ *     dA[8,H]  += dt^T h[:, :H]        (rows 0-3 = dA_q, 4-7 = dA_v)      (f32 accumulate)
+ *     dBq[H,4] += dq^T t_q ; dBv[H,4] += dv^T t_v                         (f32 accumulate)
+ *   lora_b f32 [2, H, 4] = (B_q, B_v).  Autograd of image_encoder.py:44-47 / dna_encoder.py:47-49.
+ * colsum: db[N] += sum_m g[m, n] (bias gradients of the trainable heads), g bf16 or f32.
+ * transpose_bf16: out[C,R] = in[R,C]^T (operands of the dW = dY^T X head GEMMs). */
+int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, int ld_h, int M, int H, const float* lora_b,
+                     float* dt, float* dA, float* dBq, float* dBv, void* stream);
+int bsclip_colsum(const void* g, int ld_g, int g_is_bf16, int M, int N, float* out, void* stream);
+int bsclip_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
+int bsclip_cast_f32_bf16(const float* in, int64_t n, void* out, void* stream);
+/* W_aug[3H, H+KPAD] bf16: cols [H,H+4) of rows [0,H) = B_q, cols [H+4,H+8) of rows [2H,3H) = B_v (refreshed
+ * every step from the f32 masters; the frozen [3H,H] block is written once at pack time). */
+int bsclip_waug_set_lora(void* w_aug, int ld_w, int H, const float* lora_bq, const float* lora_bv, void* stream);
+
+/* ---- optimiser: torch.optim.AdamW defaults (scripts/train_cl.py:158), one launch over a flat f32 buffer ---------- */
+int bsclip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

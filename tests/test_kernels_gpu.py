@@ -1,0 +1,374 @@
+"""Kernel-level parity: every C-ABI entry point vs an fp32 torch restatement of the same op on identical
+(bf16-rounded where the kernel consumes bf16) inputs.  Tolerances: f32 outputs 2e-5 normwise (accumulation
+order only); bf16 outputs 4e-3 normwise (one bf16 rounding = 2^-9 relative per element)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import rel_err  # noqa: E402
+
+TOL_F32 = 2e-5
+TOL_BF16 = 4e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bioscanclip.hip import ops as o
+    return o
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+def dgelu(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+# ------------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 832), (2500, 512, 576), (197 * 8, 2304, 832)])
+def test_gemm_epilogues(ops, tile, M, N, K):
+    from bioscanclip.hip.lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32)
+    ops.set_gemm_tile(tile)
+    try:
+        a = dev(rnd(M, K + 16, seed=1).bfloat16())[:, :K]      # row stride > K on purpose
+        b = dev(rnd(N, K, seed=2, scale=0.1).bfloat16())
+        bias = dev(rnd(N, seed=3))
+        ref = a.float() @ b.float().t() + bias
+        out32 = torch.full((M + 3, N), float("nan"), device="cuda")
+        ops.gemm(a, b, out32, EPI_F32, bias=bias, M=M)
+        assert rel_err(out32[:M], ref) < TOL_F32
+        assert torch.isnan(out32[M:]).all(), "rows beyond M were written"
+        out16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, b, out16, EPI_BF16, bias=bias)
+        assert rel_err(out16.float(), ref) < TOL_BF16
+        ops.gemm(a, b, out16, EPI_BF16)  # no bias
+        assert rel_err(out16.float(), ref - bias) < TOL_BF16
+        # GELU with saved pre-activation
+        z = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, b, out16, EPI_GELU_BF16, bias=bias, aux=z)
+        assert rel_err(z.float(), ref) < TOL_BF16
+        assert rel_err(out16.float(), gelu(ref)) < TOL_BF16
+        # residual
+        r = dev(rnd(M, N, seed=4))
+        ops.gemm(a, b, out32, EPI_RESID_F32, bias=bias, resid=r, M=M)
+        assert rel_err(out32[:M], ref + r) < TOL_F32
+        # in-place residual (C aliases resid): used by the loss gradient accumulation
+        acc = r.clone()
+        ops.gemm(a, b, acc, EPI_RESID_F32, resid=acc)
+        assert rel_err(acc, ref - bias + r) < TOL_F32
+        # backward GELU scaling
+        zz = dev(rnd(M, N, seed=5).bfloat16())
+        ops.gemm(a, b, out16, EPI_DGELU_BF16, aux=zz)
+        assert rel_err(out16.float(), (ref - bias) * dgelu(zz.float())) < TOL_BF16
+    finally:
+        ops.set_gemm_tile(0)
+
+
+def test_gemm_layout_identity(ops):
+    """A = I with an asymmetric B catches row/col swaps in the C write (cdna guide 3)."""
+    from bioscanclip.hip.lib import EPI_F32
+    K = N = 256
+    a = torch.eye(K, device="cuda", dtype=torch.bfloat16)
+    b = (torch.arange(N, device="cuda")[:, None] * 2 + torch.arange(K, device="cuda")[None, :] % 7).float()
+    b = b.bfloat16()
+    for tile in (1, 2, 3):
+        ops.set_gemm_tile(tile)
+        out = torch.empty(K, N, device="cuda")
+        ops.gemm(a, b, out, EPI_F32)
+        assert torch.equal(out, b.float().t().contiguous()), f"tile {tile}"
+    ops.set_gemm_tile(0)
+
+
+def test_gemm_patch_epilogue(ops):
+    from bioscanclip.hip.lib import EPI_PATCH_F32
+    B = 3
+    a = dev(rnd(B * 196, 768, seed=1).bfloat16())
+    w = dev(rnd(768, 768, seed=2, scale=0.05).bfloat16())
+    bias, pos = dev(rnd(768, seed=3)), dev(rnd(197, 768, seed=4))
+    out = torch.zeros(B * 197, 768, device="cuda")
+    ops.gemm(a, w, out, EPI_PATCH_F32, bias=bias, resid=pos)
+    ref = (a.float() @ w.float().t() + bias).reshape(B, 196, 768) + pos[1:]
+    got = out.reshape(B, 197, 768)
+    assert rel_err(got[:, 1:], ref) < TOL_F32
+    assert (got[:, 0] == 0).all()
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from bioscanclip.hip.lib import EPI_F32
+    a = torch.zeros(64, 100, device="cuda", dtype=torch.bfloat16)
+    b = torch.zeros(128, 100, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm(a, b, torch.zeros(64, 128, device="cuda"), EPI_F32)
+
+
+# ------------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("H,eps", [(768, 1e-6), (512, 1e-12)])
+@pytest.mark.parametrize("xbf16", [False, True])
+def test_layernorm_fwd_bwd(ops, H, eps, xbf16):
+    M = 1031
+    x = dev(rnd(M, H, seed=1) * 2 + 0.3)
+    if xbf16:
+        x = x.bfloat16()
+    g, b = dev(1 + 0.1 * rnd(H, seed=2)), dev(0.1 * rnd(H, seed=3))
+    A = dev(rnd(8, H, seed=4, scale=0.05))
+    ld = H + 64
+    y16 = torch.full((M, ld), 7.0, device="cuda", dtype=torch.bfloat16)
+    y32 = torch.empty(M, H, device="cuda")
+    stats = torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x, g, b, eps, y_bf16=y16, y_f32=y32, lora_a=A, stats=stats)
+    xf = x.float().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xf, (H,), g, b, eps)
+    assert rel_err(y32, ref) < TOL_F32
+    assert rel_err(y16[:, :H].float(), ref) < TOL_BF16
+    assert rel_err(y16[:, H:H + 8].float(), ref @ A.t()) < TOL_BF16
+    assert (y16[:, H + 8:] == 0).all()
+    assert rel_err(stats[:, 0], xf.mean(-1)) < 1e-4
+    # plain variant (no lora, no f32 copy)
+    y16b = torch.empty(M, H, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm_fwd(x, g, b, eps, y_bf16=y16b, stats=stats)
+    assert rel_err(y16b.float(), ref) < TOL_BF16
+
+    # backward, both modes, with and without the LoRA term
+    g_resid = dev(rnd(M, H, seed=5))
+    g_gemm = dev(rnd(M, H + 64, seed=6).bfloat16())[:, :H]
+    dt = dev(rnd(M, 8, seed=7))
+    for mode in (0, 1):
+        for use_lora in (False, True):
+            dy_ln = g_gemm.float() + (dt @ A if use_lora else 0)
+            if mode == 1:
+                dy_ln = dy_ln + g_resid
+            (gx,) = torch.autograd.grad(ref, xf, dy_ln, retain_graph=True)
+            want = gx + (g_resid if mode == 0 else 0)
+            dx32 = torch.empty(M, H, device="cuda")
+            dx16 = torch.empty(M, H, device="cuda", dtype=torch.bfloat16)
+            ops.layernorm_bwd(x, stats, g, mode, g_resid=g_resid, g_gemm=g_gemm, dt=dt if use_lora else None,
+                              lora_a=A if use_lora else None, dx_f32=dx32, dx_bf16=dx16)
+            assert rel_err(dx32, want) < 5e-5, (mode, use_lora)
+            assert rel_err(dx16.float(), want) < TOL_BF16
+    # only a GEMM gradient (top of the ViT / MLM head)
+    (gx,) = torch.autograd.grad(ref, xf, g_gemm.float())
+    dx32 = torch.empty(M, H, device="cuda")
+    ops.layernorm_bwd(x, stats, g, 0, g_gemm=g_gemm, dx_f32=dx32)
+    assert rel_err(dx32, gx) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, B, S, heads, scale, bias):
+    H = heads * 64
+    q, k, v = [t.reshape(B, S, heads, 64).transpose(1, 2) for t in qkv.split(H, dim=-1)]
+    s = (q @ k.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(B * S, H), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,S,heads,masked", [(3, 197, 12, False), (2, 133, 12, False), (5, 20, 8, True),
+                                              (2, 64, 2, False), (1, 33, 1, False), (2, 7, 3, True)])
+def test_attention_fwd_bwd(ops, B, S, heads, masked):
+    H = heads * 64
+    qkv = dev(rnd(B * S, 3 * H + 64, seed=1).bfloat16())[:, :3 * H]
+    bias = None
+    if masked:
+        lens = torch.randint(1, S + 1, (B,), generator=torch.Generator().manual_seed(3))
+        m = (torch.arange(S)[None] < lens[:, None]).float()
+        bias = dev((1.0 - m) * torch.finfo(torch.float32).min)
+    scale = 0.125
+    ctx = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, heads, S, device="cuda")
+    ops.attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=bias)
+    qf = qkv.float().reshape(B, S, 3 * H).requires_grad_(True)
+    ref, ref_lse = _attn_ref(qf, B, S, heads, scale, bias)
+    assert rel_err(ctx.float(), ref) < 6e-3          # P is rounded to bf16 before P.V
+    assert rel_err(lse, ref_lse) < 1e-5
+
+    dctx = dev(rnd(B * S, H, seed=2).bfloat16())
+    (gq,) = torch.autograd.grad(ref, qf, dctx.float())
+    dqkv = torch.full((B * S, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.attn_bwd(qkv, ctx, dctx, lse, B, S, heads, scale, dqkv, key_bias=bias)
+    gq = gq.reshape(B * S, 3 * H)
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert rel_err(dqkv[:, sl].float(), gq[:, sl]) < 1e-2, name
+
+
+# ------------------------------------------------------------------------------------------ embeddings / misc
+def test_im2col_and_cls(ops):
+    B = 3
+    img = dev(torch.rand(B, 3, 224, 224, generator=torch.Generator().manual_seed(1)))
+    cols = torch.empty(B * 196, 768, device="cuda", dtype=torch.bfloat16)
+    ops.im2col_patch16(img, cols)
+    ref = img.reshape(B, 3, 14, 16, 14, 16).permute(0, 2, 4, 1, 3, 5).reshape(B * 196, 768)
+    assert torch.equal(cols, ref.bfloat16())
+    x = torch.zeros(B * 197, 768, device="cuda")
+    cls, pos = dev(rnd(768, seed=2)), dev(rnd(197, 768, seed=3))
+    ops.vit_cls_rows(x, cls, pos, B, 197, 768)
+    got = x.reshape(B, 197, 768)
+    assert torch.equal(got[:, 0], (cls + pos[0]).expand(B, -1)) and (got[:, 1:] == 0).all()
+
+
+@pytest.mark.parametrize("H,vocab", [(768, 1027), (512, 30522)])
+def test_bert_embed(ops, H, vocab):
+    B, S = 4, 20
+    g = torch.Generator().manual_seed(1)
+    ids = dev(torch.randint(0, vocab, (B, S), generator=g))
+    tt = dev(torch.randint(0, 2, (B, S), generator=g))
+    word, pos, typ = dev(rnd(vocab, H, seed=2)), dev(rnd(512, H, seed=3)), dev(rnd(2, H, seed=4))
+    out = torch.empty(B * S, H, device="cuda")
+    ops.bert_embed(ids, tt, word, pos, typ, out)
+    ref = word[ids] + pos[:S][None] + typ[tt]
+    assert rel_err(out, ref.reshape(B * S, H)) < 1e-6
+    ops.bert_embed(ids, None, word, pos, typ, out)
+    assert rel_err(out, (word[ids] + pos[:S][None] + typ[0]).reshape(B * S, H)) < 1e-6
+
+
+def test_softmax_meanpool(ops):
+    B, S, C = 5, 133, 768
+    logits = dev(rnd(B * S, C, seed=1, scale=3.0)).requires_grad_(True)
+    pooled = torch.empty(B, C, device="cuda")
+    stats = torch.empty(B * S, 2, device="cuda")
+    ops.softmax_meanpool_fwd(logits.detach(), B, S, pooled, stats)
+    ref = torch.softmax(logits.reshape(B, S, C), -1).mean(1)
+    assert rel_err(pooled, ref) < TOL_F32
+    assert abs(pooled.sum(-1) - 1).max() < 1e-5
+    dp = dev(rnd(B, C, seed=2))
+    (gl,) = torch.autograd.grad(ref, logits, dp)
+    dl = torch.empty(B * S, C, device="cuda", dtype=torch.bfloat16)
+    ops.softmax_meanpool_bwd(logits.detach(), stats, dp, B, S, dl)
+    assert rel_err(dl.float(), gl) < TOL_BF16
+
+
+def test_meanpool_and_l2norm(ops):
+    B, S, H = 6, 20, 512
+    x = dev(rnd(B * S, H, seed=1))
+    out = torch.empty(B, H, device="cuda", dtype=torch.bfloat16)
+    ops.meanpool_tokens_fwd(x, B, S, out)
+    assert rel_err(out.float(), x.reshape(B, S, H).mean(1)) < TOL_BF16
+    dp = dev(rnd(B, 768, seed=2))[:, :H]  # strided
+    dx = torch.empty(B * S, H, device="cuda")
+    ops.meanpool_tokens_bwd(dp, B, S, dx)
+    assert rel_err(dx.reshape(B, S, H), (dp / S)[:, None].expand(B, S, H)) < 1e-6
+
+    z = dev(rnd(37, 768, seed=3)).requires_grad_(True)
+    y, inv = torch.empty(37, 768, device="cuda"), torch.empty(37, device="cuda")
+    ops.l2norm_fwd(z.detach(), y, inv)
+    ref = torch.nn.functional.normalize(z, p=2, dim=-1)
+    assert rel_err(y, ref) < 1e-6
+    dy = dev(rnd(37, 768, seed=4))
+    (gz,) = torch.autograd.grad(ref, z, dy)
+    dz = torch.empty(37, 768, device="cuda")
+    ops.l2norm_bwd(y, inv, dy, dz)
+    assert rel_err(dz, gz) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("N,nmod,dup", [(8, 2, False), (8, 3, True), (64, 3, True), (200, 2, True), (256, 2, False),
+                                        (256, 3, True)])
+def test_infonce_vs_oracle(ops, N, nmod, dup):
+    from oracle import refcpu
+    zs = [rnd(N, 768, seed=10 + i) for i in range(nmod)]
+    label = torch.arange(N)
+    if dup:
+        label = label // 3 * 3 if N > 8 else torch.tensor([0, 0, 1, 2, 3, 3, 3, 4])
+    zc = [z.clone().requires_grad_(True) for z in zs]
+    ref = refcpu.contrastive_loss(zc[0], zc[1], zc[2] if nmod == 3 else None, label)
+    ref.backward()
+    zd = [dev(z) for z in zs]
+    dz = [torch.empty(N, 768, device="cuda") for _ in range(nmod)]
+    loss = torch.zeros(1, device="cuda")
+    ws = torch.empty(ops.infonce_workspace_floats(N, nmod), device="cuda")
+    ops.infonce_fwd_bwd(zd, dev(label), 1 / 0.07, loss, dz, workspace=ws)
+    assert abs(loss.item() - ref.item()) < 2e-5 * abs(ref.item()), (loss.item(), ref.item())
+    for i in range(nmod):
+        assert rel_err(dz[i], zc[i].grad) < 2e-4, i
+    # local slice of an all-gathered batch: rows [row0, row0+n_local) only
+    if N >= 64:
+        row0, nl = N // 4, N // 2
+        dzl = [torch.empty(nl, 768, device="cuda") for _ in range(nmod)]
+        ops.infonce_fwd_bwd(zd, dev(label), 1 / 0.07, loss, dzl, row0=row0, n_local=nl, workspace=ws)
+        for i in range(nmod):
+            assert rel_err(dzl[i], zc[i].grad[row0:row0 + nl]) < 2e-4
+
+
+def test_infonce_too_few_modalities(ops):
+    with pytest.raises(ValueError, match="Too less element"):
+        ops.infonce_fwd_bwd([torch.zeros(8, 768, device="cuda")], torch.arange(8, device="cuda"), 1.0,
+                            torch.zeros(1, device="cuda"))
+
+
+# --------------------------------------------------------------------------------------- LoRA grads / optimiser
+@pytest.mark.parametrize("H", [768, 512])
+def test_lora_grad(ops, H):
+    M = 2077
+    dqkv = dev(rnd(M, 3 * H, seed=1).bfloat16())
+    h = dev(rnd(M, H + 64, seed=2).bfloat16())
+    lb = dev(rnd(2, H, 4, seed=3, scale=0.1))
+    dt = torch.empty(M, 8, device="cuda")
+    dA, dBq, dBv = torch.zeros(8, H, device="cuda"), torch.zeros(H, 4, device="cuda"), torch.zeros(H, 4, device="cuda")
+    ops.lora_grad(dqkv, h, M, H, lb, dt, dA, dBq, dBv)
+    dq, dv = dqkv[:, :H].float(), dqkv[:, 2 * H:].float()
+    y, tq, tv = h[:, :H].float(), h[:, H:H + 4].float(), h[:, H + 4:H + 8].float()
+    ref_dt = torch.cat([dq @ lb[0], dv @ lb[1]], 1)
+    assert rel_err(dt, ref_dt) < 1e-5
+    assert rel_err(dA, ref_dt.t() @ y) < 1e-4
+    assert rel_err(dBq, dq.t() @ tq) < 1e-4
+    assert rel_err(dBv, dv.t() @ tv) < 1e-4
+    ops.lora_grad(dqkv, h, M, H, lb, dt, dA, dBq, dBv)  # accumulates
+    assert rel_err(dA, 2 * ref_dt.t() @ y) < 1e-4
+
+
+def test_small_ops(ops):
+    g16 = dev(rnd(1000, 768, seed=1).bfloat16())
+    out = torch.zeros(768, device="cuda")
+    ops.colsum(g16, 1000, 768, out)
+    assert rel_err(out, g16.float().sum(0)) < 1e-5
+    g32 = dev(rnd(77, 512, seed=2))
+    out = torch.ones(512, device="cuda")
+    ops.colsum(g32, 77, 512, out)
+    assert rel_err(out, 1 + g32.sum(0)) < 1e-5
+    src = dev(rnd(300, 200, seed=3).bfloat16())
+    dst = torch.zeros(200, 304, device="cuda", dtype=torch.bfloat16)
+    ops.transpose_bf16(src, 300, 200, dst)
+    assert torch.equal(dst[:, :300], src.t()) and (dst[:, 300:] == 0).all()
+    x = dev(rnd(1003, seed=4))
+    y = torch.empty(1003, device="cuda", dtype=torch.bfloat16)
+    ops.cast_f32_bf16(x, y)
+    assert torch.equal(y, x.bfloat16())
+    w = torch.zeros(3 * 768, 832, device="cuda", dtype=torch.bfloat16)
+    bq, bv = dev(rnd(768, 4, seed=5)), dev(rnd(768, 4, seed=6))
+    ops.waug_set_lora(w, 768, bq, bv)
+    assert torch.equal(w[:768, 768:772], bq.bfloat16()) and torch.equal(w[1536:, 772:776], bv.bfloat16())
+    assert w.float().abs().sum() == bq.bfloat16().float().abs().sum() + bv.bfloat16().float().abs().sum()
+
+
+def test_adamw_matches_oracle_and_torch(ops):
+    from oracle import refcpu
+    n = 100003
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=1e-3)
+    p, m, v = dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pr, mr, vr = p0.clone(), torch.zeros(n), torch.zeros(n)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-3)
+    for step in range(1, 4):
+        gs = g * step
+        ops.adamw_step(p, dev(gs), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+        refcpu.adamw_update(pr, gs, mr, vr, step, 1e-3)
+        pt.grad = gs.clone()
+        opt.step()
+    assert rel_err(p, pr) < 1e-6
+    assert rel_err(p, pt) < 1e-6
