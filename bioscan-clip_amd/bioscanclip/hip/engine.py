@@ -1,0 +1,530 @@
+"""Host-side orchestration of the HIP kernels for the three encoders (forward + hand-written backward).
+
+Everything numerical happens in ``libbsclip_hip.so``; this file decides *which* kernel runs on *which* buffer:
+  * frozen backbone weights are packed once into bf16 [N,K] operands (plus the transposed copy the dX GEMMs
+    need -- HBM is 288 GB, the extra 0.35 GB buys a single NT GEMM kernel for forward and backward);
+  * trainable tensors (LoRA A/B, heads) are re-homed into one flat f32 buffer per encoder (``FlatParams``) whose
+    layout is exactly what the kernels consume (``lora_a[8,H]``, ``lora_b[2,H,4]`` per layer), with a twin flat
+    gradient buffer that ``p.grad`` aliases -- kernels accumulate straight into it and the fused AdamW kernel
+    updates the whole buffer in one launch;
+  * activations needed by backward live in a per-batch-size workspace sized for HBM (f32 residual stream saved per
+    sub-layer, bf16 GEMM operands, attention LSE, LN statistics).
+Reference call shapes: SURVEY.md 2.3 (K1-K15), 3.2; semantics App. A.1-A.3.
+"""
+import math
+
+import torch
+
+from . import ops
+from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_PATCH_F32, EPI_RESID_F32, KPAD)
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _bf16(w, dev):
+    return w.detach().to(dev, F32).to(BF16).contiguous()
+
+
+def _f32(w, dev):
+    return w.detach().to(dev, F32).contiguous()
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class FlatParams:
+    """Contiguous f32 home for a list of trainable parameters and their gradients."""
+
+    def __init__(self, params, device):
+        self.params = list(params)
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.offsets = offs
+        self.data = torch.zeros(total, dtype=F32, device=device)
+        self.grad = torch.zeros(total, dtype=F32, device=device)
+        for p, o in zip(self.params, offs):
+            view = self.data[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data.to(device, F32))
+            p.data = view
+        self.bind_grads(force=True)
+
+    def view(self, p_index, shape=None, n=None, grad=False):
+        o = self.offsets[p_index]
+        buf = self.grad if grad else self.data
+        n = self.params[p_index].numel() if n is None else n
+        t = buf[o:o + n]
+        return t.view(shape) if shape is not None else t
+
+    def valid(self):
+        return all(p.data.data_ptr() == self.data.data_ptr() + 4 * o and p.data.device == self.data.device
+                   for p, o in zip(self.params, self.offsets))
+
+    def bind_grads(self, force=False):
+        """Make every ``p.grad`` alias the flat gradient buffer.  If autograd/optimizer dropped the grads
+        (``zero_grad(set_to_none=True)``) the buffer is cleared first, so accumulate-into-grad stays correct."""
+        ok = [p.grad is not None and p.grad.data_ptr() == self.grad.data_ptr() + 4 * o
+              for p, o in zip(self.params, self.offsets)]
+        if all(ok) and not force:
+            return
+        if not any(ok):
+            self.grad.zero_()
+        for p, o, good in zip(self.params, self.offsets, ok):
+            if not good:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class _LoraPack:
+    """Per-layer frozen QKV weight in K-augmented form + views of the trainable LoRA tensors."""
+
+    def __init__(self, H):
+        self.H = H
+
+
+def _pack_qkv(w_qkv, b_qkv, H, dev):
+    """W_aug bf16 [3H, H+KPAD] (LoRA-B columns refreshed every step) and W^T bf16 [H, 3H] for dX."""
+    w = w_qkv.detach().to(dev, F32)
+    waug = torch.zeros(3 * H, H + KPAD, dtype=BF16, device=dev)
+    waug[:, :H] = w.to(BF16)
+    return waug, w.t().contiguous().to(BF16), _f32(b_qkv, dev)
+
+
+def _pack_linear(lin, dev):
+    w = lin.weight.detach().to(dev, F32)
+    return w.to(BF16).contiguous(), w.t().contiguous().to(BF16), _f32(lin.bias, dev)
+
+
+class _Layer:
+    pass
+
+
+class EncoderEngineBase:
+    """Shared pieces of the ViT and BERT engines: LoRA bookkeeping and the flat trainable buffer."""
+
+    def _setup_lora(self, qv_modules, H, dev, extra_params):
+        """qv_modules: per layer either None (no LoRA) or (A_q, A_v, B_q, B_v) nn.Linear modules."""
+        params = []
+        self._lora_index = []
+        for mods in qv_modules:
+            if mods is None:
+                self._lora_index.append(None)
+                continue
+            self._lora_index.append(len(params))
+            params += [mods[0].weight, mods[1].weight, mods[2].weight, mods[3].weight]
+        self._extra_index = len(params)
+        params += list(extra_params)
+        self.flat = FlatParams(params, dev)
+        self._zero_a = torch.zeros(8, H, dtype=F32, device=dev)
+
+    def lora_a(self, l, grad=False):
+        i = self._lora_index[l]
+        if i is None:
+            return None if grad else self._zero_a
+        return self.flat.view(i, (8, self.H), n=8 * self.H, grad=grad)
+
+    def lora_b(self, l, grad=False):
+        i = self._lora_index[l]
+        if i is None:
+            return None
+        return self.flat.view(i + 2, (2, self.H, 4), n=8 * self.H, grad=grad)
+
+    def extra(self, k, grad=False):
+        return self.flat.view(self._extra_index + k, self.flat.params[self._extra_index + k].shape, grad=grad)
+
+    def refresh_lora_weights(self):
+        for l, lay in enumerate(self.layers):
+            b = self.lora_b(l)
+            if b is not None:
+                ops.waug_set_lora(lay.waug, self.H, b[0], b[1])
+
+
+# ======================================================================================================== ViT
+class ViTEngine(EncoderEngineBase):
+    """LoRA ViT-B/16 forward/backward (reference image_encoder.py:15-109 over timm vit_base_patch16_224)."""
+
+    def __init__(self, module, device):
+        vit = module.lora_vit
+        self.device = dev = device
+        self.H = H = vit.blocks[0].norm1.weight.numel()
+        self.heads = vit.blocks[0].attn.num_heads
+        self.S = vit.pos_embed.shape[1]
+        assert H == 768 and self.S == 197 and vit.patch_embed.proj.weight.shape[-1] == 16, \
+            "HIP ViT engine is built for vit_base_patch16_224"
+        self.w_patch = _bf16(vit.patch_embed.proj.weight.reshape(H, -1), dev)
+        self.b_patch = _f32(vit.patch_embed.proj.bias, dev)
+        self.cls = _f32(vit.cls_token.reshape(-1), dev)
+        self.pos = _f32(vit.pos_embed.reshape(self.S, H), dev)
+        self.layers, qv = [], []
+        for blk in vit.blocks:
+            lay = _Layer()
+            q = blk.attn.qkv
+            if hasattr(q, "linear_a_q"):
+                base = q.qkv
+                qv.append((q.linear_a_q, q.linear_a_v, q.linear_b_q, q.linear_b_v))
+            else:
+                base = q
+                qv.append(None)
+            lay.waug, lay.wqkv_t, lay.b_qkv = _pack_qkv(base.weight, base.bias, H, dev)
+            lay.ln1 = (_f32(blk.norm1.weight, dev), _f32(blk.norm1.bias, dev))
+            lay.ln2 = (_f32(blk.norm2.weight, dev), _f32(blk.norm2.bias, dev))
+            lay.w_proj, lay.w_proj_t, lay.b_proj = _pack_linear(blk.attn.proj, dev)
+            lay.w_fc1, lay.w_fc1_t, lay.b_fc1 = _pack_linear(blk.mlp.fc1, dev)
+            lay.w_fc2, lay.w_fc2_t, lay.b_fc2 = _pack_linear(blk.mlp.fc2, dev)
+            self.layers.append(lay)
+        self.ln_f = (_f32(vit.norm.weight, dev), _f32(vit.norm.bias, dev))
+        self.FF = self.layers[0].w_fc1.shape[0]
+        self.out_dim = vit.head.weight.shape[0]
+        assert self.out_dim % 128 == 0, "head width must be a multiple of 128 for the HIP GEMM"
+        self._setup_lora(qv, H, dev, [vit.head.weight, vit.head.bias])
+        self.w_head_bf = torch.empty(self.out_dim, H, dtype=BF16, device=dev)
+        self.w_head_t = torch.empty(H, self.out_dim, dtype=BF16, device=dev)
+        self.ws = None
+
+    # ------------------------------------------------------------------------------------------ workspace
+    def _workspace(self, B):
+        if self.ws is not None and self.ws["B"] == B:
+            return self.ws
+        dev, H, S, L, FF = self.device, self.H, self.S, len(self.layers), self.FF
+        M = B * S
+        z = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+        ws = {"B": B, "M": M}
+        ws["cols"] = z(B * 196, H)
+        ws["x"] = [z(M, H, dt=F32) for _ in range(2 * L + 1)]         # residual stream after every sub-layer
+        ws["h1"] = [z(M, H + KPAD) for _ in range(L)]                 # LN1 output + LoRA t (QKV operand)
+        ws["st1"] = [z(M, 2, dt=F32) for _ in range(L)]
+        ws["st2"] = [z(M, 2, dt=F32) for _ in range(L)]
+        ws["qkv"] = [z(M, 3 * H) for _ in range(L)]
+        ws["ctx"] = [z(M, H) for _ in range(L)]
+        ws["lse"] = [z(B, self.heads, S, dt=F32) for _ in range(L)]
+        ws["z"] = [z(M, FF) for _ in range(L)]                        # fc1 pre-activation
+        ws["h2"] = z(M, H)
+        ws["act"] = z(M, FF)
+        ws["clsn"] = z(B, H)
+        ws["st_f"] = z(B, 2, dt=F32)
+        # backward temporaries
+        ws["dx"] = torch.zeros(M, H, dtype=F32, device=dev)
+        ws["dxb"] = torch.zeros(M, H, dtype=BF16, device=dev)
+        ws["dz"] = z(M, FF)
+        ws["dh"] = z(M, H)
+        ws["dctx"] = z(M, H)
+        ws["dqkv"] = z(M, 3 * H)
+        ws["dt"] = z(M, 8, dt=F32)
+        Bp = _pad64(B)
+        ws["dout_bf"] = torch.zeros(B, self.out_dim, dtype=BF16, device=dev)
+        ws["dout_t"] = torch.zeros(self.out_dim, Bp, dtype=BF16, device=dev)
+        ws["clsn_t"] = torch.zeros(H, Bp, dtype=BF16, device=dev)
+        ws["dclsn"] = z(B, H)
+        self.ws = ws
+        return ws
+
+    # -------------------------------------------------------------------------------------------- forward
+    def forward(self, image):
+        B = image.shape[0]
+        ws = self._workspace(B)
+        H, S, M = self.H, self.S, ws["M"]
+        scale = 64 ** -0.5
+        self.refresh_lora_weights()
+        ops.cast_f32_bf16(self.extra(0), self.w_head_bf)
+        x = ws["x"]
+        ops.im2col_patch16(image, ws["cols"])
+        ops.gemm(ws["cols"], self.w_patch, x[0], EPI_PATCH_F32, bias=self.b_patch, resid=self.pos)
+        ops.vit_cls_rows(x[0], self.cls, self.pos, B, S, H)
+        for l, lay in enumerate(self.layers):
+            ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_bf16=ws["h1"][l], lora_a=self.lora_a(l),
+                              stats=ws["st1"][l])
+            ops.gemm(ws["h1"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
+            ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l])
+            ops.gemm(ws["ctx"][l], lay.w_proj, x[2 * l + 1], EPI_RESID_F32, bias=lay.b_proj, resid=x[2 * l])
+            ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2"], stats=ws["st2"][l])
+            ops.gemm(ws["h2"], lay.w_fc1, ws["act"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
+            ops.gemm(ws["act"], lay.w_fc2, x[2 * l + 2], EPI_RESID_F32, bias=lay.b_fc2, resid=x[2 * l + 1])
+        x_cls = x[-1].view(B, S * H)[:, :H]  # token 0 of every image (row stride S*H)
+        ops.layernorm_fwd(x_cls, self.ln_f[0], self.ln_f[1], 1e-6, y_bf16=ws["clsn"], stats=ws["st_f"])
+        out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
+        ops.gemm(ws["clsn"], self.w_head_bf, out, EPI_F32, bias=self.extra(1))
+        return out
+
+    # ------------------------------------------------------------------------------------------- backward
+    def backward(self, dout):
+        ws = self.ws
+        B, M, H, S = ws["B"], ws["M"], self.H, self.S
+        scale = 64 ** -0.5
+        self.flat.bind_grads()
+        x = ws["x"]
+        dx, dxb = ws["dx"], ws["dxb"]
+        # head: dW = dout^T clsn, db = colsum(dout), dclsn = dout W
+        ops.cast_f32_bf16(dout, ws["dout_bf"])
+        ops.transpose_bf16(ws["dout_bf"], B, self.out_dim, ws["dout_t"])
+        ops.transpose_bf16(ws["clsn"], B, H, ws["clsn_t"])
+        gw = self.extra(0, grad=True)
+        ops.gemm(ws["dout_t"], ws["clsn_t"], gw, EPI_RESID_F32, resid=gw)
+        ops.colsum(dout, B, self.out_dim, self.extra(1, grad=True))
+        ops.transpose_bf16(self.w_head_bf, self.out_dim, H, self.w_head_t)
+        ops.gemm(ws["dout_bf"], self.w_head_t, ws["dclsn"], EPI_BF16)
+        # final norm on token-0 rows only: every other row of the residual gradient is zero
+        dx.zero_()
+        dxb.zero_()
+        ops.layernorm_bwd(x[-1].view(B, S * H)[:, :H], ws["st_f"], self.ln_f[0], 0, g_gemm=ws["dclsn"],
+                          dx_f32=dx.view(B, S * H)[:, :H], dx_bf16=dxb.view(B, S * H)[:, :H])
+        for l in range(len(self.layers) - 1, -1, -1):
+            lay = self.layers[l]
+            ops.gemm(dxb, lay.w_fc2_t, ws["dz"], EPI_DGELU_BF16, aux=ws["z"][l])
+            ops.gemm(ws["dz"], lay.w_fc1_t, ws["dh"], EPI_BF16)
+            ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh"], dx_f32=dx,
+                              dx_bf16=dxb)
+            ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
+            ops.attn_bwd(ws["qkv"][l], ws["ctx"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"])
+            lb = self.lora_b(l)
+            if lb is not None:
+                gb = self.lora_b(l, grad=True)
+                ops.lora_grad(ws["dqkv"], ws["h1"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gb[0], gb[1])
+            if l > 0:  # nothing trainable sits below block 0 (patch-embed, cls, pos are frozen)
+                ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
+                ops.layernorm_bwd(x[2 * l], ws["st1"][l], lay.ln1[0], 0, g_resid=dx, g_gemm=ws["dh"],
+                                  dt=ws["dt"] if lb is not None else None,
+                                  lora_a=self.lora_a(l) if lb is not None else None, dx_f32=dx, dx_bf16=dxb)
+
+
+# ======================================================================================================= BERT
+class BertEngine(EncoderEngineBase):
+    """HF-BERT trunk with LoRA on query/value (reference dna_encoder.py:40-105, language_encoder.py:24-89).
+
+    ``head`` selects what follows the trunk:
+      'mlm_softmax_mean' : cls.predictions.transform -> decoder Linear -> softmax(-1) -> mean over tokens (DNA)
+      'mean_proj'        : mean over tokens -> proj Linear (text)
+    """
+
+    def __init__(self, bert, head, head_modules, device):
+        self.device = dev = device
+        cfg = getattr(bert, "config", None)
+        emb = bert.embeddings
+        self.H = H = emb.word_embeddings.weight.shape[1]
+        assert H in (768, 512), "HIP BERT engine supports hidden sizes 768 and 512"
+        self.heads = H // 64
+        nh = getattr(cfg, "num_attention_heads", self.heads)
+        assert nh == self.heads, "HIP attention kernel is built for head_dim 64"
+        self.eps = float(getattr(cfg, "layer_norm_eps", 1e-12))
+        self.p_hidden = float(getattr(cfg, "hidden_dropout_prob", 0.0))
+        self.p_attn = float(getattr(cfg, "attention_probs_dropout_prob", 0.0))
+        self.word, self.posw, self.typew = (_f32(emb.word_embeddings.weight, dev),
+                                            _f32(emb.position_embeddings.weight, dev),
+                                            _f32(emb.token_type_embeddings.weight, dev))
+        self.ln_e = (_f32(emb.LayerNorm.weight, dev), _f32(emb.LayerNorm.bias, dev))
+        self.layers, qv = [], []
+        for layer in bert.encoder.layer:
+            lay = _Layer()
+            sa = layer.attention.self
+            q, k, v = sa.query, sa.key, sa.value
+            if hasattr(q, "w_a"):
+                qv.append((q.w_a, v.w_a, q.w_b, v.w_b))
+                qb, vb = q.w, v.w
+            else:
+                qv.append(None)
+                qb, vb = q, v
+            w = torch.cat([qb.weight.detach(), k.weight.detach(), vb.weight.detach()], 0)
+            b = torch.cat([qb.bias.detach(), k.bias.detach(), vb.bias.detach()], 0)
+            lay.waug, lay.wqkv_t, lay.b_qkv = _pack_qkv(w, b, H, dev)
+            lay.w_o, lay.w_o_t, lay.b_o = _pack_linear(layer.attention.output.dense, dev)
+            lay.ln_a = (_f32(layer.attention.output.LayerNorm.weight, dev), _f32(layer.attention.output.LayerNorm.bias, dev))
+            lay.w_fc1, lay.w_fc1_t, lay.b_fc1 = _pack_linear(layer.intermediate.dense, dev)
+            lay.w_fc2, lay.w_fc2_t, lay.b_fc2 = _pack_linear(layer.output.dense, dev)
+            lay.ln_b = (_f32(layer.output.LayerNorm.weight, dev), _f32(layer.output.LayerNorm.bias, dev))
+            self.layers.append(lay)
+        self.FF = self.layers[0].w_fc1.shape[0]
+        self.head = head
+        if head == "mlm_softmax_mean":
+            tr, dec = head_modules
+            self.w_tr, self.w_tr_t, self.b_tr = _pack_linear(tr.dense, dev)
+            self.ln_t = (_f32(tr.LayerNorm.weight, dev), _f32(tr.LayerNorm.bias, dev))
+            self.eps_t = float(tr.LayerNorm.eps)
+            trainable = [dec.weight, dec.bias]
+            self.out_dim, self.head_in = dec.weight.shape
+            assert self.out_dim == 768, "softmax-mean head kernel is built for 768 classes"
+        else:
+            (proj,) = head_modules
+            trainable = [proj.weight, proj.bias]
+            self.out_dim, self.head_in = proj.weight.shape
+        assert self.out_dim % 128 == 0 and self.head_in % 128 == 0
+        self._setup_lora(qv, H, dev, trainable)
+        self.w_head_bf = torch.empty(self.out_dim, self.head_in, dtype=BF16, device=dev)
+        self.w_head_t = torch.empty(self.head_in, self.out_dim, dtype=BF16, device=dev)
+        self.ws = None
+
+    def _workspace(self, B, S):
+        if self.ws is not None and self.ws["B"] == B and self.ws["S"] == S:
+            return self.ws
+        dev, H, L, FF = self.device, self.H, len(self.layers), self.FF
+        M = B * S
+        z = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+        ws = {"B": B, "S": S, "M": M}
+        ws["emb"] = z(M, H, dt=F32)
+        ws["yb"] = [z(M, H + KPAD) for _ in range(L + 1)]   # LN outputs feeding each layer's QKV GEMM (+ LoRA t)
+        ws["y"] = z(M, H, dt=F32)                           # f32 copy of the current layer input (residual)
+        ws["ym"] = z(M, H, dt=F32)
+        ws["ymb"] = z(M, H)
+        ws["qkv"] = [z(M, 3 * H) for _ in range(L)]
+        ws["ctx"] = [z(M, H) for _ in range(L)]
+        ws["lse"] = [z(B, self.heads, S, dt=F32) for _ in range(L)]
+        ws["s1"] = [z(M, H, dt=F32) for _ in range(L)]      # pre-LN sums (LN backward inputs)
+        ws["s2"] = [z(M, H, dt=F32) for _ in range(L)]
+        ws["sta"] = [z(M, 2, dt=F32) for _ in range(L)]
+        ws["stb"] = [z(M, 2, dt=F32) for _ in range(L)]
+        ws["z"] = [z(M, FF) for _ in range(L)]
+        ws["act"] = z(M, FF)
+        ws["key_bias"] = None
+        # backward temporaries
+        ws["ds"] = z(M, H, dt=F32)
+        ws["dsb"] = z(M, H)
+        ws["ds1"] = z(M, H, dt=F32)
+        ws["dz"] = z(M, FF)
+        ws["dh"] = z(M, H)
+        ws["dctx"] = z(M, H)
+        ws["dqkv"] = z(M, 3 * H)
+        ws["dt"] = z(M, 8, dt=F32)
+        if self.head == "mlm_softmax_mean":
+            Mp = _pad64(M)
+            ws["tz"] = z(M, H)            # transform pre-activation
+            ws["tg"] = z(M, H)            # gelu(transform)
+            ws["tn"] = z(M, H)            # LN(gelu(.)) = decoder input
+            ws["st_t"] = z(M, 2, dt=F32)
+            ws["logits"] = z(M, self.out_dim, dt=F32)
+            ws["sm"] = z(M, 2, dt=F32)
+            ws["dlog"] = z(M, self.out_dim)
+            ws["dlog_t"] = torch.zeros(self.out_dim, Mp, dtype=BF16, device=dev)
+            ws["tn_t"] = torch.zeros(H, Mp, dtype=BF16, device=dev)
+            ws["dtn"] = z(M, H)
+            ws["dtg"] = z(M, H)
+        else:
+            Bp = _pad64(B)
+            ws["mp"] = z(B, H)
+            ws["dout_bf"] = torch.zeros(B, self.out_dim, dtype=BF16, device=dev)
+            ws["dout_t"] = torch.zeros(self.out_dim, Bp, dtype=BF16, device=dev)
+            ws["mp_t"] = torch.zeros(H, Bp, dtype=BF16, device=dev)
+            ws["dmp"] = z(B, H, dt=F32)
+            ws["dyl"] = z(M, H, dt=F32)
+        self.ws = ws
+        return ws
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None):
+        B, S = input_ids.shape
+        ws = self._workspace(B, S)
+        H, M, L = self.H, ws["M"], len(self.layers)
+        scale = 0.125
+        self.refresh_lora_weights()
+        ops.cast_f32_bf16(self.extra(0), self.w_head_bf)
+        key_bias = None
+        if attention_mask is not None:
+            # HF extended mask (App. A.3): (1 - m) * finfo.min added to the scores of padded keys.
+            key_bias = ((1.0 - attention_mask.to(F32)) * torch.finfo(F32).min).contiguous()
+        ws["key_bias"] = key_bias
+        ops.bert_embed(input_ids.contiguous(), None if token_type_ids is None else token_type_ids.contiguous(),
+                       self.word, self.posw, self.typew, ws["emb"])
+        ops.layernorm_fwd(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, y_bf16=ws["yb"][0], y_f32=ws["y"],
+                          lora_a=self.lora_a(0))
+        for l, lay in enumerate(self.layers):
+            ops.gemm(ws["yb"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
+            ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], key_bias=key_bias)
+            ops.gemm(ws["ctx"][l], lay.w_o, ws["s1"][l], EPI_RESID_F32, bias=lay.b_o, resid=ws["y"])
+            ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ws["ymb"], y_f32=ws["ym"],
+                              stats=ws["sta"][l])
+            ops.gemm(ws["ymb"], lay.w_fc1, ws["act"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
+            ops.gemm(ws["act"], lay.w_fc2, ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"])
+            nxt = self.lora_a(l + 1) if l + 1 < L else self._zero_a
+            ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1], y_f32=ws["y"],
+                              lora_a=nxt, stats=ws["stb"][l])
+        out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
+        if self.head == "mlm_softmax_mean":
+            ops.gemm(ws["yb"][L], self.w_tr, ws["tg"], EPI_GELU_BF16, bias=self.b_tr, aux=ws["tz"], K=H)
+            ops.layernorm_fwd(ws["tg"], self.ln_t[0], self.ln_t[1], self.eps_t, y_bf16=ws["tn"], stats=ws["st_t"])
+            ops.gemm(ws["tn"], self.w_head_bf, ws["logits"], EPI_F32, bias=self.extra(1))
+            ops.softmax_meanpool_fwd(ws["logits"], B, S, out, ws["sm"])
+        else:
+            ops.meanpool_tokens_fwd(ws["y"], B, S, ws["mp"])
+            ops.gemm(ws["mp"], self.w_head_bf, out, EPI_F32, bias=self.extra(1))
+        return out
+
+    def backward(self, dout):
+        ws = self.ws
+        B, S, M, H, L = ws["B"], ws["S"], ws["M"], self.H, len(self.layers)
+        scale = 0.125
+        self.flat.bind_grads()
+        gw, gb = self.extra(0, grad=True), self.extra(1, grad=True)
+        ops.transpose_bf16(self.w_head_bf, self.out_dim, self.head_in, self.w_head_t)
+        if self.head == "mlm_softmax_mean":
+            ops.softmax_meanpool_bwd(ws["logits"], ws["sm"], dout, B, S, ws["dlog"])
+            ops.transpose_bf16(ws["dlog"], M, self.out_dim, ws["dlog_t"])
+            ops.transpose_bf16(ws["tn"], M, H, ws["tn_t"])
+            ops.gemm(ws["dlog_t"], ws["tn_t"], gw, EPI_RESID_F32, resid=gw)          # dW_dec += dlogits^T tn
+            ops.colsum(ws["dlog"], M, self.out_dim, gb)
+            ops.gemm(ws["dlog"], self.w_head_t, ws["dtn"], EPI_BF16)                   # d tn
+            ops.layernorm_bwd(ws["tg"], ws["st_t"], self.ln_t[0], 0, g_gemm=ws["dtn"], dx_bf16=ws["dtg"])
+            ops.dgelu_mul(ws["dtg"], ws["tz"], M, H, ws["dtg"])
+            ops.gemm(ws["dtg"], self.w_tr_t, ws["dh"], EPI_BF16)                       # d (last hidden state)
+            g_resid, g_gemm = None, ws["dh"]
+        else:
+            ops.cast_f32_bf16(dout, ws["dout_bf"])
+            ops.transpose_bf16(ws["dout_bf"], B, self.out_dim, ws["dout_t"])
+            ops.transpose_bf16(ws["mp"], B, H, ws["mp_t"])
+            ops.gemm(ws["dout_t"], ws["mp_t"], gw, EPI_RESID_F32, resid=gw)            # dW_proj += dout^T mean
+            ops.colsum(dout, B, self.out_dim, gb)
+            ops.gemm(ws["dout_bf"], self.w_head_t, ws["dmp"], EPI_F32)
+            ops.meanpool_tokens_bwd(ws["dmp"], B, S, ws["dyl"])
+            g_resid, g_gemm = ws["dyl"], None
+        dt_in, a_in = None, None
+        for l in range(L - 1, -1, -1):
+            lay = self.layers[l]
+            ops.layernorm_bwd(ws["s2"][l], ws["stb"][l], lay.ln_b[0], 1, g_resid=g_resid, g_gemm=g_gemm, dt=dt_in,
+                              lora_a=a_in, dx_f32=ws["ds"], dx_bf16=ws["dsb"])
+            ops.gemm(ws["dsb"], lay.w_fc2_t, ws["dz"], EPI_DGELU_BF16, aux=ws["z"][l])
+            ops.gemm(ws["dz"], lay.w_fc1_t, ws["dh"], EPI_BF16)
+            ops.layernorm_bwd(ws["s1"][l], ws["sta"][l], lay.ln_a[0], 1, g_resid=ws["ds"], g_gemm=ws["dh"],
+                              dx_f32=ws["ds1"], dx_bf16=ws["dsb"])
+            ops.gemm(ws["dsb"], lay.w_o_t, ws["dctx"], EPI_BF16)
+            ops.attn_bwd(ws["qkv"][l], ws["ctx"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
+                         key_bias=ws["key_bias"])
+            lb = self.lora_b(l)
+            if lb is not None:
+                gbb = self.lora_b(l, grad=True)
+                ops.lora_grad(ws["dqkv"], ws["yb"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gbb[0], gbb[1])
+            if l > 0:  # embeddings are frozen: nothing to do below layer 0
+                ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
+                g_resid, g_gemm = ws["ds1"], ws["dh"]
+                dt_in, a_in = (ws["dt"], self.lora_a(l)) if lb is not None else (None, None)
+
+
+# ====================================================================================== autograd integration
+class _EncoderFn(torch.autograd.Function):
+    """One autograd node per encoder: forward and backward are whole kernel sequences.  Trainable parameters are
+    passed only so autograd records the node; their gradients are accumulated in place by the kernels (into the
+    flat buffer ``p.grad`` aliases), hence ``None`` is returned for them."""
+
+    @staticmethod
+    def forward(ctx, engine, fwd_args, *params):
+        ctx.engine = engine
+        return engine.forward(*fwd_args)
+
+    @staticmethod
+    def backward(ctx, dout):
+        ctx.engine.backward(dout.contiguous())
+        return (None, None) + (None,) * len(ctx.engine.flat.params)
+
+
+def _engine_for(module, build):
+    eng = getattr(module, "_engine", None)
+    if eng is None or not eng.flat.valid():
+        if not torch.cuda.is_available():
+            raise RuntimeError("bioscanclip needs a ROCm GPU: all arithmetic runs in libbsclip_hip.so "
+                               "(there is no CPU/torch fallback)")
+        eng = build()
+        module._engine = eng
+    return eng
+
+
+def run_encoder(module, build, fwd_args):
+    eng = _engine_for(module, build)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in eng.flat.params):
+        return _EncoderFn.apply(eng, fwd_args, *eng.flat.params)
+    return eng.forward(*fwd_args)

@@ -28,7 +28,7 @@ SIGNATURES = {
     "bsclip_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P]),
     "bsclip_gemm_set_tile": (I, [I]),
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, P]),
-    "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, P, I, P, P, I, P, P, I, P]),
+    "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, P]),
     "bsclip_attn_bwd": (I, [P, I, P, P, I, P, I, I, I, P, F, P, I, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, P]),
@@ -38,6 +38,7 @@ SIGNATURES = {
     "bsclip_softmax_meanpool_bwd": (I, [P, P, P, I, I, I, P, I, P]),
     "bsclip_meanpool_tokens_fwd": (I, [P, I, I, I, P, I, P]),
     "bsclip_meanpool_tokens_bwd": (I, [P, I, I, I, I, P, P]),
+    "bsclip_dgelu_mul": (I, [P, I, P, I, I, I, P, I, P]),
     "bsclip_l2norm_fwd": (I, [P, I, I, P, P, P]),
     "bsclip_l2norm_bwd": (I, [P, P, P, I, I, P, P]),
     "bsclip_infonce_workspace_floats": (L, [I, I]),

@@ -101,10 +101,10 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
     M = x.shape[0] if M is None else M
     _req(x.dtype in (F32, BF16) and x.shape[1] >= H and M <= x.shape[0], "layernorm_bwd: bad x")
     _req(stats.dtype == F32 and stats.numel() >= 2 * M, "layernorm_bwd: stats")
-    ld_g = ld_dxb = 0
+    ld_g = ld_dxb = ld_gr = ld_dx = 0
     if g_resid is not None:
-        _req(g_resid.dtype == F32 and g_resid.is_contiguous() and g_resid.shape[0] >= M and g_resid.shape[1] == H,
-             "g_resid must be contiguous f32 [M,H]")
+        ld_gr = _rowmajor(g_resid, "g_resid")
+        _req(g_resid.dtype == F32 and g_resid.shape[0] >= M and g_resid.shape[1] >= H, "g_resid must be f32 [M,>=H]")
     if g_gemm is not None:
         ld_g = _rowmajor(g_gemm, "g_gemm")
         _req(g_gemm.dtype == BF16 and g_gemm.shape[0] >= M and g_gemm.shape[1] >= H, "g_gemm must be bf16 [M,>=H]")
@@ -113,14 +113,14 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
         _req(lora_a is not None and tuple(lora_a.shape) == (8, H) and lora_a.dtype == F32 and lora_a.is_contiguous(),
              "lora_a must be f32 [8,H]")
     if dx_f32 is not None:
-        _req(dx_f32.dtype == F32 and dx_f32.is_contiguous() and dx_f32.shape[0] >= M and dx_f32.shape[1] == H,
-             "dx_f32 must be contiguous f32 [M,H]")
+        ld_dx = _rowmajor(dx_f32, "dx_f32")
+        _req(dx_f32.dtype == F32 and dx_f32.shape[0] >= M and dx_f32.shape[1] >= H, "dx_f32 must be f32 [M,>=H]")
     if dx_bf16 is not None:
         ld_dxb = _rowmajor(dx_bf16, "dx_bf16")
         _req(dx_bf16.dtype == BF16 and dx_bf16.shape[0] >= M and dx_bf16.shape[1] >= H, "dx_bf16 too small")
     check(_l.load().bsclip_layernorm_bwd(_p(x), ld_x, int(x.dtype == BF16), _p(stats), _p(gamma), M, H, _p(g_resid),
-                                         _p(g_gemm), ld_g, _p(dt), _p(lora_a) if dt is not None else None, int(mode),
-                                         _p(dx_f32), _p(dx_bf16), ld_dxb, _stream()))
+                                         ld_gr, _p(g_gemm), ld_g, _p(dt), _p(lora_a) if dt is not None else None,
+                                         int(mode), _p(dx_f32), ld_dx, _p(dx_bf16), ld_dxb, _stream()))
 
 
 def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None):
@@ -200,6 +200,12 @@ def meanpool_tokens_bwd(d_pooled, B, S, dx):
     _req(d_pooled.dtype == F32 and d_pooled.shape[0] >= B and d_pooled.shape[1] >= H, "d_pooled f32 [B,>=H]")
     _req(dx.dtype == F32 and dx.is_contiguous() and dx.shape[0] >= B * S, "dx f32 [B*S,H]")
     check(_l.load().bsclip_meanpool_tokens_bwd(_p(d_pooled), _rowmajor(d_pooled, "d_pooled"), B, S, H, _p(dx), _stream()))
+
+
+def dgelu_mul(g, z, M, N, out):
+    _req(all(t.dtype == BF16 and t.shape[0] >= M and t.shape[1] >= N for t in (g, z, out)), "dgelu_mul: bf16 [M,>=N]")
+    check(_l.load().bsclip_dgelu_mul(_p(g), _rowmajor(g, "g"), _p(z), _rowmajor(z, "z"), M, N, _p(out),
+                                     _rowmajor(out, "out"), _stream()))
 
 
 def l2norm_fwd(x, y, inv_norm):

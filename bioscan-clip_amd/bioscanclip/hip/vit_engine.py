@@ -1,0 +1,12 @@
+"""Entry used by ``LoRA_ViT_timm.forward`` (reference image_encoder.py:108-109)."""
+import torch
+
+from .engine import ViTEngine, run_encoder
+
+
+def vit_forward(module, x):
+    if not (isinstance(x, torch.Tensor) and x.is_cuda):
+        raise RuntimeError("LoRA_ViT_timm.forward: the image batch must live on the GPU "
+                           "(bioscanclip has no CPU compute path)")
+    x = x.to(torch.float32).contiguous()
+    return run_encoder(module, lambda: ViTEngine(module, x.device), (x,))

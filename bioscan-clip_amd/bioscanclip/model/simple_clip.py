@@ -1,0 +1,103 @@
+"""SimpleCLIP and ``load_clip_model`` -- drop-in for reference ``bioscanclip/model/simple_clip.py``.
+
+``SimpleCLIP.forward`` keeps the reference's order and output convention (simple_clip.py:27-50): DNA, image and
+text encoders, each followed by ``F.normalize(p=2, dim=-1)`` (here the HIP l2norm kernel), ``None`` for an absent
+modality.  The open_clip branch (simple_clip.py:36-44,141-145) is outside the accelerated path
+and raises.
+"""
+import torch
+import torch.nn as nn
+
+from bioscanclip.hip.functional import l2_normalize
+from bioscanclip.model.arch import vit_base_patch16_224
+from bioscanclip.model.dna_encoder import Freeze_DNA_Encoder, LoRA_barcode_bert, load_pre_trained_bioscan_bert
+from bioscanclip.model.image_encoder import LoRA_ViT_timm
+from bioscanclip.model.language_encoder import LoRA_bert, load_pre_trained_bert
+
+
+class SimpleCLIP(nn.Module):
+    def __init__(self, image_encoder, dna_encoder, language_encoder, open_clip_model=None):
+        super(SimpleCLIP, self).__init__()
+        if open_clip_model is not None:
+            raise NotImplementedError("the open_clip (ViT-L/14) branch is not part of the HIP-accelerated path")
+        self.image_encoder = image_encoder
+        self.dna_encoder = dna_encoder
+        self.language_encoder = language_encoder
+        self.open_clip_model = None
+        self.tokenizer_for_open_clip = None
+
+    def forward(self, image_input, dna_input, language_input):
+        image_output = None
+        dna_output = None
+        language_output = None
+
+        if self.dna_encoder is not None:
+            dna_output = l2_normalize(self.dna_encoder(dna_input))
+        if self.image_encoder is not None:
+            image_output = l2_normalize(self.image_encoder(image_input))
+        if self.language_encoder is not None:
+            language_output = l2_normalize(self.language_encoder(language_input))
+        return image_output, dna_output, language_output
+
+
+def _load_vit(args):
+    """timm.create_model('vit_base_patch16_224', pretrained=True) (simple_clip.py:150) needs timm + a download.
+    Here: the same parameter tree; weights from ``args.vit_checkpoint`` (a timm state_dict file) when given,
+    otherwise timm's random init (synthetic benchmarks)."""
+    vit = vit_base_patch16_224()
+    ckpt = getattr(args, "vit_checkpoint", None) if args is not None else None
+    if ckpt:
+        vit.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=False)
+    return vit
+
+
+def load_clip_model(args, device=None):
+    """Reference simple_clip.py:125-203, same config keys (``args.model_config.{image,dna,language,output_dim,
+    disable_lora}``, ``args.bioscan_bert_checkpoint``).  MLP / open_clip / full-fine-tuning variants are outside the
+    accelerated path and raise instead of silently running something else."""
+    image_encoder = None
+    dna_encoder = None
+    language_encoder = None
+    mc = args.model_config
+
+    disable_lora = False
+    if hasattr(mc, 'disable_lora'):
+        disable_lora = mc.disable_lora
+    if disable_lora:
+        raise NotImplementedError("disable_lora (full fine-tuning) is not on the HIP-accelerated path yet (SURVEY 8f-4)")
+    if mc.image.model == "lora_clip_image" and hasattr(mc, 'language') and mc.language.model == "lora_clip_text":
+        raise NotImplementedError("the open_clip (ViT-L/14) branch is not part of the HIP-accelerated path")
+
+    if mc.image.input_type == "image":
+        image_encoder = LoRA_ViT_timm(vit_model=_load_vit(args), r=4, num_classes=mc.output_dim)
+    else:
+        raise NotImplementedError("feature-input MLP encoders are outside the accelerated path")
+
+    if hasattr(mc, 'language'):
+        if mc.language.input_type == "sequence":
+            _, pre_trained_bert = load_pre_trained_bert(getattr(args, "bert_small_checkpoint", None))
+            language_encoder = LoRA_bert(model=pre_trained_bert, r=4, num_classes=mc.output_dim)
+        else:
+            raise TypeError(f"Using {mc.language.input_type} as language input is not support yet.")
+
+    if hasattr(mc, 'dna'):
+        if hasattr(mc.dna, 'freeze') and mc.dna.freeze:
+            dna_encoder = Freeze_DNA_Encoder()
+        elif mc.dna.input_type == "sequence":
+            if mc.dna.model == "lora_barcode_bert":
+                ckpt = getattr(args, "bioscan_bert_checkpoint", None)
+                if ckpt is not None and not __import__("os").path.exists(str(ckpt)):
+                    if not getattr(args, "allow_random_init", False):
+                        raise FileNotFoundError(f"BarcodeBERT checkpoint {ckpt} not found "
+                                                "(set allow_random_init=true for synthetic runs)")
+                    ckpt = None
+                pre_trained_barcode_bert = load_pre_trained_bioscan_bert(bioscan_bert_checkpoint=ckpt)
+                dna_encoder = LoRA_barcode_bert(model=pre_trained_barcode_bert, r=4, num_classes=mc.output_dim)
+        else:
+            raise NotImplementedError("feature-input MLP encoders are outside the accelerated path")
+
+    model = SimpleCLIP(image_encoder=image_encoder, dna_encoder=dna_encoder, language_encoder=language_encoder)
+
+    if device is not None:
+        model.to(device)
+    return model

@@ -1,0 +1,42 @@
+"""``__graft_entry__.smoke()``: one tiny Image+DNA training step on cuda:0 through the HIP path, checked against
+the CPU oracle (the oracle is the checker here, never the thing that runs the step)."""
+import torch
+
+
+def run_smoke():
+    from oracle import refcpu, synth
+    from bioscanclip.hip.optim import FusedAdamW
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from bioscanclip.model.loss_func import ContrastiveLoss
+    from bioscanclip.model.simple_clip import SimpleCLIP
+
+    img = LoRA_ViT_timm(arch.VisionTransformerParams(depth=2), r=4, num_classes=768)
+    dna = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2)), r=4, num_classes=768)
+    model = SimpleCLIP(img, dna, None)
+    sd = synth.synth_state_dict(synth.shapes_of(model), seed=3)
+    model.load_state_dict(sd)
+    model.to("cuda:0").train()
+    image, ids, _, label = synth.synth_batch(4, seed=5)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    crit = ContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)
+    opt.zero_grad()
+    io, do, _ = model(image.cuda(), ids.cuda(), None)
+    loss = crit(io, do, None, label.cuda())
+    loss.backward()
+    opt.attach(model)
+    opt.step()
+    torch.cuda.synchronize()
+
+    state = refcpu.StepState(sd)
+    ref_loss, (ri, rd, _), _ = refcpu.train_step(state, image, ids, None, label)
+    e_img = ((io.detach().cpu() - ri).norm() / ri.norm()).item()
+    e_dna = ((do.detach().cpu() - rd).norm() / rd.norm()).item()
+    e_loss = abs(loss.item() - ref_loss.item()) / abs(ref_loss.item())
+    named = dict(model.named_parameters())
+    e_par = max(((named[k].detach().cpu() - state.sd[k].detach()).norm() / state.sd[k].detach().norm()).item()
+                for k in state.train_keys)
+    print(f"smoke: loss {loss.item():.6f} (oracle {ref_loss.item():.6f}), rel err img {e_img:.2e} dna {e_dna:.2e} "
+          f"loss {e_loss:.2e} params-after-step {e_par:.2e}")
+    assert e_img < 2e-2 and e_dna < 2e-2 and e_loss < 2e-3 and e_par < 2e-2, "HIP step disagrees with the CPU oracle"

@@ -123,7 +123,39 @@ __global__ __launch_bounds__(256) void meanpool_tokens_bwd_kernel(const float* _
     *reinterpret_cast<f32x4*>(dx + (size_t)row * H + c) = g;
 }
 
+// out = g * gelu'(z), 4 bf16 per thread
+__global__ __launch_bounds__(256) void dgelu_mul_kernel(const bf16_t* __restrict__ g, int ld_g,
+                                                         const bf16_t* __restrict__ z, int ld_z, int M, int N,
+                                                         bf16_t* __restrict__ out, int ld_o) {
+    const int per = N / 4;
+    const long total = (long)M * per;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long row = it / per;
+        const int c = (int)(it % per) * 4;
+        const uint2 gu = *reinterpret_cast<const uint2*>(g + row * ld_g + c);
+        const uint2 zu = *reinterpret_cast<const uint2*>(z + row * ld_z + c);
+        uint2 o;
+        o.x = pack_bf2(bf2f(gu.x & 0xffff) * dgelu_f(bf2f(zu.x & 0xffff)), bf2f(gu.x >> 16) * dgelu_f(bf2f(zu.x >> 16)));
+        o.y = pack_bf2(bf2f(gu.y & 0xffff) * dgelu_f(bf2f(zu.y & 0xffff)), bf2f(gu.y >> 16) * dgelu_f(bf2f(zu.y >> 16)));
+        *reinterpret_cast<uint2*>(out + row * ld_o + c) = o;
+    }
+}
+
 }  // namespace
+
+extern "C" int bsclip_dgelu_mul(const void* g, int ld_g, const void* z, int ld_z, int M, int N, void* out, int ld_o,
+                                void* stream) {
+    BSCLIP_REQUIRE(g && z && out && M > 0 && N > 0 && N % 4 == 0, "bsclip_dgelu_mul: bad args");
+    BSCLIP_REQUIRE(ld_g >= N && ld_z >= N && ld_o >= N && ld_g % 4 == 0 && ld_z % 4 == 0 && ld_o % 4 == 0,
+                   "bsclip_dgelu_mul: ld_g=%d ld_z=%d ld_o=%d", ld_g, ld_z, ld_o);
+    long blocks = ((long)M * (N / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dgelu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(g), ld_g, static_cast<const bf16_t*>(z), ld_z, M, N,
+                       static_cast<bf16_t*>(out), ld_o);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
 
 extern "C" int bsclip_softmax_meanpool_fwd(const float* logits, int B, int S, int C, float* pooled, float* stats,
                                            void* stream) {

@@ -247,9 +247,9 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
         }
     // contrib slots of (a,a) are unused: zero them so the final sum can run over the whole array
     for (int a = 0; a < nmod; ++a)
-        hipMemsetAsync(contrib + (size_t)(a * nmod + a) * Np, 0, sizeof(float) * Np, s);
+        (void)hipMemsetAsync(contrib + (size_t)(a * nmod + a) * Np, 0, sizeof(float) * Np, s);
     if (Np > N)
-        for (int k = 0; k < nmod * nmod; ++k) hipMemsetAsync(contrib + (size_t)k * Np + N, 0, sizeof(float) * (Np - N), s);
+        for (int k = 0; k < nmod * nmod; ++k) (void)hipMemsetAsync(contrib + (size_t)k * Np + N, 0, sizeof(float) * (Np - N), s);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, contrib, nmod * nmod * Np,
                        1.0f / ((float)ndir * (float)N), loss_out);
     BSCLIP_LAUNCH_CHECK();

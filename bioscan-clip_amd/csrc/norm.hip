@@ -149,11 +149,11 @@ template <int H, bool X_BF16, bool LORA>
 __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __restrict__ x, int ld_x,
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ gamma, int M,
-                                                                  const float* __restrict__ g_resid,
+                                                                  const float* __restrict__ g_resid, int ld_gr,
                                                                   const bf16_t* __restrict__ g_gemm, int ld_g,
                                                                   const float* __restrict__ dt,
                                                                   const float* __restrict__ lora_a, int mode,
-                                                                  float* __restrict__ dx_f32,
+                                                                  float* __restrict__ dx_f32, int ld_dx,
                                                                   bf16_t* __restrict__ dx_bf16, int ld_dxb) {
     constexpr int NV = H / 256;
     const int lane = threadIdx.x & 63;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
         if (g_resid) {
 #pragma unroll
             for (int j = 0; j < NV; ++j)
-                res[j] = *reinterpret_cast<const f32x4*>(g_resid + (size_t)row * H + j * 256 + lane * 4);
+                res[j] = *reinterpret_cast<const f32x4*>(g_resid + (size_t)row * ld_gr + j * 256 + lane * 4);
         }
         if (g_gemm) {
             const bf16_t* p = g_gemm + (size_t)row * ld_g;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
         for (int j = 0; j < NV; ++j) {
             f32x4 d = (dy[j] - c1 - v[j] * c2) * rstd;
             if (mode == 0) d += res[j];
-            if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + (size_t)row * H + j * 256 + lane * 4) = d;
+            if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + (size_t)row * ld_dx + j * 256 + lane * 4) = d;
             if (dx_bf16) {
                 uint2 o;
                 o.x = pack_bf2(d[0], d[1]);
@@ -313,19 +313,21 @@ extern "C" int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, 
 
 #define LN_BWD_LAUNCH(HH, XB, LO)                                                                                \
     hipLaunchKernelGGL((layernorm_bwd_kernel<HH, XB, LO>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, stats, \
-                       gamma, M, g_resid, static_cast<const bf16_t*>(g_gemm), ld_g, dt, lora_a, mode, dx_f32,      \
-                       static_cast<bf16_t*>(dx_bf16), ld_dxb)
+                       gamma, M, g_resid, ld_gr, static_cast<const bf16_t*>(g_gemm), ld_g, dt, lora_a, mode, dx_f32, \
+                       ld_dx, static_cast<bf16_t*>(dx_bf16), ld_dxb)
 
 extern "C" int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M,
-                                    int H, const float* g_resid, const void* g_gemm, int ld_g, const float* dt,
-                                    const float* lora_a, int mode, float* dx_f32, void* dx_bf16, int ld_dxb,
-                                    void* stream) {
+                                    int H, const float* g_resid, int ld_gr, const void* g_gemm, int ld_g,
+                                    const float* dt, const float* lora_a, int mode, float* dx_f32, int ld_dx,
+                                    void* dx_bf16, int ld_dxb, void* stream) {
     BSCLIP_REQUIRE(x && stats && gamma && M > 0, "bsclip_layernorm_bwd: null/empty input");
     BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_bwd: H=%d (supported: 768, 512)", H);
     BSCLIP_REQUIRE(g_resid || g_gemm, "bsclip_layernorm_bwd: no incoming gradient");
     BSCLIP_REQUIRE(mode == 0 || mode == 1, "bsclip_layernorm_bwd: mode=%d", mode);
     BSCLIP_REQUIRE((dt == nullptr) == (lora_a == nullptr), "bsclip_layernorm_bwd: dt and lora_a go together");
     BSCLIP_REQUIRE(!g_gemm || (ld_g >= H && ld_g % 4 == 0), "bsclip_layernorm_bwd: ld_g=%d", ld_g);
+    BSCLIP_REQUIRE(!g_resid || (ld_gr >= H && ld_gr % 4 == 0), "bsclip_layernorm_bwd: ld_gr=%d", ld_gr);
+    BSCLIP_REQUIRE(!dx_f32 || (ld_dx >= H && ld_dx % 4 == 0), "bsclip_layernorm_bwd: ld_dx=%d", ld_dx);
     BSCLIP_REQUIRE(!dx_bf16 || (ld_dxb >= H && ld_dxb % 4 == 0), "bsclip_layernorm_bwd: ld_dxb=%d", ld_dxb);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool lo = lora_a != nullptr;

@@ -69,13 +69,15 @@ int bsclip_gemm_set_tile(int tile);
  * bwd (gamma/beta frozen -> only dx): dy = g_resid(f32, nullable) + g_gemm(bf16, nullable) + dt[M,8] . lora_a
  *   mode 0 (pre-LN, ViT):  dx = g_resid + LNbwd(g_gemm + dt.lora_a)
  *   mode 1 (post-LN, BERT): dx = LNbwd(g_resid + g_gemm + dt.lora_a)
- *   writes dx_f32 [M,H] (nullable) and dx_bf16 [M, ld_dxb] (nullable). */
+ *   writes dx_f32 [M, ld_dx] (nullable) and dx_bf16 [M, ld_dxb] (nullable).  Row strides let the final ViT norm run on
+ *   the token-0 rows only (x, g and dx all strided by 197*H).  stats is indexed by the compact row number. */
 int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma, const float* beta,
                          float eps, void* y_bf16, int ld_y, float* y_f32, const float* lora_a, float* stats,
                          void* stream);
 int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M, int H,
-                         const float* g_resid, const void* g_gemm, int ld_g, const float* dt, const float* lora_a,
-                         int mode, float* dx_f32, void* dx_bf16, int ld_dxb, void* stream);
+                         const float* g_resid, int ld_gr, const void* g_gemm, int ld_g, const float* dt,
+                         const float* lora_a, int mode, float* dx_f32, int ld_dx, void* dx_bf16, int ld_dxb,
+                         void* stream);
 
 /* ---- self-attention (timm Attention.forward; HF BertSelfAttention) ---------------------------------------------
  * qkv bf16 [B*S, ld_qkv] with columns [q | k | v], each heads*64 wide; ctx bf16 [B*S, ld_ctx];
@@ -109,6 +111,9 @@ int bsclip_softmax_meanpool_bwd(const float* logits, const float* stats, const f
 int bsclip_meanpool_tokens_fwd(const float* x, int B, int S, int H, void* out_bf16, int ld_out, void* stream);
 /* autograd of the mean: dx[b,t,:] = d_pooled[b,:] / S  (f32 [B*S, H]) */
 int bsclip_meanpool_tokens_bwd(const float* d_pooled, int ld_d, int B, int S, int H, float* dx, void* stream);
+/* out = g * gelu'(z) elementwise (bf16 [M,N]): autograd of the GELU inside cls.predictions.transform, where the
+ * producer of g is the LayerNorm backward rather than a GEMM. */
+int bsclip_dgelu_mul(const void* g, int ld_g, const void* z, int ld_z, int M, int N, void* out, int ld_o, void* stream);
 int bsclip_l2norm_fwd(const float* x, int M, int D, float* y, float* inv_norm, void* stream);
 int bsclip_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, int M, int D, float* dx, void* stream);
 

@@ -1,0 +1,189 @@
+"""End-to-end parity of the HIP encoders / loss / step against (a) the CPU oracle on identical seeded weights and
+inputs and (b) the golden fixtures produced by the imported reference (tests/golden, oracle/gen_golden.py).
+
+Tolerances (normwise relative L2 error, written here as the contract):
+  * vs the oracle with bf16 operand rounding restated (emulate_bf16=True): embeddings 4e-3  -- same rounding points,
+    remaining difference = accumulation order + bf16 intermediates the oracle keeps in f32 (P, GELU output, ...).
+  * vs the f32 oracle / reference fixtures: embeddings 2e-2, gradients 6e-2 -- 12 layers of bf16 operands (2^-9
+    relative rounding per GEMM operand) against an all-f32 reference; the loss kernel itself is f32-accurate (1e-5).
+Measured values are appended to gpurun_out/parity.jsonl so DESIGN.md can quote them.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import check_summary, load_golden, rel_err  # noqa: E402
+from oracle import refcpu, synth  # noqa: E402
+
+TOL_EMB_EMU = 4e-3
+TOL_EMB_F32 = 2e-2
+TOL_GRAD_F32 = 6e-2
+
+
+def _log(rec):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity.jsonl", "a") as f:
+        f.write(json.dumps(rec) + "\n")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _load(module, prefix, seed):
+    sd = synth.synth_state_dict({prefix + k: v for k, v in synth.shapes_of(module).items()}, seed)
+    module.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    return sd
+
+
+def _oracle_grads(sd, fn):
+    sd = {k: v.clone() for k, v in sd.items()}
+    keys = [k for k in sd if refcpu.is_trainable_key(k) and sd[k].is_floating_point()]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    y = fn(sd)
+    return sd, keys, y
+
+
+def _compare_encoder(name, module, prefix, sd, hip_in, oracle_fn, cot_key, gold):
+    module.to("cuda")
+    module.train()
+    y = module(hip_in)
+    w = synth.synth_tensor(cot_key, y.shape, seed=5)
+    (y * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    sdo, keys, yo = _oracle_grads(sd, oracle_fn)
+    (yo * w).sum().backward()
+    y_emu = oracle_fn({k: v.detach() for k, v in sd.items()}, emulate=True)
+    e_f32, e_emu = rel_err(y, yo), rel_err(y, y_emu)
+    rec = {"test": name, "emb_vs_f32_oracle": e_f32, "emb_vs_bf16_emulating_oracle": e_emu, "grads": {}}
+    named = dict(module.named_parameters())
+    worst = 0.0
+    for k in keys:
+        p = named[k[len(prefix):]]
+        assert p.grad is not None, k
+        e = rel_err(p.grad, sdo[k].grad)
+        rec["grads"][k] = e
+        worst = max(worst, e)
+    rec["worst_grad"] = worst
+    _log(rec)
+    assert torch.isfinite(y).all()
+    assert e_emu < TOL_EMB_EMU, rec
+    assert e_f32 < TOL_EMB_F32, rec
+    assert worst < TOL_GRAD_F32, rec
+    if gold is not None:  # fixtures from the imported reference
+        check_summary(gold[0], y, gold[1]["out"], TOL_EMB_F32, what=name + " ")
+        for k in keys:
+            check_summary(k, named[k[len(prefix):]].grad, gold[1]["grads"][k], TOL_GRAD_F32, what=name + " ")
+
+
+@pytest.mark.parametrize("layers", [2, 12])
+def test_dna_encoder(layers):
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=layers)), r=4,
+                          num_classes=768)
+    sd = _load(m, "dna_encoder.", 11)
+    _, dna, _, _ = synth.synth_batch(2, seed=21)
+    fn = lambda s, emulate=False: refcpu.barcode_bert_encoder(s, dna, emulate_bf16=emulate)
+    _compare_encoder(f"dna_L{layers}", m, "dna_encoder.", sd, dna.cuda(), fn, f"dna.cot.{layers}",
+                     (f"dna.out.{layers}", load_golden("encoders")[f"dna_L{layers}"]))
+
+
+def test_text_encoder():
+    from bioscanclip.model import arch
+    from bioscanclip.model.language_encoder import LoRA_bert
+    m = LoRA_bert(arch.BertModelParams(arch.bert_small_config()), r=4, num_classes=768)
+    sd = _load(m, "language_encoder.", 12)
+    _, _, text, _ = synth.synth_batch(4, seed=22, with_text=True)
+    fn = lambda s, emulate=False: refcpu.bert_text_encoder(s, text, emulate_bf16=emulate)
+    _compare_encoder("txt_L4", m, "language_encoder.", sd, {k: v.cuda() for k, v in text.items()}, fn, "txt.cot",
+                     ("txt.out", load_golden("encoders")["txt_L4"]))
+
+
+@pytest.mark.parametrize("depth", [2, 12])
+def test_vit_encoder(depth):
+    from bioscanclip.model import arch
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=depth), r=4, num_classes=768)
+    sd = _load(m, "image_encoder.", 13)
+    image, _, _, _ = synth.synth_batch(2, seed=23)
+    fn = lambda s, emulate=False: refcpu.vit_encoder(s, image, emulate_bf16=emulate)
+    _compare_encoder(f"vit_L{depth}", m, "image_encoder.", sd, image.cuda(), fn, f"vit.cot.{depth}",
+                     (f"vit.out.{depth}", load_golden("encoders")[f"vit_L{depth}"]))
+
+
+def _build_clip(with_text, seed):
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from bioscanclip.model.language_encoder import LoRA_bert
+    from bioscanclip.model.simple_clip import SimpleCLIP
+    img = LoRA_ViT_timm(arch.vit_base_patch16_224(), r=4, num_classes=768)
+    dna = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config()), r=4, num_classes=768)
+    txt = LoRA_bert(arch.BertModelParams(arch.bert_small_config()), r=4, num_classes=768) if with_text else None
+    model = SimpleCLIP(img, dna, txt)
+    sd = _load(model, "", seed)
+    return model, sd
+
+
+def test_state_dict_matches_reference_keys():
+    g = load_golden("state_dict_keys")
+    model, _ = _build_clip(True, 31)
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert mine == g["keys"]
+    assert sorted(k for k, p in model.named_parameters() if p.requires_grad) == g["trainable"]
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == g["n_trainable"] == 1902848
+
+
+@pytest.mark.parametrize("with_text", [False, True])
+def test_training_trajectory_matches_reference(with_text):
+    """BASELINE config 1 (I+D, B=8, 10 steps) and a 3-step I+D+T run: loss per step and trainable parameters after
+    the last step vs the trajectory the imported reference produced with torch.optim.AdamW."""
+    from bioscanclip.hip.optim import FusedAdamW
+    from bioscanclip.model.loss_func import ContrastiveLoss
+    g = load_golden("trajectory_idt" if with_text else "trajectory_id")
+    model, sd = _build_clip(with_text, g["weight_seed"])
+    model.to("cuda").train()
+    opt = FusedAdamW(model.parameters(), lr=g["lr"])
+    crit = ContrastiveLoss(criterion=torch.nn.CrossEntropyLoss(), logit_scale=1 / 0.07)
+    losses = []
+    for s in range(g["steps"]):
+        image, dna, text, label = synth.synth_batch(g["B"], seed=g["batch_seed0"] + s, with_text=with_text)
+        opt.zero_grad()
+        text = None if text is None else {k: v.cuda() for k, v in text.items()}
+        io, do, to = model(image.cuda(), dna.cuda(), text)
+        loss = crit(io, do, to, label.cuda())
+        loss.backward()
+        if s == 0:
+            named = dict(model.named_parameters())
+            check_summary("traj.img", io, g["first_step"]["image_out"], TOL_EMB_F32)
+            check_summary("traj.dna", do, g["first_step"]["dna_out"], TOL_EMB_F32)
+            worst = 0.0
+            for k, gs in g["first_step"]["grads"].items():
+                s_ = check_summary(k, named[k].grad, gs, 0.15)
+                worst = max(worst, abs(s_["norm"] - gs["norm"]) / max(gs["norm"], 1e-30))
+            _log({"test": f"trajectory text={with_text}", "worst_grad_norm_rel": worst})
+            opt.attach(model)
+        opt.step()
+        losses.append(loss.item())
+    _log({"test": f"trajectory text={with_text}", "losses": losses, "ref": g["losses"]})
+    for a, b in zip(losses, g["losses"]):
+        assert abs(a - b) < 2e-3 * abs(b), (losses, g["losses"])
+    named = dict(model.named_parameters())
+    for k, gs in g["params_after"].items():
+        check_summary(k, named[k], gs, 2e-2)
+
+
+def test_requires_gpu_inputs():
+    from bioscanclip.model import arch
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=1), r=4, num_classes=768)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(1, 3, 224, 224))

@@ -353,7 +353,9 @@ def test_small_ops(ops):
     bq, bv = dev(rnd(768, 4, seed=5)), dev(rnd(768, 4, seed=6))
     ops.waug_set_lora(w, 768, bq, bv)
     assert torch.equal(w[:768, 768:772], bq.bfloat16()) and torch.equal(w[1536:, 772:776], bv.bfloat16())
-    assert w.float().abs().sum() == bq.bfloat16().float().abs().sum() + bv.bfloat16().float().abs().sum()
+    w[:768, 768:772] = 0
+    w[1536:, 772:776] = 0
+    assert (w == 0).all(), "waug_set_lora wrote outside the two LoRA-B blocks"
 
 
 def test_adamw_matches_oracle_and_torch(ops):
