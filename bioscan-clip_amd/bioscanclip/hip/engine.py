@@ -276,7 +276,7 @@ class ViTEngine(EncoderEngineBase):
             ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh"], dx_f32=dx,
                               dx_bf16=dxb)
             ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
-            ops.attn_bwd(ws["qkv"][l], ws["ctx"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"])
+            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"])
             lb = self.lora_b(l)
             if lb is not None:
                 gb = self.lora_b(l, grad=True)
@@ -483,7 +483,7 @@ class BertEngine(EncoderEngineBase):
             ops.layernorm_bwd(ws["s1"][l], ws["sta"][l], lay.ln_a[0], 1, g_resid=ws["ds"], g_gemm=ws["dh"],
                               dx_f32=ws["ds1"], dx_bf16=ws["dsb"])
             ops.gemm(ws["dsb"], lay.w_o_t, ws["dctx"], EPI_BF16)
-            ops.attn_bwd(ws["qkv"][l], ws["ctx"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
+            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
                          key_bias=ws["key_bias"])
             lb = self.lora_b(l)
             if lb is not None:

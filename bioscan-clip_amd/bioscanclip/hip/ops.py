@@ -134,14 +134,15 @@ def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None):
                                     _stream()))
 
 
-def attn_bwd(qkv, ctx, dctx, lse, B, S, heads, scale, dqkv, key_bias=None):
-    ld_qkv, ld_ctx, ld_d = _rowmajor(qkv, "qkv"), _rowmajor(ctx, "ctx"), _rowmajor(dqkv, "dqkv")
-    _req(_rowmajor(dctx, "dctx") == ld_ctx, "attn_bwd: ctx and dctx must share a row stride")
-    _req(all(t.dtype == BF16 for t in (qkv, ctx, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
-    _req(min(qkv.shape[0], ctx.shape[0], dctx.shape[0], dqkv.shape[0]) >= B * S, "attn_bwd: rows")
-    _req(qkv.shape[1] >= 3 * heads * 64 and dqkv.shape[1] >= 3 * heads * 64 and ctx.shape[1] >= heads * 64
-         and dctx.shape[1] >= heads * 64 and lse.numel() >= B * heads * S, "attn_bwd: cols")
-    check(_l.load().bsclip_attn_bwd(_p(qkv), ld_qkv, _p(ctx), _p(dctx), ld_ctx, _p(lse), B, S, heads, _p(key_bias),
+def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None):
+    ld_qkv, ld_ctx, ld_d = _rowmajor(qkv, "qkv"), _rowmajor(dctx, "dctx"), _rowmajor(dqkv, "dqkv")
+    _req(all(t.dtype == BF16 for t in (qkv, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
+    _req(min(qkv.shape[0], dctx.shape[0], dqkv.shape[0]) >= B * S, "attn_bwd: rows")
+    _req(qkv.shape[1] >= 3 * heads * 64 and dqkv.shape[1] >= 3 * heads * 64 and dctx.shape[1] >= heads * 64
+         and lse.numel() >= B * heads * S, "attn_bwd: cols")
+    if key_bias is not None:
+        _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
+    check(_l.load().bsclip_attn_bwd(_p(qkv), ld_qkv, _p(dctx), ld_ctx, _p(lse), B, S, heads, _p(key_bias),
                                     float(scale), _p(dqkv), ld_d, _stream()))
 
 

@@ -11,8 +11,8 @@
 //     next MFMA's operand", cdna_hip_programming.md 3): P^T never goes through LDS.
 // The operand that must be k-strided for that second product (V^T, Q^T, dO^T, K^T) is staged once per workgroup as a
 // transposed LDS image with rows padded by 8 B, which makes the paired ds_read_b64 fragment reads conflict-free.
-// Backward runs two phases in one launch: key-owner waves produce dK/dV, then query-owner waves produce dQ, so
-// nothing is accumulated across waves (no atomics, bitwise reproducible).
+// Backward runs two phases in one launch: query-owner waves produce delta = rowsum(P.dP) and dQ, then key-owner waves
+// produce dK/dV, so nothing is accumulated across waves (no atomics, bitwise reproducible).
 #include <math.h>
 
 #include "common.h"
@@ -184,7 +184,6 @@ __global__ __launch_bounds__(NB * 64) void attn_fwd_kernel(const bf16_t* __restr
 
 template <int NB>
 __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
-                                                            const bf16_t* __restrict__ ctx,
                                                             const bf16_t* __restrict__ dctx, int ld_ctx,
                                                             const float* __restrict__ lse, int S, int heads,
                                                             const float* __restrict__ key_bias, float scale,
@@ -192,10 +191,10 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
     constexpr int SP = NB * 32;
     constexpr int RM = SP * ROWB, TR = 64 * tstride(SP);
     __shared__ __attribute__((aligned(16))) char smem[2 * RM + 2 * TR + 3 * SP * 4];
-    char* sR0 = smem;            // phase A: Q   | phase B: K
-    char* sR1 = smem + RM;       // phase A: dO  | phase B: V
-    char* sT0 = smem + 2 * RM;   // phase A: Q^T | phase B: K^T
-    char* sT1 = sT0 + TR;        // phase A: dO^T
+    char* sR0 = smem;            // phase 1: K   | phase 2: Q
+    char* sR1 = smem + RM;       // phase 1: V   | phase 2: dO
+    char* sT0 = smem + 2 * RM;   // phase 1: K^T | phase 2: Q^T
+    char* sT1 = sT0 + TR;        //              | phase 2: dO^T
     float* sLse = reinterpret_cast<float*>(sT1 + TR);
     float* sDelta = sLse + SP;
     float* sBias = sDelta + SP;
@@ -208,34 +207,85 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
     const bf16_t* qb = qkv + (size_t)b * S * ld + hd * 64;
     const bf16_t* kb = qb + HW;
     const bf16_t* vb = kb + HW;
-    const bf16_t* ob = ctx + (size_t)b * S * ld_ctx + hd * 64;
     const bf16_t* dob = dctx + (size_t)b * S * ld_ctx + hd * 64;
     bf16_t* dqb = dqkv + (size_t)b * S * ld_d + hd * 64;
 
-    // ---------------- phase A staging: Q, dO (row-major + transposed), lse, delta, bias ----------------
-    stage_tile<SP>(qb, ld, S, sR0, sT0, tid, NT);
-    stage_tile<SP>(dob, ld_ctx, S, sR1, sT1, tid, NT);
-    for (int it = tid; it < SP * 8; it += NT) {  // delta[q] = sum_d dO[q,d] O[q,d]; 8 consecutive lanes share a row
-        const int row = it >> 3, c = it & 7;
-        float d = 0.f;
-        if (row < S) {
-            const u32x4 a = *reinterpret_cast<const u32x4*>(dob + (size_t)row * ld_ctx + c * 8);
-            const u32x4 o = *reinterpret_cast<const u32x4*>(ob + (size_t)row * ld_ctx + c * 8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                d += bf2f(a[i] & 0xffff) * bf2f(o[i] & 0xffff) + bf2f(a[i] >> 16) * bf2f(o[i] >> 16);
-        }
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        d += __shfl_xor(d, 4, 64);
-        if (c == 0) sDelta[row] = d;
-    }
+    // ---------------- phase 1 staging: K (row-major + transposed), V (row-major), lse, bias ----------------
+    stage_tile<SP>(kb, ld, S, sR0, sT0, tid, NT);
+    stage_tile<SP>(vb, ld, S, sR1, nullptr, tid, NT);
     for (int k = tid; k < SP; k += NT) {
         sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
         sLse[k] = (k < S) ? lse[((size_t)b * heads + hd) * S + k] : INFINITY;  // padded queries -> p = 0
     }
     {
-        // ---------------- phase A: this wave owns keys [k0, k0+32): dV, dK ----------------
+        // ---------------- phase 1: this wave owns queries [q0, q0+32): delta, then dQ ----------------
+        const int q0 = wave * 32;
+        const int qrow = min(q0 + (lane & 31), S - 1);
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = frag_global(qb, ld, qrow, ks, lane);
+            dof[ks] = frag_global(dob, ld_ctx, qrow, ks, lane);
+        }
+        __syncthreads();
+        const float lse_q = sLse[q0 + (lane & 31)];
+        // pass 1: delta_q = sum_key P[q,key] dP[q,key], from the SAME P and dP the gradient uses, so that
+        // sum_key dS[q,key] = 0 holds to f32 rounding (delta from the bf16-rounded O does not: it loses the
+        // cancellation whenever the values of a head are nearly equal across keys).
+        float dpart = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < NB; ++kt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);     // S^T[key, q]
+                dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);  // dP^T[key, q]
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dpart += __expf(s[4 * g + i] * scale + b4[i] - lse_q) * dp[4 * g + i];
+            }
+        }
+        const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
+        if (h == 0) sDelta[q0 + (lane & 31)] = delta_q;
+        // pass 2: dS^T = P^T (dP^T - delta) * scale;  dQ^T += K^T dS^T
+        f32x16 dq[2] = {zero16(), zero16()};
+#pragma unroll 1
+        for (int kt = 0; kt < NB; ++kt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);
+                dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pr = __expf(s[4 * g + i] * scale + b4[i] - lse_q);
+                    dp[4 * g + i] = pr * (dp[4 * g + i] - delta_q) * scale;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 dsb = pack8(dp, s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = mfma32(frag_t<SP>(sT0, 32 * dt, 32 * kt + 16 * s2, lane), dsb, dq[dt]);  // K^T dS^T
+            }
+        }
+        const int q = q0 + (lane & 31);
+        if (q < S) store_dt(dq, 1.0f, dqb + (size_t)q * ld_d, lane);
+    }
+    __syncthreads();
+    // ---------------- phase 2 staging: Q, dO (row-major + transposed) ----------------
+    stage_tile<SP>(qb, ld, S, sR0, sT0, tid, NT);
+    stage_tile<SP>(dob, ld_ctx, S, sR1, sT1, tid, NT);
+    {
+        // ---------------- phase 2: this wave owns keys [k0, k0+32): dV, dK ----------------
         const int k0 = wave * 32;
         const int krow = min(k0 + (lane & 31), S - 1);
         bf16x8 kf[4], vf[4];
@@ -282,52 +332,6 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
             store_dt(dv, 1.0f, dqb + (size_t)key * ld_d + 2 * HW, lane);
         }
     }
-    __syncthreads();
-    // ---------------- phase B staging: K, V row-major, K^T ----------------
-    stage_tile<SP>(kb, ld, S, sR0, sT0, tid, NT);
-    stage_tile<SP>(vb, ld, S, sR1, nullptr, tid, NT);
-    {
-        // ---------------- phase B: this wave owns queries [q0, q0+32): dQ ----------------
-        const int q0 = wave * 32;
-        const int qrow = min(q0 + (lane & 31), S - 1);
-        bf16x8 qf[4], dof[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = frag_global(qb, ld, qrow, ks, lane);
-            dof[ks] = frag_global(dob, ld_ctx, qrow, ks, lane);
-        }
-        __syncthreads();
-        const float lse_q = sLse[q0 + (lane & 31)];
-        const float delta_q = sDelta[q0 + (lane & 31)];
-        f32x16 dq[2] = {zero16(), zero16()};
-#pragma unroll 1
-        for (int kt = 0; kt < NB; ++kt) {
-            f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);     // S^T[key, q]
-                dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);  // dP^T[key, q]
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float pr = __expf(s[4 * g + i] * scale + b4[i] - lse_q);
-                    dp[4 * g + i] = pr * (dp[4 * g + i] - delta_q) * scale;
-                }
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 dsb = pack8(dp, s2);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = mfma32(frag_t<SP>(sT0, 32 * dt, 32 * kt + 16 * s2, lane), dsb, dq[dt]);  // K^T dS^T
-            }
-        }
-        const int q = q0 + (lane & 31);
-        if (q < S) store_dt(dq, 1.0f, dqb + (size_t)q * ld_d, lane);
-    }
 }
 
 }  // namespace
@@ -357,15 +361,14 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
 #define ATTN_BWD_CASE(NBV)                                                                                       \
     case NBV:                                                                                                    \
         hipLaunchKernelGGL((attn_bwd_kernel<NBV>), dim3(B * heads), dim3(NBV * 64), 0, s,                        \
-                           static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(ctx),             \
-                           static_cast<const bf16_t*>(dctx), ld_ctx, lse, S, heads, key_bias, scale,             \
-                           static_cast<bf16_t*>(dqkv), ld_dqkv);                                                 \
+                           static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx,    \
+                           lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv);                 \
         break;
 
-extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* ctx, const void* dctx, int ld_ctx,
-                               const float* lse, int B, int S, int heads, const float* key_bias, float scale,
-                               void* dqkv, int ld_dqkv, void* stream) {
-    BSCLIP_REQUIRE(qkv && ctx && dctx && lse && dqkv, "bsclip_attn_bwd: null pointer");
+extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
+                               int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
+                               void* stream) {
+    BSCLIP_REQUIRE(qkv && dctx && lse && dqkv, "bsclip_attn_bwd: null pointer");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_bwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_dqkv >= 3 * heads * 64 && ld_dqkv % 4 == 0 &&
                        ld_ctx >= heads * 64 && ld_ctx % 8 == 0,

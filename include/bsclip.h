@@ -83,12 +83,12 @@ int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats
  * qkv bf16 [B*S, ld_qkv] with columns [q | k | v], each heads*64 wide; ctx bf16 [B*S, ld_ctx];
  * key_bias f32 [B,S] additive per key (HF extended attention mask, language_encoder.py:89) or NULL;
  * lse f32 [B, heads, S] = log-sum-exp of the scaled scores (saved for backward).  head_dim is 64.
- * S <= 224.  bwd consumes dctx/ctx and writes dqkv in the same layout as qkv. */
+ * S <= 224.  bwd recomputes P from qkv + lse, forms delta = rowsum(P . dP) in f32 from the same tiles (not from the
+ * bf16-rounded ctx: that loses the softmax-backward cancellation), and writes dqkv in the same layout as qkv. */
 int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale,
                     void* ctx, int ld_ctx, float* lse, void* stream);
-int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* ctx, const void* dctx, int ld_ctx, const float* lse,
-                    int B, int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
-                    void* stream);
+int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
+                    int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, void* stream);
 
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column

@@ -201,7 +201,7 @@ def test_attention_fwd_bwd(ops, B, S, heads, masked):
     dctx = dev(rnd(B * S, H, seed=2).bfloat16())
     (gq,) = torch.autograd.grad(ref, qf, dctx.float())
     dqkv = torch.full((B * S, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
-    ops.attn_bwd(qkv, ctx, dctx, lse, B, S, heads, scale, dqkv, key_bias=bias)
+    ops.attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=bias)
     gq = gq.reshape(B * S, 3 * H)
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
         assert rel_err(dqkv[:, sl].float(), gq[:, sl]) < 1e-2, name
