@@ -109,18 +109,39 @@ def time_dominant_gemm(B, device, iters=20):
             "avg_launch_ms": round(mean_ms, 4), "per_shape_ms": [round(x, 4) for x in ms]}
 
 
-def cpu_baseline(seconds_budget=25.0):
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box exposes every
+    host CPU in the mask but grants a 16-CPU share; oversubscribing the torch pool makes the baseline meaningless)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // p))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(seconds_budget=20.0):
     """CPU oracle (port of the reference path) on BASELINE configs[0]: I+D, B=8, f32, AdamW; bounded sample."""
     from oracle import refcpu, synth
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
     from bioscanclip.model.image_encoder import LoRA_ViT_timm
     from bioscanclip.model.simple_clip import SimpleCLIP
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
     torch.set_num_threads(cores)
     model = SimpleCLIP(LoRA_ViT_timm(arch.vit_base_patch16_224(), r=4, num_classes=768),
                        LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config()), r=4, num_classes=768),
@@ -132,10 +153,11 @@ def cpu_baseline(seconds_budget=25.0):
         t0 = time.perf_counter()
         refcpu.train_step(state, image, dna, None, label)
         dt = time.perf_counter() - t0
+        print(f"[bench] cpu_baseline step {s}: {dt:.2f} s", file=sys.stderr, flush=True)
         if s >= 1:  # first step warms the allocator / thread pool
             done += 1
             t_total += dt
-        if t_total > seconds_budget and done >= 2:
+        if done >= 1 and t_total + dt > seconds_budget:
             break
     cpu = "unknown"
     try:
@@ -172,10 +194,6 @@ def main():
     torch.cuda.set_device(device)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline()
-
     from bioscanclip.hip import dist as hdist
     from bioscanclip.hip.optim import FusedAdamW
     from bioscanclip.model.loss_func import ContrastiveLoss, GlobalBatchContrastiveLoss
@@ -198,6 +216,9 @@ def main():
         return loss
 
     loss = step()  # builds engines / workspaces
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] first step done, loss {loss.item():.5f}", file=sys.stderr, flush=True)
     opt.attach(model)
     hdist.broadcast_trainable(model)
     for _ in range(a.warmup):
@@ -247,8 +268,9 @@ def main():
                               "algorithmic_tflop_per_gpu_step": round(step_tflop_per_gpu, 3)},
         }
         out["roofline"] = time_dominant_gemm(B, device)
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
+        print(f"[bench] gpu: {ms:.2f} ms/step, {out['value']} pairs/s; timing cpu baseline ...", file=sys.stderr, flush=True)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
