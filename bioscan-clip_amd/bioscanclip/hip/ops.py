@@ -253,6 +253,18 @@ def infonce_fwd_bwd(zs, labels, scale, loss_out, dzs=None, row0=0, n_local=None,
                                            _p(workspace), _stream()))
 
 
+_LG_WS = {}
+
+
+def _lora_grad_workspace(H, device):
+    key = (H, str(device))
+    ws = _LG_WS.get(key)
+    if ws is None:
+        ws = torch.empty(_l.load().bsclip_lora_grad_workspace_floats(H), dtype=F32, device=device)
+        _LG_WS[key] = ws
+    return ws
+
+
 def lora_grad(dqkv, h_aug, M, H, lora_b, dt, dA, dBq, dBv):
     _req(dqkv.dtype == BF16 and h_aug.dtype == BF16, "lora_grad: bf16 inputs")
     _req(dqkv.shape[0] >= M and dqkv.shape[1] >= 3 * H and h_aug.shape[0] >= M and h_aug.shape[1] >= H + 8, "lora_grad shapes")
@@ -261,7 +273,8 @@ def lora_grad(dqkv, h_aug, M, H, lora_b, dt, dA, dBq, dBv):
     _req(dA.dtype == F32 and dA.is_contiguous() and tuple(dA.shape) == (8, H), "dA f32 [8,H]")
     _req(all(t.dtype == F32 and t.is_contiguous() and tuple(t.shape) == (H, 4) for t in (dBq, dBv)), "dB f32 [H,4]")
     check(_l.load().bsclip_lora_grad(_p(dqkv), _rowmajor(dqkv, "dqkv"), _p(h_aug), _rowmajor(h_aug, "h_aug"), M, H,
-                                     _p(lora_b), _p(dt), _p(dA), _p(dBq), _p(dBv), _stream()))
+                                     _p(lora_b), _p(dt), _p(dA), _p(dBq), _p(dBv),
+                                     _p(_lora_grad_workspace(H, dqkv.device)), _stream()))
 
 
 def colsum(g, M, N, out):

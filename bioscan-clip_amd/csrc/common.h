@@ -39,8 +39,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(unsigned short, h);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    const f32x2_t v = {lo, hi};  // one v_cvt_pk_bf16_f32 (the scalar-cast-and-or form costs 3 VALU per pair)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 // ---- wave (64-lane) reductions ---------------------------------------------------------------------

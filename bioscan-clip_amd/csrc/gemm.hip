@@ -11,7 +11,20 @@
 //   * XCD-aware bijective blockIdx remap: the 8 XCDs each walk a contiguous range of tiles, N fastest, so the
 //     A row-panel and the (small) weight matrix are re-used out of that XCD's private L2;
 //   * epilogues fused in registers: bias, exact GELU (+ saved pre-activation), residual add in f32, GELU'
-//     scaling for the backward pass, and the ViT patch-embed row remap + position add.
+//     scaling for the backward pass, and the ViT patch-embed row remap + position add.  Bias is loaded once per
+//     thread before the stores and every epilogue is branch-free per element (a per-element "if (bias)" makes
+//     hipcc wait vmcnt(0) around each load: 32 serial L2 round trips per tile).
+//
+// Two main loops:
+//   gemm_nt_kernel     generic BMxBN tile, one barrier per K-tile (prefetch of tile t+1 behind the MFMAs of tile t);
+//                      used for small / odd shapes (128x128, 256x128).
+//   gemm_nt_pp_kernel  256x256 tile, 8 waves = two groups of four that run half a phase apart ("ping-pong"): each
+//                      K-tile is four phases {ds_read fragments + issue one half-tile of LDS-DMA | barrier | 16 MFMA |
+//                      barrier}; while one group's waves are in their MFMA segment their SIMD partners (other group)
+//                      are in the LDS/DMA segment.  LDS-DMA stays in flight across barriers: one counted
+//                      s_waitcnt vmcnt(2) per K-tile (never 0 in the steady state), A halves issued 3-4 phases ahead.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -32,12 +45,9 @@ struct EpiArgs {
     int ld_aux;
 };
 
+// v already holds acc (+ bias).  No data-dependent branch guards a load.
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, int ldc, const EpiArgs& e) {
-    if (e.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + n);
-        v += b;
-    }
     if constexpr (EPI == BSCLIP_EPI_BF16) {
         uint2 o;
         o.x = pack_bf2(v[0], v[1]);
@@ -46,7 +56,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, i
     } else if constexpr (EPI == BSCLIP_EPI_F32) {
         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
     } else if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
-        if (e.aux) {
+        if (e.aux) {  // store only
             uint2 z;
             z.x = pack_bf2(v[0], v[1]);
             z.y = pack_bf2(v[2], v[3]);
@@ -74,7 +84,10 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, i
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+// ---------------------------------------------------------------------------------------------------------------
+// generic tile, one barrier per K-tile
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool HAS_BIAS>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda,
                                                                          const bf16_t* __restrict__ B, int ldb,
                                                                          void* __restrict__ C, int ldc, int M, int N,
@@ -163,55 +176,287 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const bf
     }
 
     // ---- epilogue: lane holds C[m][n..n+3] with m = ... + (lane&15), n = ... + (lane>>4)*4 ----
+    f32x4 bias[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + fr;
-        if (m < M) {
+    for (int j = 0; j < TN; ++j) {
+        bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (HAS_BIAS) bias[j] = *reinterpret_cast<const f32x4*>(e.bias + n0 + wn * WTN + j * 16 + fq * 4);
+    }
+    // bias is consumed before the row guards: a loaded register live across a divergent branch makes hipcc wait
+    // vmcnt(0) (which also drains the previous row's stores) at the top of every guarded block
+    if constexpr (HAS_BIAS) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WTN + j * 16 + fq * 4;
-                epilogue_store<EPI>(acc[i][j], m, n, C, ldc, e);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += bias[j];
+    }
+    // Row guards only on the last (partial) M tile: per-row divergent branches make hipcc drain vmcnt(0) -- loads AND
+    // the previous row's stores -- at the top of every guarded block.
+    auto store_rows = [&](auto guard) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+            if (!decltype(guard)::value || m < M) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WTN + j * 16 + fq * 4;
+                    epilogue_store<EPI>(acc[i][j], m, n, C, ldc, e);
+                }
             }
         }
+    };
+    if (m0 + BM <= M) store_rows(std::false_type{});
+    else store_rows(std::true_type{});
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256x256 ping-pong kernel
+// ---------------------------------------------------------------------------------------------------------------
+// LDS: 2 buffer sets x {A[256][64], B[256][64]} bf16 = 128 KiB; a "half" is 128 rows (16 KiB) = 16 wave-instructions of
+// LDS-DMA, two per wave.  Wave w: group g = w>>2 owns output rows [128g, 128g+128) (so it reads only A-half g),
+// wc = w&3 owns output columns [64wc, 64wc+64) (B-half wc>>1).  Per K-tile the wave holds ALL its fragments in
+// registers (A: 2 blocks of 64 rows, B: 2 blocks of 32 columns = 96 VGPRs), loaded in phases 0-2:
+//   phase 0: read A(m0), B(n0) -> MFMA (m0,n0)      DMA: A-half1 of tile t+1
+//   phase 1: read A(m1)        -> MFMA (m1,n0)      DMA: B-half0 of tile t+1
+//   phase 2: read B(n1)        -> MFMA (m1,n1)      DMA: B-half1 of tile t+1
+//   phase 3: (no reads)        -> MFMA (m0,n1)      DMA: A-half0 of tile t+2 ; s_waitcnt vmcnt(2)
+// Hazards (instants = barrier releases; group 1 runs one instant behind group 0):
+//   WAR  A[set] is last read in phase 1, B[set] in phase 2; their re-staging starts two phases later (phase 3 / phase 1
+//        of the next tile), i.e. >= 2 barrier instants after the slower group's reads have been waited for.
+//   RAW  every wave waits (vmcnt) for its own DMA pieces of tile t+1 BEFORE the first barrier of phase 3; the first
+//        reads of tile t+1 (phase 0) come after at least one more barrier for both groups.
+template <int EPI, bool HAS_BIAS>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restrict__ A, int lda,
+                                                          const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
+                                                          int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
+    constexpr int SET = 65536, HALF = 16384, B_OFF = 32768;
+    __shared__ __attribute__((aligned(16))) char smem[2 * SET];
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wc = wave & 3;
+
+    // ---- LDS-DMA sources: for half h, this wave moves chunks (wave) and (wave+8): rows 128h + 8*chunk + (lane>>3) ----
+    const bf16_t* srcA[2][2];
+    const bf16_t* srcB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 128 * h + 8 * (wave + 8 * i) + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            srcA[h][i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+            srcB[h][i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
+        }
+    const int dma_off = wave * 1024;  // + i*8192 + half*HALF (+ B_OFF) + set*SET
+    auto dmaA = [&](int set, int h, int k0) {
+        char* d = smem + set * SET + h * HALF + dma_off;
+        glds16(srcA[h][0] + k0, d);
+        glds16(srcA[h][1] + k0, d + 8192);
+    };
+    auto dmaB = [&](int set, int h, int k0) {
+        char* d = smem + set * SET + B_OFF + h * HALF + dma_off;
+        glds16(srcB[h][0] + k0, d);
+        glds16(srcB[h][1] + k0, d + 8192);
+    };
+
+    // ---- fragment read offsets ----
+    const int fr = lane & 15, fq = lane >> 4;
+    const int sw = fr >> 1;
+    const int a_off = (128 * g + fr) * ROW_BYTES + ((fq ^ sw) << 4);
+    const int b_off = B_OFF + (64 * wc + fr) * ROW_BYTES + ((fq ^ sw) << 4);
+
+    f32x4 acc[2][2][4][2];  // [m block][n block][row tile][col tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fa[2][2][4];  // [m block][ks][row tile]
+    bf16x8 fb[2][2][2];  // [n block][ks][col tile]
+    auto readA = [&](const char* base, int mi) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[mi][ks][i] = *reinterpret_cast<const bf16x8*>(base + ((a_off ^ (ks << 6)) + (64 * mi + 16 * i) * ROW_BYTES));
+    };
+    auto readB = [&](const char* base, int ni) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fb[ni][ks][j] = *reinterpret_cast<const bf16x8*>(base + ((b_off ^ (ks << 6)) + (32 * ni + 16 * j) * ROW_BYTES));
+    };
+    auto mma = [&](int mi, int ni) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mi][ni][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni][ks][j], fa[mi][ks][i], acc[mi][ni][i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PP_BARRIER()                          \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+
+    const int nk = K / BK;
+    // ---- prologue: tile 0 complete, plus the first piece of tile 1 (the "phase 3 of tile -1" slot) ----
+    dmaA(0, 0, 0);
+    dmaA(0, 1, 0);
+    dmaB(0, 0, 0);
+    dmaB(0, 1, 0);
+    if (nk > 1) {
+        dmaA(1, 0, BK);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    PP_BARRIER();
+    if (g == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
+
+    for (int t = 0; t < nk; ++t) {
+        const int set = t & 1;
+        const char* base = smem + set * SET;
+        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+        const int k1 = (t + 1) * BK, k2 = (t + 2) * BK;
+        // ---- phase 0 ----
+        if (has1) dmaA(set ^ 1, 1, k1);
+        readA(base, 0);
+        readB(base, 0);
+        PP_BARRIER();
+        mma(0, 0);
+        PP_BARRIER();
+        // ---- phase 1 ----
+        if (has1) dmaB(set ^ 1, 0, k1);
+        readA(base, 1);
+        PP_BARRIER();
+        mma(1, 0);
+        PP_BARRIER();
+        // ---- phase 2 ----
+        if (has1) dmaB(set ^ 1, 1, k1);
+        readB(base, 1);
+        PP_BARRIER();
+        mma(1, 1);
+        PP_BARRIER();
+        // ---- phase 3 ----
+        if (has2) {
+            dmaA(set, 0, k2);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // everything of tile t+1 has landed; A-half0(t+2) may fly
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();
+        mma(0, 1);
+        PP_BARRIER();
+    }
+    if (g == 0) PP_BARRIER();  // balance group 1's extra barrier
+#undef PP_BARRIER
+
+    // ---- epilogue ----
+    f32x4 bias[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bias[ni][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (HAS_BIAS)
+                bias[ni][j] = *reinterpret_cast<const f32x4*>(e.bias + n0 + 64 * wc + 32 * ni + 16 * j + fq * 4);
+        }
+    if constexpr (HAS_BIAS) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[mi][ni][i][j] += bias[ni][j];
+    }
+    auto store_rows = [&](auto guard) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 128 * g + 64 * mi + 16 * i + fr;
+                if (!decltype(guard)::value || m < M) {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int n = n0 + 64 * wc + 32 * ni + 16 * j + fq * 4;
+                            epilogue_store<EPI>(acc[mi][ni][i][j], m, n, C, ldc, e);
+                        }
+                }
+            }
+    };
+    if (m0 + 256 <= M) store_rows(std::false_type{});
+    else store_rows(std::true_type{});
 }
 
 int g_tile_override = 0;
 
-template <int BM, int BN, int WM, int WN, int EPI>
-int launch_cfg(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
-               const EpiArgs& e, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int EPI, bool HB>
+void launch_cfg(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
+                const EpiArgs& e, hipStream_t s) {
     const int tiles_m = ceil_div(M, BM), tiles_n = N / BN;
-    const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K,
-                       tiles_n, e);
-    return 0;
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI, HB>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s, A,
+                       lda, B, ldb, C, ldc, M, N, K, tiles_n, e);
 }
 
-template <int EPI>
-int launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
+template <int EPI, bool HB>
+void launch_pp(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
                const EpiArgs& e, hipStream_t s) {
+    const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, HB>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, lda, B, ldb, C, ldc, M,
+                       N, K, tiles_n, e);
+}
+
+template <int EPI, bool HB>
+void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
+                const EpiArgs& e, hipStream_t s) {
     int tile = g_tile_override;
     if (tile == 0) {
         // 256x256 (8 waves, 1 block/CU) halves L2->LDS traffic per FLOP; fall back when N is not a multiple of
         // 256 or the grid would not fill the 256 CUs.
         const long t256 = (long)ceil_div(M, 256) * (N / 256);
-        if (N % 256 == 0 && t256 >= 512) tile = 3;
+        if (N % 256 == 0 && t256 >= 512) tile = 4;
         else if (M >= 2048) tile = 2;
         else tile = 1;
     }
-    if (tile == 3 && N % 256 != 0) tile = 2;
+    if ((tile == 3 || tile == 4) && N % 256 != 0) tile = 2;
     switch (tile) {
-        case 3: return launch_cfg<256, 256, 2, 4, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, s);
-        case 2: return launch_cfg<256, 128, 4, 2, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, s);
-        default: return launch_cfg<128, 128, 2, 2, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, s);
+        case 4: launch_pp<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
+        case 3: launch_cfg<256, 256, 2, 4, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
+        case 2: launch_cfg<256, 128, 4, 2, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
+        default: launch_cfg<128, 128, 2, 2, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
     }
+}
+
+template <int EPI>
+void launch_bias(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
+                 const EpiArgs& e, hipStream_t s) {
+    if (e.bias) launch_epi<EPI, true>(A, lda, B, ldb, C, ldc, M, N, K, e, s);
+    else launch_epi<EPI, false>(A, lda, B, ldb, C, ldc, M, N, K, e, s);
 }
 
 }  // namespace
 
 extern "C" int bsclip_gemm_set_tile(int tile) {
-    BSCLIP_REQUIRE(tile >= 0 && tile <= 3, "bsclip_gemm_set_tile: tile %d not in [0,3]", tile);
+    BSCLIP_REQUIRE(tile >= 0 && tile <= 4, "bsclip_gemm_set_tile: tile %d not in [0,4]", tile);
     g_tile_override = tile;
     return BSCLIP_OK;
 }
@@ -234,24 +479,25 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
         e.aux = static_cast<bf16_t*>(args->aux);
         e.ld_aux = args->ld_aux;
     }
+    BSCLIP_REQUIRE(!e.bias || (((uintptr_t)e.bias) & 15) == 0, "bsclip_gemm_bf16: bias must be 16-B aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t* a = static_cast<const bf16_t*>(A);
     const bf16_t* b = static_cast<const bf16_t*>(B);
     switch (epilogue) {
-        case BSCLIP_EPI_BF16: launch_epi<BSCLIP_EPI_BF16>(a, lda, b, ldb, C, ldc, M, N, K, e, s); break;
-        case BSCLIP_EPI_F32: launch_epi<BSCLIP_EPI_F32>(a, lda, b, ldb, C, ldc, M, N, K, e, s); break;
-        case BSCLIP_EPI_GELU_BF16: launch_epi<BSCLIP_EPI_GELU_BF16>(a, lda, b, ldb, C, ldc, M, N, K, e, s); break;
+        case BSCLIP_EPI_BF16: launch_bias<BSCLIP_EPI_BF16>(a, lda, b, ldb, C, ldc, M, N, K, e, s); break;
+        case BSCLIP_EPI_F32: launch_bias<BSCLIP_EPI_F32>(a, lda, b, ldb, C, ldc, M, N, K, e, s); break;
+        case BSCLIP_EPI_GELU_BF16: launch_bias<BSCLIP_EPI_GELU_BF16>(a, lda, b, ldb, C, ldc, M, N, K, e, s); break;
         case BSCLIP_EPI_RESID_F32:
             BSCLIP_REQUIRE(e.resid && e.ld_resid >= N, "bsclip_gemm_bf16: RESID needs resid/ld_resid");
-            launch_epi<BSCLIP_EPI_RESID_F32>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
+            launch_bias<BSCLIP_EPI_RESID_F32>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
             break;
         case BSCLIP_EPI_DGELU_BF16:
             BSCLIP_REQUIRE(e.aux && e.ld_aux >= N, "bsclip_gemm_bf16: DGELU needs aux/ld_aux");
-            launch_epi<BSCLIP_EPI_DGELU_BF16>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
+            launch_bias<BSCLIP_EPI_DGELU_BF16>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
             break;
         case BSCLIP_EPI_PATCH_F32:
             BSCLIP_REQUIRE(e.resid && e.ld_resid >= N && M % 196 == 0, "bsclip_gemm_bf16: PATCH needs pos, M%%196==0");
-            launch_epi<BSCLIP_EPI_PATCH_F32>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
+            launch_bias<BSCLIP_EPI_PATCH_F32>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
             break;
         default: BSCLIP_REQUIRE(false, "bsclip_gemm_bf16: unknown epilogue %d", epilogue);
     }

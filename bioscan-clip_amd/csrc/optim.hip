@@ -49,8 +49,8 @@ template <int H>
 __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t* __restrict__ dqkv, int ld,
                                                                     const bf16_t* __restrict__ haug, int ld_h, int M,
                                                                     const float* __restrict__ lora_b,
-                                                                    float* __restrict__ dt, float* __restrict__ dBq,
-                                                                    float* __restrict__ dBv) {
+                                                                    float* __restrict__ dt,
+                                                                    float* __restrict__ partial) {
     constexpr int NV = H / 256;
     __shared__ float red[2 * NV * 16 * 64];
     const int lane = threadIdx.x & 63;
@@ -98,31 +98,33 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t*
         const float tl = __shfl(tot, src, 64);
         if (lane < 8) dt[(size_t)row * 8 + lane] = tl;
     }
-    __syncthreads();
+    // cross-wave sum in wave order (no LDS atomics: the order of float adds is fixed)
+    const int wib = threadIdx.x >> 6;
+    for (int w = 0; w < LG_BLOCK / 64; ++w) {
+        __syncthreads();
+        if (wib == w) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
+            for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                atomicAdd(&red[((j * 16 + i * 4 + r) * 64) + lane], aq[j][i][r]);
-                atomicAdd(&red[((NV * 16 + j * 16 + i * 4 + r) * 64) + lane], av[j][i][r]);
-            }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 2 * NV * 16 * 64; idx += LG_BLOCK) {
-        const int l = idx & 63, k = idx >> 6;
-        const bool is_v = k >= NV * 16;
-        const int kk = is_v ? k - NV * 16 : k;
-        const int j = kk >> 4, i = (kk >> 2) & 3, r = kk & 3;
-        const int c = j * 256 + l * 4 + i;
-        atomicAdd((is_v ? dBv : dBq) + (size_t)c * 4 + r, red[idx]);
+                    for (int r = 0; r < 4; ++r) {
+                        red[((j * 16 + i * 4 + r) * 64) + lane] += aq[j][i][r];
+                        red[((NV * 16 + j * 16 + i * 4 + r) * 64) + lane] += av[j][i][r];
+                    }
+        }
     }
+    __syncthreads();
+    // per-workgroup partial slab (plain coalesced stores; summed in a fixed order by lora_grad_reduce_kernel)
+    for (int idx = threadIdx.x; idx < 2 * NV * 16 * 64; idx += LG_BLOCK)
+        partial[(size_t)blockIdx.x * (2 * NV * 16 * 64) + idx] = red[idx];
 }
 
 // pass 2: dA[8,H] += dt^T y
 template <int H>
 __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __restrict__ haug, int ld_h, int M,
-                                                                 const float* __restrict__ dt, float* __restrict__ dA) {
+                                                                 const float* __restrict__ dt,
+                                                                 float* __restrict__ partial) {
     constexpr int NV = H / 256;
     __shared__ float red[8 * NV * 4 * 64];
     const int lane = threadIdx.x & 63;
@@ -147,18 +149,50 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __
             }
         }
     }
+    const int wib = threadIdx.x >> 6;
+    for (int w = 0; w < LG_BLOCK / 64; ++w) {
+        __syncthreads();
+        if (wib == w) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) red[(((r * NV + j) * 4 + i) * 64) + lane] += acc[r][j][i];
+        }
+    }
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(&red[(((r * NV + j) * 4 + i) * 64) + lane], acc[r][j][i]);
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 8 * NV * 4 * 64; idx += LG_BLOCK) {
-        const int l = idx & 63, k = idx >> 6;
+    for (int idx = threadIdx.x; idx < 8 * NV * 4 * 64; idx += LG_BLOCK)
+        partial[(size_t)blockIdx.x * (8 * NV * 4 * 64) + idx] = red[idx];
+}
+
+// Sum the per-workgroup slabs in block order (bitwise reproducible) and accumulate into dBq/dBv/dA.
+// Slab A (8H floats): index k*64 + l, k = [is_v][j][i][r];  slab B (8H floats): index ((r*NV + j)*4 + i)*64 + l.
+template <int H>
+__global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __restrict__ pa,
+                                                                const float* __restrict__ pb, int nblocks,
+                                                                float* __restrict__ dA, float* __restrict__ dBq,
+                                                                float* __restrict__ dBv) {
+    constexpr int NV = H / 256;
+    constexpr int SLAB = 8 * H;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 2 * SLAB) return;
+    const bool second = idx >= SLAB;
+    const int e = second ? idx - SLAB : idx;
+    const float* src = (second ? pb : pa) + e;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += src[(size_t)b * SLAB];
+    const int l = e & 63, k = e >> 6;
+    if (!second) {
+        const bool is_v = k >= NV * 16;
+        const int kk = is_v ? k - NV * 16 : k;
+        const int j = kk >> 4, i = (kk >> 2) & 3, r = kk & 3;
+        const int c = j * 256 + l * 4 + i;
+        float* dst = (is_v ? dBv : dBq) + (size_t)c * 4 + r;
+        *dst += s;
+    } else {
         const int i = k & 3, j = (k >> 2) % NV, r = (k >> 2) / NV;
-        atomicAdd(dA + (size_t)r * H + j * 256 + l * 4 + i, red[idx]);
+        dA[(size_t)r * H + j * 256 + l * 4 + i] += s;
     }
 }
 
@@ -196,26 +230,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
+constexpr int LG_MAX_BLOCKS = 512;
+
+extern "C" int64_t bsclip_lora_grad_workspace_floats(int H) { return (int64_t)LG_MAX_BLOCKS * 16 * H; }
+
 extern "C" int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, int ld_h, int M, int H,
-                                const float* lora_b, float* dt, float* dA, float* dBq, float* dBv, void* stream) {
-    BSCLIP_REQUIRE(dqkv && h && lora_b && dt && dA && dBq && dBv && M > 0, "bsclip_lora_grad: null/empty input");
+                                const float* lora_b, float* dt, float* dA, float* dBq, float* dBv, float* workspace,
+                                void* stream) {
+    BSCLIP_REQUIRE(dqkv && h && lora_b && dt && dA && dBq && dBv && workspace && M > 0,
+                   "bsclip_lora_grad: null/empty input");
     BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_lora_grad: H=%d (supported: 768, 512)", H);
     BSCLIP_REQUIRE(ld_dqkv >= 3 * H && ld_dqkv % 4 == 0 && ld_h >= H + 8 && ld_h % 8 == 0,
                    "bsclip_lora_grad: ld_dqkv=%d ld_h=%d", ld_dqkv, ld_h);
     hipStream_t s = static_cast<hipStream_t>(stream);
     int blocks = ceil_div(M, 4 * 8);  // >= 8 rows per wave
-    if (blocks > 512) blocks = 512;
+    if (blocks > LG_MAX_BLOCKS) blocks = LG_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
     const bf16_t* g = static_cast<const bf16_t*>(dqkv);
     const bf16_t* hh = static_cast<const bf16_t*>(h);
+    float* pa = workspace;
+    float* pb = workspace + (size_t)LG_MAX_BLOCKS * 8 * H;
     if (H == 768) {
         hipLaunchKernelGGL((lora_grad_dt_db_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, g, ld_dqkv, hh, ld_h, M,
-                           lora_b, dt, dBq, dBv);
-        hipLaunchKernelGGL((lora_grad_da_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, dA);
+                           lora_b, dt, pa);
+        hipLaunchKernelGGL((lora_grad_da_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, pb);
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<768>), dim3(ceil_div(16 * 768, 256)), dim3(256), 0, s, pa, pb,
+                           blocks, dA, dBq, dBv);
     } else {
         hipLaunchKernelGGL((lora_grad_dt_db_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, g, ld_dqkv, hh, ld_h, M,
-                           lora_b, dt, dBq, dBv);
-        hipLaunchKernelGGL((lora_grad_da_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, dA);
+                           lora_b, dt, pa);
+        hipLaunchKernelGGL((lora_grad_da_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, pb);
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<512>), dim3(ceil_div(16 * 512, 256)), dim3(256), 0, s, pa, pb,
+                           blocks, dA, dBq, dBv);
     }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;

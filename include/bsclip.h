@@ -136,10 +136,13 @@ int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int64_t* label
  *     dA[8,H]  += dt^T h[:, :H]        (rows 0-3 = dA_q, 4-7 = dA_v)      (f32 accumulate)
  *     dBq[H,4] += dq^T t_q ; dBv[H,4] += dv^T t_v                         (f32 accumulate)
  *   lora_b f32 [2, H, 4] = (B_q, B_v).  Autograd of image_encoder.py:44-47 / dna_encoder.py:47-49.
+ *   workspace: f32, bsclip_lora_grad_workspace_floats(H) elements (per-workgroup partial slabs; the final sum runs in a
+ *   fixed order, so results are bitwise reproducible -- no float atomics).
  * colsum: db[N] += sum_m g[m, n] (bias gradients of the trainable heads), g bf16 or f32.
  * transpose_bf16: out[C,R] = in[R,C]^T (operands of the dW = dY^T X head GEMMs). */
+int64_t bsclip_lora_grad_workspace_floats(int H);
 int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, int ld_h, int M, int H, const float* lora_b,
-                     float* dt, float* dA, float* dBq, float* dBv, void* stream);
+                     float* dt, float* dA, float* dBq, float* dBv, float* workspace, void* stream);
 int bsclip_colsum(const void* g, int ld_g, int g_is_bf16, int M, int N, float* out, void* stream);
 int bsclip_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
 int bsclip_cast_f32_bf16(const float* in, int64_t n, void* out, void* stream);
