@@ -432,9 +432,10 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
     if (tile == 0) {
         // 256x256 (8 waves, 1 block/CU) halves L2->LDS traffic per FLOP; fall back when N is not a multiple of
         // 256 or the grid would not fill the 256 CUs.
+        // measured on MI355X (profiles/r01_b_gemm_tiles.log): the ping-pong 256x256 kernel wins on every encoder shape
+        // once the grid covers the chip; 128x128 (2 workgroups/CU) is the better small-grid choice.
         const long t256 = (long)ceil_div(M, 256) * (N / 256);
-        if (N % 256 == 0 && t256 >= 512) tile = 4;
-        else if (M >= 2048) tile = 2;
+        if (N % 256 == 0 && t256 >= 192) tile = 4;
         else tile = 1;
     }
     if ((tile == 3 || tile == 4) && N % 256 != 0) tile = 2;

@@ -166,8 +166,10 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __
         partial[(size_t)blockIdx.x * (8 * NV * 4 * 64) + idx] = red[idx];
 }
 
-// Sum the per-workgroup slabs in block order (bitwise reproducible) and accumulate into dBq/dBv/dA.
+// Sum the per-workgroup slabs in a fixed order (bitwise reproducible) and accumulate into dBq/dBv/dA.
 // Slab A (8H floats): index k*64 + l, k = [is_v][j][i][r];  slab B (8H floats): index ((r*NV + j)*4 + i)*64 + l.
+// Workgroup = 32 consecutive slab elements x 8 slab-groups; thread (i, p) sums slabs p, p+8, ... and the 8 partial
+// sums are combined in p order through LDS.
 template <int H>
 __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __restrict__ pa,
                                                                 const float* __restrict__ pb, int nblocks,
@@ -175,24 +177,29 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __re
                                                                 float* __restrict__ dBv) {
     constexpr int NV = H / 256;
     constexpr int SLAB = 8 * H;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 2 * SLAB) return;
+    __shared__ float red[8][32];
+    const int i = threadIdx.x & 31, p = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + i;  // < 2*SLAB by construction (grid = 2*SLAB/32)
     const bool second = idx >= SLAB;
     const int e = second ? idx - SLAB : idx;
     const float* src = (second ? pb : pa) + e;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += src[(size_t)b * SLAB];
+    for (int b = p; b < nblocks; b += 8) s += src[(size_t)b * SLAB];
+    red[p][i] = s;
+    __syncthreads();
+    if (p != 0) return;
+    s = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + ((red[4][i] + red[5][i]) + (red[6][i] + red[7][i]));
     const int l = e & 63, k = e >> 6;
     if (!second) {
         const bool is_v = k >= NV * 16;
         const int kk = is_v ? k - NV * 16 : k;
-        const int j = kk >> 4, i = (kk >> 2) & 3, r = kk & 3;
-        const int c = j * 256 + l * 4 + i;
+        const int j = kk >> 4, ii = (kk >> 2) & 3, r = kk & 3;
+        const int c = j * 256 + l * 4 + ii;
         float* dst = (is_v ? dBv : dBq) + (size_t)c * 4 + r;
         *dst += s;
     } else {
-        const int i = k & 3, j = (k >> 2) % NV, r = (k >> 2) / NV;
-        dA[(size_t)r * H + j * 256 + l * 4 + i] += s;
+        const int ii = k & 3, j = (k >> 2) % NV, r = (k >> 2) / NV;
+        dA[(size_t)r * H + j * 256 + l * 4 + ii] += s;
     }
 }
 
@@ -254,13 +261,13 @@ extern "C" int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, in
         hipLaunchKernelGGL((lora_grad_dt_db_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, g, ld_dqkv, hh, ld_h, M,
                            lora_b, dt, pa);
         hipLaunchKernelGGL((lora_grad_da_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, pb);
-        hipLaunchKernelGGL((lora_grad_reduce_kernel<768>), dim3(ceil_div(16 * 768, 256)), dim3(256), 0, s, pa, pb,
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<768>), dim3(16 * 768 / 32), dim3(256), 0, s, pa, pb,
                            blocks, dA, dBq, dBv);
     } else {
         hipLaunchKernelGGL((lora_grad_dt_db_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, g, ld_dqkv, hh, ld_h, M,
                            lora_b, dt, pa);
         hipLaunchKernelGGL((lora_grad_da_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, pb);
-        hipLaunchKernelGGL((lora_grad_reduce_kernel<512>), dim3(ceil_div(16 * 512, 256)), dim3(256), 0, s, pa, pb,
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<512>), dim3(16 * 512 / 32), dim3(256), 0, s, pa, pb,
                            blocks, dA, dBq, dBv);
     }
     BSCLIP_LAUNCH_CHECK();
