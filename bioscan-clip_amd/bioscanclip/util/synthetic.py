@@ -1,0 +1,35 @@
+"""Synthetic stand-in for the HDF5 data layer (reference ``bioscanclip/util/dataset.py``, out of scope: SURVEY 2.1 #4).
+
+Yields batches in the reference's 7-tuple layout (dataset.py:267-275): ``(processid, image [B,3,224,224] f32 in [0,1),
+dna_tokens [B,133] i64, input_ids, token_type_ids, attention_mask [B,20] i64 (or None), label [B] i64)``.
+"""
+import torch
+
+
+class SyntheticCLIPLoader:
+    def __init__(self, batch_size, steps, with_text=False, seed=1234, rank=0, world_size=1):
+        self.batch_size, self.steps, self.with_text = batch_size, steps, with_text
+        self.seed, self.rank, self.world = seed, rank, world_size
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        B = self.batch_size
+        for s in range(self.steps):
+            g = torch.Generator().manual_seed(self.seed + 1000 * s + self.rank)
+            image = torch.rand(B, 3, 224, 224, generator=g)
+            dna = torch.randint(3, 1027, (B, 133), generator=g)
+            dna[:, 0] = 0  # the literal <MASK>=0 prefix of get_sequence_pipeline (dna_encoder.py:33)
+            ids = tt = am = None
+            if self.with_text:
+                ids = torch.randint(1000, 30522, (B, 20), generator=g)
+                lens = torch.randint(6, 21, (B,), generator=g)
+                am = (torch.arange(20)[None] < lens[:, None]).long()
+                ids = ids * am
+                ids[:, 0] = 101
+                ids[torch.arange(B), lens - 1] = 102
+                tt = torch.zeros_like(ids)
+            label = torch.arange(B) + (s * self.world + self.rank) * B
+            pid = [f"SYN{self.rank}_{s}_{i}" for i in range(B)]
+            yield pid, image, dna, ids, tt, am, label

@@ -1,0 +1,128 @@
+"""Host-side logic that needs no GPU: drop-in surface (state_dict keys, constructor semantics, error behaviour),
+config loader, k-mer pipeline, flat-parameter plumbing."""
+import os
+
+import pytest
+import torch
+
+from helpers import load_golden
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bioscan-clip_amd")
+
+
+def _build_clip():
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from bioscanclip.model.language_encoder import LoRA_bert
+    from bioscanclip.model.simple_clip import SimpleCLIP
+    return SimpleCLIP(LoRA_ViT_timm(arch.vit_base_patch16_224(), r=4, num_classes=768),
+                      LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config()), r=4, num_classes=768),
+                      LoRA_bert(arch.BertModelParams(arch.bert_small_config()), r=4, num_classes=768))
+
+
+def test_state_dict_keys_and_trainable_set_match_reference():
+    """Keys/shapes captured from the imported reference (oracle/gen_golden.py:gen_state_dict_keys)."""
+    g = load_golden("state_dict_keys")
+    model = _build_clip()
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == g["keys"]
+    assert sorted(k for k, p in model.named_parameters() if p.requires_grad) == g["trainable"]
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == g["n_trainable"] == 1902848
+    assert sum(p.numel() for p in model.parameters()) == g["n_total"]
+
+
+def test_lora_init_and_lora_layer_semantics():
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=3), r=4, num_classes=768)
+    assert all((w.weight == 0).all() for w in m.w_Bs) and all(w.weight.abs().sum() > 0 for w in m.w_As)
+    assert len(m.w_As) == 6 and m.lora_layer == [0, 1, 2]
+    # reference quirk: ViT treats [] as "all layers", the BERT wrappers as "no layers"
+    assert LoRA_ViT_timm(arch.VisionTransformerParams(depth=2), r=4, lora_layer=[]).lora_layer == [0, 1]
+    d = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2)), r=4, lora_layer=[])
+    assert d.lora_layer == [] and len(d.w_As) == 0
+    with pytest.raises(AssertionError):
+        LoRA_ViT_timm(arch.VisionTransformerParams(depth=1), r=0)
+
+
+def test_no_cpu_compute_path():
+    """The product must fail loudly instead of computing on the CPU."""
+    from bioscanclip.model import arch
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from bioscanclip.model.loss_func import ContrastiveLoss
+    m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=1), r=4, num_classes=768)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(RuntimeError):
+        m.lora_vit(torch.zeros(1, 3, 224, 224))
+    crit = ContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)
+    with pytest.raises(ValueError, match="Too less element"):
+        crit(torch.zeros(4, 768), None, None, torch.arange(4))
+    with pytest.raises(RuntimeError, match="GPU"):
+        crit(torch.zeros(4, 768), torch.zeros(4, 768), None, torch.arange(4))
+
+
+def test_sequence_pipeline_matches_reference_semantics():
+    """dna_encoder.py:25-35 + util.py:48-69: 660 nt -> [0] + 132 5-mer ids, 'N' k-mers -> <UNK>=2."""
+    from bioscanclip.model.dna_encoder import get_sequence_pipeline, kmer_vocab
+    pipe = get_sequence_pipeline(5)
+    v = kmer_vocab(5)
+    assert len(v) == 1027 and v["AAAAA"] == 3 and v["AAAAC"] == 4 and v["TTTTT"] == 1026
+    ids = pipe("ACGTA" * 10)
+    assert len(ids) == 133 and ids[0] == 0
+    assert ids[1] == 3 + (0 * 256 + 1 * 64 + 2 * 16 + 3 * 4 + 0)
+    assert ids[11:] == [2] * 122           # padding with 'N' -> <UNK>
+    assert len(pipe("A" * 1000)) == 133    # truncation
+    assert pipe("ACGTN" + "A" * 655)[1] == 2
+
+
+def test_config_loader_hydra_like():
+    from bioscanclip.util.config import load_config
+    cfg = load_config(os.path.join(PKG, "bioscanclip", "config"),
+                      ["model_config=lora_vit_lora_barcode_bert_ssl", "model_config.batch_size=8",
+                       "model_config.lr_config.lr=0.0005", "model_config.lr_scheduler=cosine"])
+    mc = cfg.model_config
+    assert mc.batch_size == 8 and mc.image.input_type == "image" and mc.dna.model == "lora_barcode_bert"
+    assert not hasattr(mc, "language") and hasattr(mc, "lr_config") and mc.lr_config.lr == 0.0005
+    assert mc.output_dim == 768 and cfg.debug_flag is True
+    with pytest.raises(FileNotFoundError):
+        load_config(os.path.join(PKG, "bioscanclip", "config"), ["model_config=mlp_ssl"])
+
+
+def test_load_clip_model_config_keys():
+    from bioscanclip.model.simple_clip import load_clip_model
+    from bioscanclip.util.config import load_config
+    cfg = load_config(os.path.join(PKG, "bioscanclip", "config"), ["model_config=lora_vit_lora_barcode_bert_lora_bert_ssl"])
+    model = load_clip_model(cfg)
+    assert model.image_encoder is not None and model.dna_encoder is not None and model.language_encoder is not None
+    cfg.model_config.disable_lora = True
+    with pytest.raises(NotImplementedError):
+        load_clip_model(cfg)
+
+
+def test_flat_params_alias_parameters_and_grads():
+    from bioscanclip.hip.engine import FlatParams
+    a, b = torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7))
+    a0, b0 = a.detach().clone(), b.detach().clone()
+    flat = FlatParams([a, b], torch.device("cpu"))
+    assert torch.equal(a, a0) and torch.equal(b, b0) and flat.valid()
+    flat.data.mul_(2)
+    assert torch.equal(a, 2 * a0) and torch.equal(b, 2 * b0)
+    flat.grad.fill_(3.0)
+    assert (a.grad == 3).all() and (b.grad == 3).all()
+    a.grad = None
+    b.grad = None
+    flat.bind_grads()          # dropped grads -> buffer cleared, aliases restored
+    assert (flat.grad == 0).all() and a.grad.data_ptr() == flat.grad.data_ptr()
+    a.data = a.data.clone()
+    assert not flat.valid()
+
+
+def test_synthetic_loader_layout():
+    from bioscanclip.util.synthetic import SyntheticCLIPLoader
+    batch = next(iter(SyntheticCLIPLoader(4, 2, with_text=True)))
+    pid, image, dna, ids, tt, am, label = batch
+    assert image.shape == (4, 3, 224, 224) and 0 <= image.min() and image.max() < 1
+    assert dna.shape == (4, 133) and (dna[:, 0] == 0).all() and dna[:, 1:].min() >= 3 and dna.max() <= 1026
+    assert ids.shape == (4, 20) and (ids[:, 0] == 101).all() and am.sum(1).min() >= 6 and len(pid) == 4
