@@ -59,23 +59,30 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- exact-GELU pieces (erf via Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7) ---------------------------
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+// One exp and one rcp per element serve both gelu and gelu': with u = |x|/sqrt2, E = exp(-u^2) = exp(-x^2/2),
+//   erf(u) = 1 - poly(t) E,  t = 1/(1 + p u);   Phi(x) = 0.5 (1 + sign(x) erf(u));   phi(x) = E / sqrt(2 pi).
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
     float p = 1.061405429f;
-    p = p * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
-    const float y = 1.0f - p * t * __expf(-ax * ax);
-    return copysignf(y, x);
+    p = fmaf(p, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);  // exp(-x^2/2) = 2^(-x^2 / (2 ln 2))
+    const float half_tail = 0.5f * p * t * e;                   // 0.5 * erfc(u)
+    cdf = x >= 0.f ? 1.0f - half_tail : half_tail;
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_f(float x) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return x * cdf;
+}
 // d/dx gelu(x) = Phi(x) + x * phi(x)
 __device__ __forceinline__ float dgelu_f(float x) {
-    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return fmaf(x * 0.39894228040143268f, e, cdf);
 }
 
 // ---- async global -> LDS, 16 B per lane (LDS dest = wave-uniform base + lane*16) ---------------------

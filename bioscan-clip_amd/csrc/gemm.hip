@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                                                           const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                           int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
     constexpr int SET = 65536, HALF = 16384, B_OFF = 32768;
-    __shared__ __attribute__((aligned(16))) char smem[2 * SET];
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 1040 > 2 * SET ? 2 * 64 * 1040 : 2 * SET];  // main loop 128 KiB; epilogue slabs 130 KiB
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
@@ -386,25 +386,98 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[mi][ni][i][j] += bias[ni][j];
     }
-    auto store_rows = [&](auto guard) {
+    // ---- LDS-staged, row-coalesced stores --------------------------------------------------------------------
+    // In the accumulator layout a lane owns 4 consecutive columns of 16 different rows, so direct stores are 8-B
+    // (bf16) pieces of 32-B row segments: 64-128 store instructions per lane, store-ISSUE bound (the epilogue cost
+    // more than the 12-tile K loop of the K=768 GEMMs).  The main-loop LDS is free now: each group stages a 64-row
+    // slab of its output, then its 256 threads walk the slab row-wise with 16 B per lane, so every global access
+    // (C, residual, saved pre-activation) is a full 512-B / 1-KiB row segment.
+    constexpr int SB = 528;   // bf16 slab row stride (256*2 + 16)
+    constexpr int SF = 1040;  // f32 slab row stride (256*4 + 16)
+    char* slab = smem + g * (64 * SF);
+    const int wq = wave & 3;
+    __syncthreads();  // every wave is past its last fragment read
+    auto stage_bf16 = [&](int mi, auto&& f) {  // f(value) -> value to store
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + 128 * g + 64 * mi + 16 * i + fr;
-                if (!decltype(guard)::value || m < M) {
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 v = acc[mi][ni][i][j];
+                    uint2 o;
+                    o.x = pack_bf2(f(v[0]), f(v[1]));
+                    o.y = pack_bf2(f(v[2]), f(v[3]));
+                    *reinterpret_cast<uint2*>(slab + (16 * i + fr) * SB + (64 * wc + 32 * ni + 16 * j + 4 * fq) * 2) = o;
+                }
+    };
+    auto rows_bf16 = [&](int mi, bf16_t* dst, int ld) {
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int n = n0 + 64 * wc + 32 * ni + 16 * j + fq * 4;
-                            epilogue_store<EPI>(acc[mi][ni][i][j], m, n, C, ldc, e);
-                        }
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 8 + wq * 2 + (lane >> 5);
+            const int m = m0 + 128 * g + 64 * mi + r;
+            const uint4 v = *reinterpret_cast<const uint4*>(slab + r * SB + (lane & 31) * 16);
+            if (m < M) *reinterpret_cast<uint4*>(dst + (size_t)m * ld + n0 + (lane & 31) * 8) = v;
+        }
+    };
+    auto stage_f32 = [&](int mi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<f32x4*>(slab + (16 * i + fr) * SF + (64 * wc + 32 * ni + 16 * j + 4 * fq) * 4) =
+                        acc[mi][ni][i][j];
+    };
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        if constexpr (EPI == BSCLIP_EPI_BF16 || EPI == BSCLIP_EPI_GELU_BF16) {
+            if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
+                if (e.aux) {  // saved pre-activation
+                    stage_bf16(mi, [](float x) { return x; });
+                    __syncthreads();
+                    rows_bf16(mi, e.aux, e.ld_aux);
+                    __syncthreads();
+                }
+                stage_bf16(mi, [](float x) { return gelu_f(x); });
+            } else {
+                stage_bf16(mi, [](float x) { return x; });
+            }
+            __syncthreads();
+            rows_bf16(mi, static_cast<bf16_t*>(C), ldc);
+            __syncthreads();
+        } else {
+            stage_f32(mi);
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 4 + wq;                       // one 1-KiB row per wave instruction
+                const int m = m0 + 128 * g + 64 * mi + r;
+                const int n = n0 + lane * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(slab + r * SF + lane * 16);
+                if (m < M) {
+                    if constexpr (EPI == BSCLIP_EPI_F32) {
+                        *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
+                    } else if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
+                        v += *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
+                        *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
+                    } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
+                        const uint2 z = *reinterpret_cast<const uint2*>(e.aux + (size_t)m * e.ld_aux + n);
+                        uint2 o;
+                        o.x = pack_bf2(v[0] * dgelu_f(bf2f(z.x & 0xffff)), v[1] * dgelu_f(bf2f(z.x >> 16)));
+                        o.y = pack_bf2(v[2] * dgelu_f(bf2f(z.y & 0xffff)), v[3] * dgelu_f(bf2f(z.y >> 16)));
+                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = o;
+                    } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
+                        const int b = m / 196, p = m - b * 196;
+                        v += *reinterpret_cast<const f32x4*>(e.resid + (size_t)(1 + p) * e.ld_resid + n);
+                        *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = v;
+                    }
                 }
             }
-    };
-    if (m0 + 256 <= M) store_rows(std::false_type{});
-    else store_rows(std::true_type{});
+            __syncthreads();
+        }
+    }
 }
 
 int g_tile_override = 0;
