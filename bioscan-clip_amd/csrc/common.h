@@ -78,7 +78,13 @@ __device__ __forceinline__ float gelu_f(float x) {
     gelu_parts(x, cdf, e);
     return x * cdf;
 }
-// d/dx gelu(x) = Phi(x) + x * phi(x)
+// gelu(x) and d/dx gelu(x) = Phi(x) + x * phi(x) from one exp + one rcp
+__device__ __forceinline__ void gelu_both(float x, float& gl, float& dg) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    gl = x * cdf;
+    dg = fmaf(x * 0.39894228040143268f, e, cdf);
+}
 __device__ __forceinline__ float dgelu_f(float x) {
     float cdf, e;
     gelu_parts(x, cdf, e);

@@ -11,7 +11,8 @@
 //   * XCD-aware bijective blockIdx remap: the 8 XCDs each walk a contiguous range of tiles, N fastest, so the
 //     A row-panel and the (small) weight matrix are re-used out of that XCD's private L2;
 //   * epilogues fused in registers: bias, exact GELU (+ saved pre-activation), residual add in f32, GELU'
-//     scaling for the backward pass, and the ViT patch-embed row remap + position add.  Bias is loaded once per
+//     scaling for the backward pass (the forward saves gelu'(pre-activation), so the backward epilogue is one multiply),
+//     and the ViT patch-embed row remap + position add.  Bias is loaded once per
 //     thread before the stores and every epilogue is branch-free per element (a per-element "if (bias)" makes
 //     hipcc wait vmcnt(0) around each load: 32 serial L2 round trips per tile).
 //
@@ -56,15 +57,18 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, i
     } else if constexpr (EPI == BSCLIP_EPI_F32) {
         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
     } else if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
-        if (e.aux) {  // store only
+        float gl[4], dg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gelu_both(v[i], gl[i], dg[i]);
+        if (e.aux) {  // store only: gelu'(pre-activation), all the backward pass needs
             uint2 z;
-            z.x = pack_bf2(v[0], v[1]);
-            z.y = pack_bf2(v[2], v[3]);
+            z.x = pack_bf2(dg[0], dg[1]);
+            z.y = pack_bf2(dg[2], dg[3]);
             *reinterpret_cast<uint2*>(e.aux + (size_t)m * e.ld_aux + n) = z;
         }
         uint2 o;
-        o.x = pack_bf2(gelu_f(v[0]), gelu_f(v[1]));
-        o.y = pack_bf2(gelu_f(v[2]), gelu_f(v[3]));
+        o.x = pack_bf2(gl[0], gl[1]);
+        o.y = pack_bf2(gl[2], gl[3]);
         *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = o;
     } else if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
         const f32x4 r = *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
@@ -73,8 +77,8 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, i
     } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
         const uint2 z = *reinterpret_cast<const uint2*>(e.aux + (size_t)m * e.ld_aux + n);
         uint2 o;
-        o.x = pack_bf2(v[0] * dgelu_f(bf2f(z.x & 0xffff)), v[1] * dgelu_f(bf2f(z.x >> 16)));
-        o.y = pack_bf2(v[2] * dgelu_f(bf2f(z.y & 0xffff)), v[3] * dgelu_f(bf2f(z.y >> 16)));
+        o.x = pack_bf2(v[0] * bf2f(z.x & 0xffff), v[1] * bf2f(z.x >> 16));
+        o.y = pack_bf2(v[2] * bf2f(z.y & 0xffff), v[3] * bf2f(z.y >> 16));
         *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = o;
     } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
         const int b = m / 196, p = m - b * 196;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                                                           const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                           int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
     constexpr int SET = 65536, HALF = 16384, B_OFF = 32768;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 1040 > 2 * SET ? 2 * 64 * 1040 : 2 * SET];  // main loop 128 KiB; epilogue slabs 130 KiB
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 528];  // 132 KiB: main loop uses 128 KiB; epilogue slabs 2x64x1040 (f32) or 4x64x528 (bf16 x2)
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
@@ -397,7 +401,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     char* slab = smem + g * (64 * SF);
     const int wq = wave & 3;
     __syncthreads();  // every wave is past its last fragment read
-    auto stage_bf16 = [&](int mi, auto&& f) {  // f(value) -> value to store
+    char* slab2 = smem + 2 * 64 * SB + g * (64 * SB);  // second bf16 slab (GELU: gelu' side band)
+    auto stage_bf16 = [&](int mi) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -405,18 +410,31 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const f32x4 v = acc[mi][ni][i][j];
+                    const int off = (16 * i + fr) * SB + (64 * wc + 32 * ni + 16 * j + 4 * fq) * 2;
                     uint2 o;
-                    o.x = pack_bf2(f(v[0]), f(v[1]));
-                    o.y = pack_bf2(f(v[2]), f(v[3]));
-                    *reinterpret_cast<uint2*>(slab + (16 * i + fr) * SB + (64 * wc + 32 * ni + 16 * j + 4 * fq) * 2) = o;
+                    if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
+                        float gl[4], dg[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gelu_both(v[q], gl[q], dg[q]);
+                        o.x = pack_bf2(gl[0], gl[1]);
+                        o.y = pack_bf2(gl[2], gl[3]);
+                        uint2 d;
+                        d.x = pack_bf2(dg[0], dg[1]);
+                        d.y = pack_bf2(dg[2], dg[3]);
+                        *reinterpret_cast<uint2*>(slab2 + off) = d;
+                    } else {
+                        o.x = pack_bf2(v[0], v[1]);
+                        o.y = pack_bf2(v[2], v[3]);
+                    }
+                    *reinterpret_cast<uint2*>((g ? smem + 64 * SB : smem) + off) = o;
                 }
     };
-    auto rows_bf16 = [&](int mi, bf16_t* dst, int ld) {
+    auto rows_bf16 = [&](int mi, const char* src, bf16_t* dst, int ld) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int r = it * 8 + wq * 2 + (lane >> 5);
             const int m = m0 + 128 * g + 64 * mi + r;
-            const uint4 v = *reinterpret_cast<const uint4*>(slab + r * SB + (lane & 31) * 16);
+            const uint4 v = *reinterpret_cast<const uint4*>(src + r * SB + (lane & 31) * 16);
             if (m < M) *reinterpret_cast<uint4*>(dst + (size_t)m * ld + n0 + (lane & 31) * 8) = v;
         }
     };
@@ -433,19 +451,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         if constexpr (EPI == BSCLIP_EPI_BF16 || EPI == BSCLIP_EPI_GELU_BF16) {
-            if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
-                if (e.aux) {  // saved pre-activation
-                    stage_bf16(mi, [](float x) { return x; });
-                    __syncthreads();
-                    rows_bf16(mi, e.aux, e.ld_aux);
-                    __syncthreads();
-                }
-                stage_bf16(mi, [](float x) { return gelu_f(x); });
-            } else {
-                stage_bf16(mi, [](float x) { return x; });
-            }
+            stage_bf16(mi);
             __syncthreads();
-            rows_bf16(mi, static_cast<bf16_t*>(C), ldc);
+            rows_bf16(mi, smem + g * (64 * SB), static_cast<bf16_t*>(C), ldc);
+            if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
+                if (e.aux) rows_bf16(mi, slab2, e.aux, e.ld_aux);  // gelu'(pre-activation) for the backward pass
+            }
             __syncthreads();
         } else {
             stage_f32(mi);
@@ -465,8 +476,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                     } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
                         const uint2 z = *reinterpret_cast<const uint2*>(e.aux + (size_t)m * e.ld_aux + n);
                         uint2 o;
-                        o.x = pack_bf2(v[0] * dgelu_f(bf2f(z.x & 0xffff)), v[1] * dgelu_f(bf2f(z.x >> 16)));
-                        o.y = pack_bf2(v[2] * dgelu_f(bf2f(z.y & 0xffff)), v[3] * dgelu_f(bf2f(z.y >> 16)));
+                        o.x = pack_bf2(v[0] * bf2f(z.x & 0xffff), v[1] * bf2f(z.x >> 16));
+                        o.y = pack_bf2(v[2] * bf2f(z.y & 0xffff), v[3] * bf2f(z.y >> 16));
                         *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = o;
                     } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
                         const int b = m / 196, p = m - b * 196;

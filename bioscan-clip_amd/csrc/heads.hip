@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void meanpool_tokens_bwd_kernel(const float* _
     *reinterpret_cast<f32x4*>(dx + (size_t)row * H + c) = g;
 }
 
-// out = g * gelu'(z), 4 bf16 per thread
+// out = g * d (d = gelu'(pre-activation) saved by the forward GELU epilogue), 4 bf16 per thread
 __global__ __launch_bounds__(256) void dgelu_mul_kernel(const bf16_t* __restrict__ g, int ld_g,
                                                          const bf16_t* __restrict__ z, int ld_z, int M, int N,
                                                          bf16_t* __restrict__ out, int ld_o) {
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void dgelu_mul_kernel(const bf16_t* __restrict
         const uint2 gu = *reinterpret_cast<const uint2*>(g + row * ld_g + c);
         const uint2 zu = *reinterpret_cast<const uint2*>(z + row * ld_z + c);
         uint2 o;
-        o.x = pack_bf2(bf2f(gu.x & 0xffff) * dgelu_f(bf2f(zu.x & 0xffff)), bf2f(gu.x >> 16) * dgelu_f(bf2f(zu.x >> 16)));
-        o.y = pack_bf2(bf2f(gu.y & 0xffff) * dgelu_f(bf2f(zu.y & 0xffff)), bf2f(gu.y >> 16) * dgelu_f(bf2f(zu.y >> 16)));
+        o.x = pack_bf2(bf2f(gu.x & 0xffff) * bf2f(zu.x & 0xffff), bf2f(gu.x >> 16) * bf2f(zu.x >> 16));
+        o.y = pack_bf2(bf2f(gu.y & 0xffff) * bf2f(zu.y & 0xffff), bf2f(gu.y >> 16) * bf2f(zu.y >> 16));
         *reinterpret_cast<uint2*>(out + row * ld_o + c) = o;
     }
 }

@@ -42,9 +42,9 @@ int bsclip_abi_version(void);
 enum bsclip_epilogue {
     BSCLIP_EPI_BF16 = 0,       /* C bf16 = acc + bias                                               */
     BSCLIP_EPI_F32 = 1,        /* C f32  = acc + bias                                               */
-    BSCLIP_EPI_GELU_BF16 = 2,  /* C bf16 = gelu(acc + bias); aux (bf16, optional) = acc + bias      */
+    BSCLIP_EPI_GELU_BF16 = 2,  /* C bf16 = gelu(acc + bias); aux (bf16, optional) = gelu'(acc + bias) */
     BSCLIP_EPI_RESID_F32 = 3,  /* C f32  = acc + bias + resid                                       */
-    BSCLIP_EPI_DGELU_BF16 = 4, /* C bf16 = acc * gelu'(aux)   (aux bf16 = saved pre-activation)     */
+    BSCLIP_EPI_DGELU_BF16 = 4, /* C bf16 = acc * aux          (aux bf16 = gelu' saved by the forward) */
     BSCLIP_EPI_PATCH_F32 = 5   /* C f32 row (b*197+1+p) = acc + bias + pos[1+p], input row b*196+p  */
 };
 typedef struct bsclip_epi_args {
@@ -111,8 +111,8 @@ int bsclip_softmax_meanpool_bwd(const float* logits, const float* stats, const f
 int bsclip_meanpool_tokens_fwd(const float* x, int B, int S, int H, void* out_bf16, int ld_out, void* stream);
 /* autograd of the mean: dx[b,t,:] = d_pooled[b,:] / S  (f32 [B*S, H]) */
 int bsclip_meanpool_tokens_bwd(const float* d_pooled, int ld_d, int B, int S, int H, float* dx, void* stream);
-/* out = g * gelu'(z) elementwise (bf16 [M,N]): autograd of the GELU inside cls.predictions.transform, where the
- * producer of g is the LayerNorm backward rather than a GEMM. */
+/* out = g * z elementwise (bf16 [M,N]), z = gelu'(pre-activation) as saved by BSCLIP_EPI_GELU_BF16: autograd of the
+ * GELU inside cls.predictions.transform, where the producer of g is the LayerNorm backward rather than a GEMM. */
 int bsclip_dgelu_mul(const void* g, int ld_g, const void* z, int ld_z, int M, int N, void* out, int ld_o, void* stream);
 int bsclip_l2norm_fwd(const float* x, int M, int D, float* y, float* inv_norm, void* stream);
 int bsclip_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, int M, int D, float* dx, void* stream);
