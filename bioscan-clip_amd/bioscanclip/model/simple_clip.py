@@ -15,6 +15,17 @@ from bioscanclip.model.image_encoder import LoRA_ViT_timm
 from bioscanclip.model.language_encoder import LoRA_bert, load_pre_trained_bert
 
 
+_TOWER_STREAMS = __import__("os").environ.get("BSCLIP_TOWER_STREAMS", "1") != "0"
+_streams = {}
+
+
+def _tower_stream(k, device):
+    key = (k, device.index)
+    if key not in _streams:
+        _streams[key] = torch.cuda.Stream(device=device)
+    return _streams[key]
+
+
 class SimpleCLIP(nn.Module):
     def __init__(self, image_encoder, dna_encoder, language_encoder, open_clip_model=None):
         super(SimpleCLIP, self).__init__()
@@ -31,12 +42,33 @@ class SimpleCLIP(nn.Module):
         dna_output = None
         language_output = None
 
-        if self.dna_encoder is not None:
-            dna_output = l2_normalize(self.dna_encoder(dna_input))
-        if self.image_encoder is not None:
-            image_output = l2_normalize(self.image_encoder(image_input))
-        if self.language_encoder is not None:
-            language_output = l2_normalize(self.language_encoder(language_input))
+        # The towers are independent until the loss: each runs on its own HIP stream (forward here, backward through
+        # autograd, which replays a node on the stream of its forward), so one tower's memory-bound kernels and
+        # tail waves fill the other's idle CUs.  Disable with BSCLIP_TOWER_STREAMS=0.
+        towers = [(self.dna_encoder, dna_input), (self.image_encoder, image_input),
+                  (self.language_encoder, language_input)]
+        outs = [None, None, None]
+        use_streams = _TOWER_STREAMS and sum(enc is not None for enc, _ in towers) > 1 and torch.cuda.is_available()
+        cur = torch.cuda.current_stream() if use_streams else None
+        for k, (enc, x) in enumerate(towers):
+            if enc is None:
+                continue
+            if use_streams and not isinstance(enc, Freeze_DNA_Encoder):
+                side = _tower_stream(k, cur.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    y = l2_normalize(enc(x))
+                y.record_stream(cur)
+                outs[k] = (y, side)
+            else:
+                outs[k] = (l2_normalize(enc(x)), None)
+        for k in range(3):
+            if outs[k] is not None:
+                y, side = outs[k]
+                if side is not None:
+                    cur.wait_stream(side)
+                outs[k] = y
+        dna_output, image_output, language_output = outs
         return image_output, dna_output, language_output
 
 
