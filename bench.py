@@ -232,8 +232,11 @@ def main():
 
     fence()
     t0 = time.perf_counter()
+    c0 = time.process_time()
     for _ in range(a.steps):
         loss = step()
+    host_cpu_s = time.process_time() - c0   # CPU time spent enqueueing (all threads of this process)
+    t_enq = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -268,7 +271,8 @@ def main():
                               "algorithmic_tflop_per_gpu_step": round(step_tflop_per_gpu, 3)},
         }
         out["roofline"] = time_dominant_gemm(B, device)
-        print(f"[bench] gpu: {ms:.2f} ms/step, {out['value']} pairs/s; timing cpu baseline ...", file=sys.stderr, flush=True)
+        print(f"[bench] gpu: {ms:.2f} ms/step, {out['value']} pairs/s; host enqueue wall {t_enq / a.steps * 1e3:.2f} ms/step, "
+              f"host cpu {host_cpu_s / a.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
