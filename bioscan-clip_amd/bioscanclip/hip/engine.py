@@ -408,11 +408,22 @@ class BertEngine(EncoderEngineBase):
         self.ws = ws
         return ws
 
+    def _drop(self, ws, p, layer, site):
+        """(p, seed) of one dropout site for the current step, or None when dropout is off (eval mode / p = 0)."""
+        if not ws["train"] or p <= 0.0:
+            return None
+        return (p, (ws["drop_base"] + 0x9E3779B1 * (layer + 2) + 0x85EBCA6B * site) & 0xFFFFFFFF)
+
     def forward(self, input_ids, token_type_ids=None, attention_mask=None):
         B, S = input_ids.shape
         ws = self._workspace(B, S)
         H, M, L = self.H, ws["M"], len(self.layers)
         scale = 0.125
+        # HF BERT dropout (hidden 0.1 / attention-probs 0.1) is active in train mode (reference train_epoch.py:20);
+        # masks are functions of (seed, element index), regenerated in backward from the seeds kept here
+        self._fwd_calls = getattr(self, "_fwd_calls", 0) + 1
+        ws["train"] = bool(getattr(self, "training", False))
+        ws["drop_base"] = (torch.initial_seed() * 0x2545F491 + self._fwd_calls * 0x9E3779B9) & 0xFFFFFFFF
         self.refresh_lora_weights()
         ops.cast_f32_bf16(self.extra(0), self.w_head_bf)
         key_bias = None
@@ -423,15 +434,18 @@ class BertEngine(EncoderEngineBase):
         ops.bert_embed(input_ids.contiguous(), None if token_type_ids is None else token_type_ids.contiguous(),
                        self.word, self.posw, self.typew, ws["emb"])
         ops.layernorm_fwd(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, y_bf16=ws["yb"][0], y_f32=ws["y"],
-                          lora_a=self.lora_a(0))
+                          lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0))
         for l, lay in enumerate(self.layers):
             ops.gemm(ws["yb"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
-            ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], key_bias=key_bias)
-            ops.gemm(ws["ctx"][l], lay.w_o, ws["s1"][l], EPI_RESID_F32, bias=lay.b_o, resid=ws["y"])
+            ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], key_bias=key_bias,
+                         dropout=self._drop(ws, self.p_attn, l, 1))
+            ops.gemm(ws["ctx"][l], lay.w_o, ws["s1"][l], EPI_RESID_F32, bias=lay.b_o, resid=ws["y"],
+                     dropout=self._drop(ws, self.p_hidden, l, 2))
             ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ws["ymb"], y_f32=ws["ym"],
                               stats=ws["sta"][l])
             ops.gemm(ws["ymb"], lay.w_fc1, ws["act"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
-            ops.gemm(ws["act"], lay.w_fc2, ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"])
+            ops.gemm(ws["act"], lay.w_fc2, ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"],
+                     dropout=self._drop(ws, self.p_hidden, l, 3))
             nxt = self.lora_a(l + 1) if l + 1 < L else self._zero_a
             ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1], y_f32=ws["y"],
                               lora_a=nxt, stats=ws["stb"][l])
@@ -476,15 +490,17 @@ class BertEngine(EncoderEngineBase):
         dt_in, a_in = None, None
         for l in range(L - 1, -1, -1):
             lay = self.layers[l]
+            # dsb is the operand of fc2's dX GEMM: it carries the mask fc2's forward output was dropped with
             ops.layernorm_bwd(ws["s2"][l], ws["stb"][l], lay.ln_b[0], 1, g_resid=g_resid, g_gemm=g_gemm, dt=dt_in,
-                              lora_a=a_in, dx_f32=ws["ds"], dx_bf16=ws["dsb"])
+                              lora_a=a_in, dx_f32=ws["ds"], dx_bf16=ws["dsb"],
+                              dropout=self._drop(ws, self.p_hidden, l, 3))
             ops.gemm(ws["dsb"], lay.w_fc2_t, ws["dz"], EPI_DGELU_BF16, aux=ws["z"][l])
             ops.gemm(ws["dz"], lay.w_fc1_t, ws["dh"], EPI_BF16)
             ops.layernorm_bwd(ws["s1"][l], ws["sta"][l], lay.ln_a[0], 1, g_resid=ws["ds"], g_gemm=ws["dh"],
-                              dx_f32=ws["ds1"], dx_bf16=ws["dsb"])
+                              dx_f32=ws["ds1"], dx_bf16=ws["dsb"], dropout=self._drop(ws, self.p_hidden, l, 2))
             ops.gemm(ws["dsb"], lay.w_o_t, ws["dctx"], EPI_BF16)
             ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
-                         key_bias=ws["key_bias"])
+                         key_bias=ws["key_bias"], dropout=self._drop(ws, self.p_attn, l, 1))
             lb = self.lora_b(l)
             if lb is not None:
                 gbb = self.lora_b(l, grad=True)
@@ -525,6 +541,7 @@ def _engine_for(module, build):
 
 def run_encoder(module, build, fwd_args):
     eng = _engine_for(module, build)
+    eng.training = module.training
     if torch.is_grad_enabled() and any(p.requires_grad for p in eng.flat.params):
         return _EncoderFn.apply(eng, fwd_args, *eng.flat.params)
     return eng.forward(*fwd_args)

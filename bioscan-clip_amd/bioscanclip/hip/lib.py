@@ -5,7 +5,7 @@ The library is built in-tree by ``__graft_entry__.build()`` / ``make -C bioscan-
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint32, c_void_p
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libbsclip_hip.so")
@@ -16,10 +16,11 @@ LORA_COLS = 8
 
 
 class EpiArgs(Structure):
-    _fields_ = [("bias", c_void_p), ("resid", c_void_p), ("ld_resid", c_int), ("aux", c_void_p), ("ld_aux", c_int)]
+    _fields_ = [("bias", c_void_p), ("resid", c_void_p), ("ld_resid", c_int), ("aux", c_void_p), ("ld_aux", c_int),
+                ("dropout_p", c_float), ("dropout_seed", c_uint32)]
 
 
-P, I, F, L = c_void_p, c_int, c_float, c_int64
+P, I, F, L, U = c_void_p, c_int, c_float, c_int64, c_uint32
 
 # name -> (restype, argtypes); mirrors include/bsclip.h one to one (tests/test_abi.py checks both directions)
 SIGNATURES = {
@@ -27,10 +28,10 @@ SIGNATURES = {
     "bsclip_abi_version": (I, []),
     "bsclip_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P]),
     "bsclip_gemm_set_tile": (I, [I]),
-    "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, P]),
-    "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, P]),
-    "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, P]),
-    "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, P]),
+    "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
+    "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, P]),
+    "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, F, U, P]),
+    "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, F, U, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, P]),
     "bsclip_vit_cls_rows": (I, [P, P, P, I, I, I, P]),
     "bsclip_bert_embed": (I, [P, P, I, I, I, P, I, P, P, P, P]),

@@ -35,7 +35,7 @@ def _rowmajor(t, name):
     return t.stride(0)
 
 
-def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, K=None):
+def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, K=None, dropout=None):
     """out = epilogue(a[:M, :K] @ b[:, :K].T).  a [M, >=K] bf16, b [N, >=K] bf16 (row strides may exceed K)."""
     lda, ldb, ldc = _rowmajor(a, "a"), _rowmajor(b, "b"), _rowmajor(out, "out")
     _req(a.dtype == BF16 and b.dtype == BF16, "gemm operands must be bf16")
@@ -63,6 +63,9 @@ def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, 
         _req(aux.dtype == BF16 and aux.shape[0] >= M and aux.shape[1] >= N, "gemm: aux must be bf16 [M, N]")
         args.aux = aux.data_ptr()
         args.ld_aux = _rowmajor(aux, "aux")
+    if dropout is not None:  # (p, seed): C = dropout(acc + bias) + resid
+        _req(epilogue == EPI_RESID_F32, "gemm: dropout is only defined for EPI_RESID_F32")
+        args.dropout_p, args.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF
     check(_l.load().bsclip_gemm_bf16(_p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, epilogue, ctypes.byref(args),
                                      _stream()))
     return out
@@ -72,7 +75,7 @@ def set_gemm_tile(tile):
     check(_l.load().bsclip_gemm_set_tile(tile))
 
 
-def layernorm_fwd(x, gamma, beta, eps, y_bf16=None, y_f32=None, lora_a=None, stats=None, M=None):
+def layernorm_fwd(x, gamma, beta, eps, y_bf16=None, y_f32=None, lora_a=None, stats=None, M=None, dropout=None):
     ld_x = _rowmajor(x, "x")
     H = gamma.numel()
     M = x.shape[0] if M is None else M
@@ -90,12 +93,13 @@ def layernorm_fwd(x, gamma, beta, eps, y_bf16=None, y_f32=None, lora_a=None, sta
         _req(lora_a.dtype == F32 and lora_a.is_contiguous() and tuple(lora_a.shape) == (8, H), "lora_a must be f32 [8,H]")
     if stats is not None:
         _req(stats.dtype == F32 and stats.is_contiguous() and stats.numel() >= 2 * M, "stats must be f32 [M,2]")
+    dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_layernorm_fwd(_p(x), ld_x, int(x.dtype == BF16), M, H, _p(gamma), _p(beta), float(eps),
-                                         _p(y_bf16), ld_y, _p(y_f32), _p(lora_a), _p(stats), _stream()))
+                                         _p(y_bf16), ld_y, _p(y_f32), _p(lora_a), _p(stats), dp, ds, _stream()))
 
 
 def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lora_a=None, dx_f32=None, dx_bf16=None,
-                  M=None):
+                  M=None, dropout=None):
     ld_x = _rowmajor(x, "x")
     H = gamma.numel()
     M = x.shape[0] if M is None else M
@@ -120,21 +124,24 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
         _req(dx_bf16.dtype == BF16 and dx_bf16.shape[0] >= M and dx_bf16.shape[1] >= H, "dx_bf16 too small")
     check(_l.load().bsclip_layernorm_bwd(_p(x), ld_x, int(x.dtype == BF16), _p(stats), _p(gamma), M, H, _p(g_resid),
                                          ld_gr, _p(g_gemm), ld_g, _p(dt), _p(lora_a) if dt is not None else None,
-                                         int(mode), _p(dx_f32), ld_dx, _p(dx_bf16), ld_dxb, _stream()))
+                                         int(mode), _p(dx_f32), ld_dx, _p(dx_bf16), ld_dxb,
+                                         0.0 if dropout is None else float(dropout[0]),
+                                         0 if dropout is None else int(dropout[1]) & 0xFFFFFFFF, _stream()))
 
 
-def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None):
+def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None):
     ld_qkv, ld_ctx = _rowmajor(qkv, "qkv"), _rowmajor(ctx, "ctx")
     _req(qkv.dtype == BF16 and ctx.dtype == BF16 and lse.dtype == F32, "attn_fwd dtypes")
     _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64, "attn_fwd: qkv too small")
     _req(ctx.shape[0] >= B * S and ctx.shape[1] >= heads * 64 and lse.numel() >= B * heads * S, "attn_fwd: outputs too small")
     if key_bias is not None:
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
+    dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_attn_fwd(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), ld_ctx, _p(lse),
-                                    _stream()))
+                                    dp, ds, _stream()))
 
 
-def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None):
+def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None):
     ld_qkv, ld_ctx, ld_d = _rowmajor(qkv, "qkv"), _rowmajor(dctx, "dctx"), _rowmajor(dqkv, "dqkv")
     _req(all(t.dtype == BF16 for t in (qkv, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
     _req(min(qkv.shape[0], dctx.shape[0], dqkv.shape[0]) >= B * S, "attn_bwd: rows")
@@ -142,8 +149,9 @@ def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None):
          and lse.numel() >= B * heads * S, "attn_bwd: cols")
     if key_bias is not None:
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
+    dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_attn_bwd(_p(qkv), ld_qkv, _p(dctx), ld_ctx, _p(lse), B, S, heads, _p(key_bias),
-                                    float(scale), _p(dqkv), ld_d, _stream()))
+                                    float(scale), _p(dqkv), ld_d, dp, ds, _stream()))
 
 
 def im2col_patch16(image, cols):

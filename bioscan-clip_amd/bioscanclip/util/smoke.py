@@ -13,7 +13,7 @@ def run_smoke():
     from bioscanclip.model.simple_clip import SimpleCLIP
 
     img = LoRA_ViT_timm(arch.VisionTransformerParams(depth=2), r=4, num_classes=768)
-    dna = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2)), r=4, num_classes=768)
+    dna = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)), r=4, num_classes=768)
     model = SimpleCLIP(img, dna, None)
     sd = synth.synth_state_dict(synth.shapes_of(model), seed=3)
     model.load_state_dict(sd)

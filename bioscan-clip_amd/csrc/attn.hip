@@ -105,7 +105,7 @@ template <int NB>
 __global__ __launch_bounds__(NB * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S, int heads,
                                                             const float* __restrict__ key_bias, float scale,
                                                             bf16_t* __restrict__ ctx, int ld_ctx,
-                                                            float* __restrict__ lse) {
+                                                            float* __restrict__ lse, DropCfg drop) {
     constexpr int SP = NB * 32;
     __shared__ __attribute__((aligned(16))) char smem[SP * ROWB + 64 * tstride(SP) + SP * 4];
     char* sK = smem;
@@ -163,6 +163,13 @@ __global__ __launch_bounds__(NB * 64) void attn_fwd_kernel(const bf16_t* __restr
             sum += e;
         }
     sum += __shfl_xor(sum, 32, 64);
+    if (drop.thr16) {  // HF: dropout on the normalised probabilities (the row sum above is taken before it)
+        const unsigned base = ((unsigned)(b * heads + hd) * S + (unsigned)min(q0 + (lane & 31), S - 1)) * S;
+#pragma unroll
+        for (int kt = 0; kt < NB; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[kt][r] *= drop_factor(drop, base + 32 * kt + acc_row(r, h));
+    }
 
     // O^T[d, query] = sum_key V^T[d, key] P^T[key, query]
     f32x16 o[2] = {zero16(), zero16()};
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
                                                             const bf16_t* __restrict__ dctx, int ld_ctx,
                                                             const float* __restrict__ lse, int S, int heads,
                                                             const float* __restrict__ key_bias, float scale,
-                                                            bf16_t* __restrict__ dqkv, int ld_d) {
+                                                            bf16_t* __restrict__ dqkv, int ld_d, DropCfg drop) {
     constexpr int SP = NB * 32;
     constexpr int RM = SP * ROWB, TR = 64 * tstride(SP);
     __shared__ __attribute__((aligned(16))) char smem[2 * RM + 2 * TR + 3 * SP * 4];
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
         }
         __syncthreads();
         const float lse_q = sLse[q0 + (lane & 31)];
+        const unsigned dbase = ((unsigned)(b * heads + hd) * S + (unsigned)qrow) * S;  // dropout index of (q, key 0)
         // pass 1: delta_q = sum_key P[q,key] dP[q,key], from the SAME P and dP the gradient uses, so that
         // sum_key dS[q,key] = 0 holds to f32 rounding (delta from the bf16-rounded O does not: it loses the
         // cancellation whenever the values of a head are nearly equal across keys).
@@ -245,7 +253,11 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dpart += __expf(s[4 * g + i] * scale + b4[i] - lse_q) * dp[4 * g + i];
+                for (int i = 0; i < 4; ++i) {
+                    float dpm = dp[4 * g + i];
+                    if (drop.thr16) dpm *= drop_factor(drop, dbase + 32 * kt + 8 * g + 4 * h + i);
+                    dpart += __expf(s[4 * g + i] * scale + b4[i] - lse_q) * dpm;
+                }
             }
         }
         const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
@@ -266,7 +278,9 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float pr = __expf(s[4 * g + i] * scale + b4[i] - lse_q);
-                    dp[4 * g + i] = pr * (dp[4 * g + i] - delta_q) * scale;
+                    float dpm = dp[4 * g + i];
+                    if (drop.thr16) dpm *= drop_factor(drop, dbase + 32 * kt + 8 * g + 4 * h + i);
+                    dp[4 * g + i] = pr * (dpm - delta_q) * scale;
                 }
             }
 #pragma unroll
@@ -312,8 +326,13 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float pr = __expf(s[4 * g + i] * scale + bias_k - l4[i]);
-                    s[4 * g + i] = pr;                                        // P
-                    dp[4 * g + i] = pr * (dp[4 * g + i] - d4[i]) * scale;     // dS (scaled)
+                    float keep = 1.0f;
+                    if (drop.thr16) {
+                        const int q = min(32 * qt + 8 * g + 4 * h + i, S - 1);
+                        keep = drop_factor(drop, ((unsigned)(b * heads + hd) * S + (unsigned)q) * S + (unsigned)krow);
+                    }
+                    s[4 * g + i] = pr * keep;                                        // dropped P (feeds dV)
+                    dp[4 * g + i] = pr * (dp[4 * g + i] * keep - d4[i]) * scale;     // dS (scaled)
                 }
             }
 #pragma unroll
@@ -340,15 +359,18 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
     case NBV:                                                                                                   \
         hipLaunchKernelGGL((attn_fwd_kernel<NBV>), dim3(B * heads), dim3(NBV * 64), 0, s,                       \
                            static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,                  \
-                           static_cast<bf16_t*>(ctx), ld_ctx, lse);                                             \
+                           static_cast<bf16_t*>(ctx), ld_ctx, lse, drop);                                       \
         break;
 
 extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias,
-                               float scale, void* ctx, int ld_ctx, float* lse, void* stream) {
+                               float scale, void* ctx, int ld_ctx, float* lse, float dropout_p, uint32_t dropout_seed,
+                               void* stream) {
     BSCLIP_REQUIRE(qkv && ctx && lse, "bsclip_attn_fwd: null pointer");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_fwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_ctx >= heads * 64 && ld_ctx % 4 == 0,
                    "bsclip_attn_fwd: ld_qkv=%d ld_ctx=%d", ld_qkv, ld_ctx);
+    BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_fwd: dropout_p=%f", dropout_p);
+    const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch ((S + 31) / 32) {
         ATTN_FWD_CASE(1) ATTN_FWD_CASE(2) ATTN_FWD_CASE(3) ATTN_FWD_CASE(4) ATTN_FWD_CASE(5) ATTN_FWD_CASE(6)
@@ -362,17 +384,19 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
     case NBV:                                                                                                    \
         hipLaunchKernelGGL((attn_bwd_kernel<NBV>), dim3(B * heads), dim3(NBV * 64), 0, s,                        \
                            static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx,    \
-                           lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv);                 \
+                           lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop);           \
         break;
 
 extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
                                int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
-                               void* stream) {
+                               float dropout_p, uint32_t dropout_seed, void* stream) {
     BSCLIP_REQUIRE(qkv && dctx && lse && dqkv, "bsclip_attn_bwd: null pointer");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_bwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_dqkv >= 3 * heads * 64 && ld_dqkv % 4 == 0 &&
                        ld_ctx >= heads * 64 && ld_ctx % 8 == 0,
                    "bsclip_attn_bwd: ld_qkv=%d ld_dqkv=%d ld_ctx=%d", ld_qkv, ld_dqkv, ld_ctx);
+    BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_bwd: dropout_p=%f", dropout_p);
+    const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch ((S + 31) / 32) {
         ATTN_BWD_CASE(1) ATTN_BWD_CASE(2) ATTN_BWD_CASE(3) ATTN_BWD_CASE(4) ATTN_BWD_CASE(5) ATTN_BWD_CASE(6)

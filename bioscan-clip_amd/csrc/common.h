@@ -46,6 +46,49 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
+// ---- dropout: counter-based, layout-independent ----------------------------------------------------
+// The decision for logical element `idx` of a site depends only on (seed, idx): every kernel that touches the
+// element (forward epilogue, the backward pass that regenerates the mask, either attention orientation) gets the
+// same answer without storing masks.  One 32-bit hash serves the element pair (idx & ~1, idx | 1): 16 bits each,
+// keep <=> bits >= thr16 with thr16 = round(p * 65536).  HF BERT: hidden_dropout_prob /
+// attention_probs_dropout_prob = 0.1, active under model.train().
+struct DropCfg {
+    unsigned thr16;  // 0 = dropout off
+    unsigned seed;
+    float scale;     // 1 / (1 - p)
+};
+__device__ __forceinline__ unsigned hash32(unsigned x) {  // "lowbias32" integer mixer
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned drop_pair_bits(const DropCfg& d, unsigned idx) {
+    return hash32((idx >> 1) * 0x9E3779B9U + d.seed);
+}
+__device__ __forceinline__ float drop_factor(const DropCfg& d, unsigned idx) {  // 1/(1-p) if kept, 0 if dropped
+    const unsigned bits = (drop_pair_bits(d, idx) >> ((idx & 1) * 16)) & 0xffffU;
+    return bits >= d.thr16 ? d.scale : 0.f;
+}
+// four consecutive elements starting at idx (idx % 4 == 0)
+__device__ __forceinline__ f32x4 drop4(const DropCfg& d, unsigned idx, f32x4 v) {
+    const unsigned b0 = drop_pair_bits(d, idx), b1 = drop_pair_bits(d, idx + 2);
+    v[0] = (b0 & 0xffffU) >= d.thr16 ? v[0] * d.scale : 0.f;
+    v[1] = (b0 >> 16) >= d.thr16 ? v[1] * d.scale : 0.f;
+    v[2] = (b1 & 0xffffU) >= d.thr16 ? v[2] * d.scale : 0.f;
+    v[3] = (b1 >> 16) >= d.thr16 ? v[3] * d.scale : 0.f;
+    return v;
+}
+static inline DropCfg make_drop(float p, unsigned seed) {
+    DropCfg d;
+    d.thr16 = p > 0.f ? (unsigned)(p * 65536.0f + 0.5f) : 0u;
+    d.seed = seed;
+    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return d;
+}
+
 // ---- wave (64-lane) reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -44,6 +44,8 @@ struct EpiArgs {
     int ld_resid;
     bf16_t* aux;
     int ld_aux;
+    DropCfg drop;  // RESID only: C = dropout(acc + bias) + resid  (HF BertSelfOutput / BertOutput)
+    int n_total;   // logical row width for the dropout element index
 };
 
 // v already holds acc (+ bias).  No data-dependent branch guards a load.
@@ -72,6 +74,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, i
         *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = o;
     } else if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
         const f32x4 r = *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
+        if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
         v += r;
         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
     } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
@@ -471,6 +474,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                     if constexpr (EPI == BSCLIP_EPI_F32) {
                         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
                     } else if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
+                        if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
                         v += *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
                         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
                     } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
@@ -563,7 +567,12 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
         e.ld_resid = args->ld_resid;
         e.aux = static_cast<bf16_t*>(args->aux);
         e.ld_aux = args->ld_aux;
+        BSCLIP_REQUIRE(args->dropout_p >= 0.f && args->dropout_p < 1.f, "bsclip_gemm_bf16: dropout_p=%f", args->dropout_p);
+        BSCLIP_REQUIRE(args->dropout_p == 0.f || epilogue == BSCLIP_EPI_RESID_F32,
+                       "bsclip_gemm_bf16: dropout is only defined for BSCLIP_EPI_RESID_F32");
+        e.drop = make_drop(args->dropout_p, args->dropout_seed);
     }
+    e.n_total = N;
     BSCLIP_REQUIRE(!e.bias || (((uintptr_t)e.bias) & 15) == 0, "bsclip_gemm_bf16: bias must be 16-B aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t* a = static_cast<const bf16_t*>(A);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
                                                                   bf16_t* __restrict__ y_bf16, int ld_y,
                                                                   float* __restrict__ y_f32,
                                                                   const float* __restrict__ lora_a,
-                                                                  float* __restrict__ stats) {
+                                                                  float* __restrict__ stats, DropCfg drop) {
     constexpr int NV = H / 256;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;
@@ -105,6 +105,10 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
         const float rstd = rsqrtf(var + eps);
 #pragma unroll
         for (int j = 0; j < NV; ++j) v[j] = v[j] * rstd * g[j] + b[j];
+        if (drop.thr16) {  // HF BertEmbeddings: dropout(LayerNorm(.)); everything downstream sees the dropped values
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = drop4(drop, (unsigned)row * H + j * 256 + lane * 4, v[j]);
+        }
 
         if (stats && lane == 0) {
             stats[2 * (size_t)row] = mean;
@@ -154,7 +158,8 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
                                                                   const float* __restrict__ dt,
                                                                   const float* __restrict__ lora_a, int mode,
                                                                   float* __restrict__ dx_f32, int ld_dx,
-                                                                  bf16_t* __restrict__ dx_bf16, int ld_dxb) {
+                                                                  bf16_t* __restrict__ dx_bf16, int ld_dxb,
+                                                                  DropCfg drop) {
     constexpr int NV = H / 256;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;
@@ -223,6 +228,8 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
             if (mode == 0) d += res[j];
             if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + (size_t)row * ld_dx + j * 256 + lane * 4) = d;
             if (dx_bf16) {
+                // gradient w.r.t. the output of the Linear whose forward result was dropped with this (p, seed)
+                if (drop.thr16) d = drop4(drop, (unsigned)row * H + j * 256 + lane * 4, d);
                 uint2 o;
                 o.x = pack_bf2(d[0], d[1]);
                 o.y = pack_bf2(d[2], d[3]);
@@ -287,17 +294,20 @@ int ln_grid(int M) {
 
 #define LN_FWD_LAUNCH(HH, XB, LO)                                                                              \
     hipLaunchKernelGGL((layernorm_fwd_kernel<HH, XB, LO>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, M, \
-                       gamma, beta, eps, static_cast<bf16_t*>(y_bf16), ld_y, y_f32, lora_a, stats)
+                       gamma, beta, eps, static_cast<bf16_t*>(y_bf16), ld_y, y_f32, lora_a, stats, drop)
 
 extern "C" int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma,
                                     const float* beta, float eps, void* y_bf16, int ld_y, float* y_f32,
-                                    const float* lora_a, float* stats, void* stream) {
+                                    const float* lora_a, float* stats, float dropout_p, uint32_t dropout_seed,
+                                    void* stream) {
     BSCLIP_REQUIRE(x && gamma && beta && M > 0, "bsclip_layernorm_fwd: null/empty input");
     BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_fwd: H=%d (supported: 768, 512)", H);
     BSCLIP_REQUIRE(ld_x >= H && ld_x % 4 == 0, "bsclip_layernorm_fwd: ld_x=%d", ld_x);
     BSCLIP_REQUIRE(!y_bf16 || (ld_y % 4 == 0 && ld_y >= H + (lora_a ? BSCLIP_KPAD : 0)),
                    "bsclip_layernorm_fwd: ld_y=%d too small for H=%d%s", ld_y, H, lora_a ? "+KPAD" : "");
     BSCLIP_REQUIRE(!lora_a || y_bf16, "bsclip_layernorm_fwd: lora_a needs y_bf16");
+    BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_layernorm_fwd: dropout_p=%f", dropout_p);
+    const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool lo = lora_a != nullptr;
     if (H == 768) {
@@ -314,12 +324,12 @@ extern "C" int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, 
 #define LN_BWD_LAUNCH(HH, XB, LO)                                                                                \
     hipLaunchKernelGGL((layernorm_bwd_kernel<HH, XB, LO>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, stats, \
                        gamma, M, g_resid, ld_gr, static_cast<const bf16_t*>(g_gemm), ld_g, dt, lora_a, mode, dx_f32, \
-                       ld_dx, static_cast<bf16_t*>(dx_bf16), ld_dxb)
+                       ld_dx, static_cast<bf16_t*>(dx_bf16), ld_dxb, drop)
 
 extern "C" int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M,
                                     int H, const float* g_resid, int ld_gr, const void* g_gemm, int ld_g,
                                     const float* dt, const float* lora_a, int mode, float* dx_f32, int ld_dx,
-                                    void* dx_bf16, int ld_dxb, void* stream) {
+                                    void* dx_bf16, int ld_dxb, float dropout_p, uint32_t dropout_seed, void* stream) {
     BSCLIP_REQUIRE(x && stats && gamma && M > 0, "bsclip_layernorm_bwd: null/empty input");
     BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_bwd: H=%d (supported: 768, 512)", H);
     BSCLIP_REQUIRE(g_resid || g_gemm, "bsclip_layernorm_bwd: no incoming gradient");
@@ -329,6 +339,8 @@ extern "C" int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const f
     BSCLIP_REQUIRE(!g_resid || (ld_gr >= H && ld_gr % 4 == 0), "bsclip_layernorm_bwd: ld_gr=%d", ld_gr);
     BSCLIP_REQUIRE(!dx_f32 || (ld_dx >= H && ld_dx % 4 == 0), "bsclip_layernorm_bwd: ld_dx=%d", ld_dx);
     BSCLIP_REQUIRE(!dx_bf16 || (ld_dxb >= H && ld_dxb % 4 == 0), "bsclip_layernorm_bwd: ld_dxb=%d", ld_dxb);
+    BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_layernorm_bwd: dropout_p=%f", dropout_p);
+    const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool lo = lora_a != nullptr;
     if (H == 768) {

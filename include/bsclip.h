@@ -53,6 +53,8 @@ typedef struct bsclip_epi_args {
     int ld_resid;
     void* aux; /* GELU: bf16 out (nullable); DGELU: bf16 in */
     int ld_aux;
+    float dropout_p;        /* RESID only: C = dropout(acc + bias) + resid (HF hidden_dropout_prob); 0 = off */
+    uint32_t dropout_seed;  /* decision of element (m,n) = f(seed, m*N + n): see bsclip_layernorm_bwd */
 } bsclip_epi_args;
 int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      int epilogue, const bsclip_epi_args* args, void* stream);
@@ -69,26 +71,31 @@ int bsclip_gemm_set_tile(int tile);
  * bwd (gamma/beta frozen -> only dx): dy = g_resid(f32, nullable) + g_gemm(bf16, nullable) + dt[M,8] . lora_a
  *   mode 0 (pre-LN, ViT):  dx = g_resid + LNbwd(g_gemm + dt.lora_a)
  *   mode 1 (post-LN, BERT): dx = LNbwd(g_resid + g_gemm + dt.lora_a)
+ *   Dropout (HF BERT, K15): fwd applies it to y (both copies; the embeddings LayerNorm); bwd applies it to dx_bf16 only --
+ *   dx_bf16 is the operand of the dX GEMM of a Linear whose FORWARD output was dropped with the same (p, seed), and the
+ *   mask of element (row, col) is a pure function of (seed, row*H + col), so it is regenerated, never stored.
  *   writes dx_f32 [M, ld_dx] (nullable) and dx_bf16 [M, ld_dxb] (nullable).  Row strides let the final ViT norm run on
  *   the token-0 rows only (x, g and dx all strided by 197*H).  stats is indexed by the compact row number. */
 int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma, const float* beta,
                          float eps, void* y_bf16, int ld_y, float* y_f32, const float* lora_a, float* stats,
-                         void* stream);
+                         float dropout_p, uint32_t dropout_seed, void* stream);
 int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M, int H,
                          const float* g_resid, int ld_gr, const void* g_gemm, int ld_g, const float* dt,
                          const float* lora_a, int mode, float* dx_f32, int ld_dx, void* dx_bf16, int ld_dxb,
-                         void* stream);
+                         float dropout_p, uint32_t dropout_seed, void* stream);
 
 /* ---- self-attention (timm Attention.forward; HF BertSelfAttention) ---------------------------------------------
  * qkv bf16 [B*S, ld_qkv] with columns [q | k | v], each heads*64 wide; ctx bf16 [B*S, ld_ctx];
  * key_bias f32 [B,S] additive per key (HF extended attention mask, language_encoder.py:89) or NULL;
  * lse f32 [B, heads, S] = log-sum-exp of the scaled scores (saved for backward).  head_dim is 64.
+ * dropout_p > 0: HF attention_probs_dropout_prob on the normalised probabilities (mask of (b,head,q,k) regenerated in bwd).
  * S <= 224.  bwd recomputes P from qkv + lse, forms delta = rowsum(P . dP) in f32 from the same tiles (not from the
  * bf16-rounded ctx: that loses the softmax-backward cancellation), and writes dqkv in the same layout as qkv. */
 int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale,
-                    void* ctx, int ld_ctx, float* lse, void* stream);
+                    void* ctx, int ld_ctx, float* lse, float dropout_p, uint32_t dropout_seed, void* stream);
 int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
-                    int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, void* stream);
+                    int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, float dropout_p,
+                    uint32_t dropout_seed, void* stream);
 
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column

@@ -1,0 +1,162 @@
+"""Dropout (HF BERT hidden 0.1 / attention-probs 0.1, active in train mode).  Bit-parity with torch's
+Philox stream is impossible by construction, so correctness is established structurally:
+  * every site keeps ~ (1-p) of its elements and scales survivors by 1/(1-p) (statistics);
+  * the mask is a pure function of (seed, element index): the backward kernels regenerate exactly the mask the forward
+    used (pattern equality / comparison with torch autograd run on the mask extracted from the forward)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import rel_err  # noqa: E402
+
+P = 0.1
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bioscanclip.hip import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).cuda()
+
+
+def test_gemm_resid_dropout_and_layernorm_bwd_share_the_mask(ops):
+    from bioscanclip.hip.lib import EPI_RESID_F32
+    M, N, K = 3000, 768, 768
+    a, w = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16()
+    bias, resid = rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = a.float() @ w.float().t() + bias
+    outs = {}
+    for tile in (1, 4):
+        ops.set_gemm_tile(tile)
+        out = torch.empty(M, N, device="cuda")
+        ops.gemm(a, w, out, EPI_RESID_F32, bias=bias, resid=resid, dropout=(P, 1234))
+        outs[tile] = out - resid
+    ops.set_gemm_tile(0)
+    assert torch.equal(outs[1] == 0, outs[4] == 0), "mask must not depend on the kernel/tile layout"
+    d = outs[4]
+    kept = d != 0
+    assert abs(kept.float().mean().item() - (1 - P)) < 5e-3
+    assert rel_err(d[kept], (ref / (1 - P))[kept]) < 1e-5
+    out2 = torch.empty(M, N, device="cuda")
+    ops.gemm(a, w, out2, EPI_RESID_F32, bias=bias, resid=resid, dropout=(P, 1234))
+    assert torch.equal(out2 - resid, d), "same seed -> same mask"
+    ops.gemm(a, w, out2, EPI_RESID_F32, bias=bias, resid=resid, dropout=(P, 99))
+    assert ((out2 - resid == 0) != (d == 0)).float().mean() > 0.1, "different seed -> different mask"
+    # backward: dx_bf16 of the LayerNorm that consumes this GEMM's output carries the same mask; dx_f32 does not
+    x = rnd(M, N, seed=5)
+    g, b = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+    stats = torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x, g, b, 1e-12, y_f32=torch.empty(M, N, device="cuda"), stats=stats)
+    gres = rnd(M, N, seed=6)
+    dx32, dx16 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm_bwd(x, stats, g, 1, g_resid=gres, dx_f32=dx32, dx_bf16=dx16, dropout=(P, 1234))
+    assert torch.equal(dx16 == 0, ~kept)
+    assert (dx32 != 0).all()
+    assert rel_err(dx16.float()[kept], (dx32 / (1 - P))[kept]) < 4e-3
+
+
+def test_layernorm_fwd_dropout(ops):
+    M, H = 2000, 768
+    x = rnd(M, H, seed=1)
+    g, b = 1 + 0.1 * rnd(H, seed=2), 0.1 * rnd(H, seed=3) + 0.5
+    A = rnd(8, H, seed=4, scale=0.05)
+    y16 = torch.empty(M, H + 64, device="cuda", dtype=torch.bfloat16)
+    y32 = torch.empty(M, H, device="cuda")
+    ops.layernorm_fwd(x, g, b, 1e-12, y_bf16=y16, y_f32=y32, lora_a=A, dropout=(P, 7))
+    ref = torch.nn.functional.layer_norm(x, (H,), g, b, 1e-12)
+    kept = y32 != 0
+    assert abs(kept.float().mean().item() - (1 - P)) < 5e-3
+    assert rel_err(y32[kept], (ref / (1 - P))[kept]) < 1e-5
+    assert torch.equal(y16[:, :H] == 0, ~kept)
+    assert rel_err(y16[:, H:H + 8].float(), y32 @ A.t()) < 4e-3, "LoRA projection must see the dropped activations"
+
+
+@pytest.mark.parametrize("B,S,heads,masked", [(2, 64, 2, False), (3, 20, 8, True), (2, 197, 3, False)])
+def test_attention_dropout_fwd_bwd(ops, B, S, heads, masked):
+    H = heads * 64
+    scale = 0.125
+    qkv = rnd(B * S, 3 * H, seed=1).bfloat16()
+    bias = None
+    if masked:
+        lens = torch.randint(2, S + 1, (B,), generator=torch.Generator().manual_seed(3))
+        bias = ((1.0 - (torch.arange(S)[None] < lens[:, None]).float()) * torch.finfo(torch.float32).min).cuda()
+    seed = 4242
+    # 1) extract the mask: with V = [I; 0] blocks the context rows spell out the dropped probabilities
+    n_chunk = (S + 63) // 64
+    mask = torch.zeros(B, heads, S, S, device="cuda")
+    ptil = torch.zeros(B, heads, S, S, device="cuda")
+    lse = torch.empty(B, heads, S, device="cuda")
+    for c in range(n_chunk):
+        probe = qkv.clone().float().reshape(B, S, 3, heads, 64)
+        v = torch.zeros(B, S, heads, 64, device="cuda")
+        ks = torch.arange(c * 64, min(S, c * 64 + 64), device="cuda")
+        v[:, ks, :, ks - c * 64] = 1.0
+        probe[:, :, 2] = v
+        ctx = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
+        ops.attn_fwd(probe.reshape(B * S, 3 * H).bfloat16(), B, S, heads, scale, ctx, lse, key_bias=bias, dropout=(P, seed))
+        got = ctx.float().reshape(B, S, heads, 64).permute(0, 2, 1, 3)  # [B, heads, q, key-in-chunk]
+        ptil[:, :, :, ks] = got[..., : len(ks)]
+    q, k, v = [t.reshape(B, S, heads, 64).transpose(1, 2) for t in qkv.float().split(H, dim=-1)]
+    s = (q @ k.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    p = torch.softmax(s, -1)
+    visible = p > 1e-3                      # bf16 output cannot resolve tiny probabilities
+    mask = (ptil != 0)
+    frac = mask[visible].float().mean().item()
+    assert abs(frac - (1 - P)) < 0.02, frac
+    assert rel_err(ptil[visible & mask], (p / (1 - P))[visible & mask]) < 6e-3
+    # 2) forward + backward with the real V against torch autograd driven by the extracted mask
+    keepf = torch.where(visible, mask.float(), torch.ones_like(p)) / (1 - P)   # invisible entries: contribution ~0
+    qf = qkv.float().reshape(B, S, 3 * H).requires_grad_(True)
+    q2, k2, v2 = [t.reshape(B, S, heads, 64).transpose(1, 2) for t in qf.split(H, dim=-1)]
+    s2 = (q2 @ k2.transpose(-1, -2)) * scale
+    if bias is not None:
+        s2 = s2 + bias[:, None, None, :]
+    ref = ((torch.softmax(s2, -1) * keepf) @ v2).transpose(1, 2).reshape(B * S, H)
+    ctx = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
+    ops.attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=bias, dropout=(P, seed))
+    assert rel_err(ctx.float(), ref) < 2e-2
+    dctx = rnd(B * S, H, seed=2).bfloat16()
+    (gq,) = torch.autograd.grad(ref, qf, dctx.float())
+    dqkv = torch.empty(B * S, 3 * H, device="cuda", dtype=torch.bfloat16)
+    ops.attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=bias, dropout=(P, seed))
+    gq = gq.reshape(B * S, 3 * H)
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert rel_err(dqkv[:, sl].float(), gq[:, sl]) < 3e-2, name
+
+
+def test_engine_train_vs_eval_mode():
+    """train mode: stochastic (a new mask per forward) with an unbiased mean; eval mode: deterministic and identical
+    to the p = 0 configuration."""
+    from oracle import synth
+    from bioscanclip.model import arch
+    from bioscanclip.model.language_encoder import LoRA_bert
+    def build(**kw):
+        m = LoRA_bert(arch.BertModelParams(arch.bert_small_config(**kw)), r=4, num_classes=768)
+        sd = synth.synth_state_dict({k: v for k, v in synth.shapes_of(m).items()}, 12)
+        m.load_state_dict(sd)
+        return m.cuda()
+    _, _, text, _ = synth.synth_batch(16, seed=22, with_text=True)
+    text = {k: v.cuda() for k, v in text.items()}
+    m_drop, m_nodrop = build(), build(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m_nodrop.train()
+    ref = m_nodrop(text).detach()
+    m_drop.eval()
+    with torch.no_grad():
+        assert torch.equal(m_drop(text), m_drop(text))
+        assert rel_err(m_drop(text), ref) < 1e-6
+    m_drop.train()
+    y1 = m_drop(text)
+    y2 = m_drop(text)
+    assert rel_err(y1, y2) > 1e-3, "two train-mode forwards must use different masks"
+    assert rel_err(y1, ref) < 0.5
+    (y2 * torch.randn_like(y2)).sum().backward()
+    grads = [p.grad for p in m_drop.parameters() if p.requires_grad]
+    assert all(torch.isfinite(g).all() and g.abs().sum() > 0 for g in grads)

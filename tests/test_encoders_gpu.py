@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 from helpers import check_summary, load_golden, rel_err  # noqa: E402
 from oracle import refcpu, synth  # noqa: E402
 
+NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)  # parity = deterministic path
 TOL_EMB_EMU = 4e-3
 TOL_EMB_F32 = 2e-2
 TOL_GRAD_F32 = 1e-1
@@ -89,7 +90,7 @@ def _compare_encoder(name, module, prefix, sd, hip_in, oracle_fn, cot_key, gold)
 def test_dna_encoder(layers):
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
-    m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=layers)), r=4,
+    m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=layers, **NODROP)), r=4,
                           num_classes=768)
     sd = _load(m, "dna_encoder.", 11)
     _, dna, _, _ = synth.synth_batch(2, seed=21)
@@ -101,7 +102,7 @@ def test_dna_encoder(layers):
 def test_text_encoder():
     from bioscanclip.model import arch
     from bioscanclip.model.language_encoder import LoRA_bert
-    m = LoRA_bert(arch.BertModelParams(arch.bert_small_config()), r=4, num_classes=768)
+    m = LoRA_bert(arch.BertModelParams(arch.bert_small_config(**NODROP)), r=4, num_classes=768)
     sd = _load(m, "language_encoder.", 12)
     _, _, text, _ = synth.synth_batch(4, seed=22, with_text=True)
     fn = lambda s, emulate=False: refcpu.bert_text_encoder(s, text, emulate_bf16=emulate)
@@ -128,8 +129,8 @@ def _build_clip(with_text, seed):
     from bioscanclip.model.language_encoder import LoRA_bert
     from bioscanclip.model.simple_clip import SimpleCLIP
     img = LoRA_ViT_timm(arch.vit_base_patch16_224(), r=4, num_classes=768)
-    dna = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config()), r=4, num_classes=768)
-    txt = LoRA_bert(arch.BertModelParams(arch.bert_small_config()), r=4, num_classes=768) if with_text else None
+    dna = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(**NODROP)), r=4, num_classes=768)
+    txt = LoRA_bert(arch.BertModelParams(arch.bert_small_config(**NODROP)), r=4, num_classes=768) if with_text else None
     model = SimpleCLIP(img, dna, txt)
     sd = _load(model, "", seed)
     return model, sd
