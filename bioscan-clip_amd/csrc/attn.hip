@@ -3,14 +3,15 @@
 // Replaces timm Attention.forward (softmax(q k^T * 64^-0.5) v; reached from image_encoder.py:108-109) and HF
 // BertSelfAttention (same, plus the additive key mask used by the text tower, language_encoder.py:89).
 //
-// One workgroup per (batch, head); the whole K / V (or Q / dO) of that head lives in LDS, one 64-lane wave per
-// 32-row block.  All five/seven products run on v_mfma_f32_32x32x16_bf16.  Score tiles are computed TRANSPOSED
+// One workgroup (4 waves) per (batch, head); the whole K / V (or Q / dO) of that head lives in LDS as row-major
+// XOR-swizzled tiles; a wave owns 32-row blocks w, w+4, ...  LDS <= 58 KiB, so two workgroups share a CU and one's
+// staging/barriers hide behind the other's MFMA work.  All five/seven products run on v_mfma_f32_32x32x16_bf16.  Score tiles are computed TRANSPOSED
 // (key on the accumulator rows, query on the lane) so that
 //   * the softmax reduction over keys is in-lane (16 registers per tile) plus one xor-32 shuffle, and
 //   * the probability tile feeds the next MFMA straight from the accumulator registers ("accumulator tile as the
 //     next MFMA's operand", cdna_hip_programming.md 3): P^T never goes through LDS.
-// The operand that must be k-strided for that second product (V^T, Q^T, dO^T, K^T) is staged once per workgroup as a
-// transposed LDS image with rows padded by 8 B, which makes the paired ds_read_b64 fragment reads conflict-free.
+// The operand that must be k-strided for that second product (V^T, Q^T, dO^T, K^T) is read TRANSPOSED out of the same
+// row-major image with ds_read_b64_tr_b16 -- no second LDS copy, no 2-byte scatter writes.
 // Backward runs two phases in one launch: query-owner waves produce delta = rowsum(P.dP) and dQ, then key-owner waves
 // produce dK/dV, so nothing is accumulated across waves (no atomics, bitwise reproducible).
 #include <math.h>
@@ -41,28 +42,19 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
 }
 
 constexpr int ROWB = 128;  // bytes per row of a row-major [rows][64] bf16 tile
-__host__ __device__ constexpr int tstride(int SP) { return SP * 2 + 8; }  // bytes per row of a transposed [64][SP] tile
+constexpr int ATT_WAVES = 4;  // waves per workgroup; wave w owns 32-row blocks w, w+4, ...
 
 // Row-major tile, 16-B chunk index XOR-swizzled with (row>>1)&7: conflict-free ds_read_b128 for the 32x32x16 A operand.
 __device__ __forceinline__ int rm_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// Stage rows [0,S) of a [S][64] bf16 matrix (row stride ld elements) into LDS: row-major (dst_rm, nullable) and/or
-// transposed (dst_t, nullable).  Rows >= S are zero-filled.
+// Stage rows [0,S) of a [S][64] bf16 matrix (row stride ld elements) into a row-major LDS tile; rows >= S are zero.
 template <int SP>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int S, char* dst_rm, char* dst_t,
-                                           int tid, int nthreads) {
-    for (int it = tid; it < SP * 8; it += nthreads) {
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int S, char* dst_rm, int tid) {
+    for (int it = tid; it < SP * 8; it += ATT_WAVES * 64) {
         const int row = it >> 3, c = it & 7;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row < S) v = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + c * 8);
-        if (dst_rm) *reinterpret_cast<u32x4*>(dst_rm + rm_off(row, c)) = v;
-        if (dst_t) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<bf16_t*>(dst_t + (c * 8 + 2 * i) * tstride(SP) + row * 2) = (bf16_t)(v[i] & 0xffff);
-                *reinterpret_cast<bf16_t*>(dst_t + (c * 8 + 2 * i + 1) * tstride(SP) + row * 2) = (bf16_t)(v[i] >> 16);
-            }
-        }
+        *reinterpret_cast<u32x4*>(dst_rm + rm_off(row, c)) = v;
     }
 }
 
@@ -70,15 +62,23 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int l
 __device__ __forceinline__ bf16x8 frag_rm(const char* tile, int r0, int ks, int lane) {
     return *reinterpret_cast<const bf16x8*>(tile + rm_off(r0 + (lane & 31), 2 * ks + (lane >> 5)));
 }
-// A-operand fragment of a transposed tile for the accumulator-as-B product: rows d0 + (lane&31); element j is column
-// c0 + 8*(j>>2) + 4*(lane>>5) + (j&3)  (matches the k order of pack8()).
-template <int SP>
-__device__ __forceinline__ bf16x8 frag_t(const char* tile, int d0, int c0, int lane) {
-    const char* p = tile + (d0 + (lane & 31)) * tstride(SP) + (c0 + 4 * (lane >> 5)) * 2;
-    const uint2 lo = *reinterpret_cast<const uint2*>(p);
-    const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
-    u32x4 u = {lo.x, lo.y, hi.x, hi.y};
-    return __builtin_bit_cast(bf16x8, u);
+// TRANSPOSED A-operand fragment of the same row-major tile, for the accumulator-as-B product: MFMA row = tile COLUMN
+// d0 + (lane&31); element j is tile ROW c0 + 8*(j>>2) + 4*(lane>>5) + (j&3) (the k order of pack8()).
+// ds_read_b64_tr_b16 (verified on hardware by tools/probe/tr_probe.py): within each 16-lane group, lane 4q+p supplies
+// the address of row q / columns 4p..4p+3 of a 4x16 block and lane i receives column i of the 4 rows.  Group
+// gi = lane>>4 serves columns d0 + 16*(gi&1) + [0,16) and rows c0 + 4*(gi>>1) + [0,4)  (gi>>1 == lane>>5).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int d0, int c0, int lane) {
+    const int gi = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row = c0 + 4 * (gi >> 1) + q;
+    const int col = d0 + 16 * (gi & 1) + 4 * pp;  // 4 consecutive bf16 = 8 B inside one 16-B chunk
+    const char* p0 = tile + rm_off(row, col >> 3) + (col & 7) * 2;
+    const char* p1 = tile + rm_off(row + 8, col >> 3) + (col & 7) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
 }
 // B-operand fragment straight from global: row (clamped) of a [S][64] matrix, k = 16*ks + 8*(lane>>5) + j
 __device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, int ld, int row, int ks, int lane) {
@@ -102,15 +102,15 @@ __device__ __forceinline__ void store_dt(const f32x16 (&acc)[2], float mul, bf16
 }
 
 template <int NB>
-__global__ __launch_bounds__(NB * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S, int heads,
-                                                            const float* __restrict__ key_bias, float scale,
-                                                            bf16_t* __restrict__ ctx, int ld_ctx,
-                                                            float* __restrict__ lse, DropCfg drop) {
+__global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S,
+                                                                   int heads, const float* __restrict__ key_bias,
+                                                                   float scale, bf16_t* __restrict__ ctx, int ld_ctx,
+                                                                   float* __restrict__ lse, DropCfg drop) {
     constexpr int SP = NB * 32;
-    __shared__ __attribute__((aligned(16))) char smem[SP * ROWB + 64 * tstride(SP) + SP * 4];
+    __shared__ __attribute__((aligned(16))) char smem[2 * SP * ROWB + SP * 4];
     char* sK = smem;
-    char* sVt = smem + SP * ROWB;
-    float* sBias = reinterpret_cast<float*>(smem + SP * ROWB + 64 * tstride(SP));
+    char* sV = smem + SP * ROWB;
+    float* sBias = reinterpret_cast<float*>(smem + 2 * SP * ROWB);
 
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -120,113 +120,118 @@ __global__ __launch_bounds__(NB * 64) void attn_fwd_kernel(const bf16_t* __restr
     const bf16_t* kb = qb + HW;
     const bf16_t* vb = kb + HW;
 
-    stage_tile<SP>(kb, ld, S, sK, nullptr, tid, NB * 64);
-    stage_tile<SP>(vb, ld, S, nullptr, sVt, tid, NB * 64);
-    for (int k = tid; k < SP; k += NB * 64)
+    stage_tile<SP>(kb, ld, S, sK, tid);
+    stage_tile<SP>(vb, ld, S, sV, tid);
+    for (int k = tid; k < SP; k += ATT_WAVES * 64)
         sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
-
-    const int q0 = wave * 32;
-    const int qrow = min(q0 + (lane & 31), S - 1);
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qb, ld, qrow, ks, lane);
     __syncthreads();
 
-    // S^T tiles: rows = keys, lane = query
-    f32x16 p[NB];
-    float m = -INFINITY;
+#pragma unroll 1
+    for (int blk = wave; blk < NB; blk += ATT_WAVES) {
+        asm volatile("" ::: "memory");  // LDS tiles are loop-invariant: stop LICM from hoisting ~100 fragment registers
+        const int q0 = blk * 32;
+        const int qrow = min(q0 + (lane & 31), S - 1);
+        bf16x8 qf[4];
 #pragma unroll
-    for (int kt = 0; kt < NB; ++kt) {
-        f32x16 acc = zero16();
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qb, ld, qrow, ks, lane);
+
+        // S^T tiles: rows = keys, lane = query
+        f32x16 p[NB];
+        float m = -INFINITY;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = mfma32(frag_rm(sK, 32 * kt, ks, lane), qf[ks], acc);
+        for (int kt = 0; kt < NB; ++kt) {
+            f32x16 acc = zero16();
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+            for (int ks = 0; ks < 4; ++ks) acc = mfma32(frag_rm(sK, 32 * kt, ks, lane), qf[ks], acc);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float s = acc[4 * g + i] * scale + bias[i];
-                acc[4 * g + i] = s;
-                m = fmaxf(m, s);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float s = acc[4 * g + i] * scale + bias[i];
+                    acc[4 * g + i] = s;
+                    m = fmaxf(m, s);
+                }
             }
+            p[kt] = acc;
         }
-        p[kt] = acc;
-    }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NB; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = __expf(p[kt][r] - m);
-            p[kt][r] = e;
-            sum += e;
-        }
-    sum += __shfl_xor(sum, 32, 64);
-    if (drop.thr16) {  // HF: dropout on the normalised probabilities (the row sum above is taken before it)
-        const unsigned base = ((unsigned)(b * heads + hd) * S + (unsigned)min(q0 + (lane & 31), S - 1)) * S;
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NB; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[kt][r] *= drop_factor(drop, base + 32 * kt + acc_row(r, h));
-    }
-
-    // O^T[d, query] = sum_key V^T[d, key] P^T[key, query]
-    f32x16 o[2] = {zero16(), zero16()};
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(p[kt][r] - m);
+                p[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        if (drop.thr16) {  // HF: dropout on the normalised probabilities (the row sum above is taken before it)
+            const unsigned base = ((unsigned)(b * heads + hd) * S + (unsigned)qrow) * S;
 #pragma unroll
-    for (int kt = 0; kt < NB; ++kt)
+            for (int kt = 0; kt < NB; ++kt)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pb = pack8(p[kt], s2);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_t<SP>(sVt, 32 * dt, 32 * kt + 16 * s2, lane), pb, o[dt]);
+                for (int r = 0; r < 16; ++r) p[kt][r] *= drop_factor(drop, base + 32 * kt + acc_row(r, h));
         }
 
-    const int q = q0 + (lane & 31);
-    if (q < S) {
-        store_dt(o, 1.0f / sum, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
-        if (h == 0) lse[((size_t)b * heads + hd) * S + q] = m + __logf(sum);
+        // O^T[d, query] = sum_key V^T[d, key] P^T[key, query]
+        f32x16 o[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int kt = 0; kt < NB; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = pack8(p[kt], s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_tr(sV, 32 * dt, 32 * kt + 16 * s2, lane), pb, o[dt]);
+            }
+
+        const int q = q0 + (lane & 31);
+        if (q < S) {
+            store_dt(o, 1.0f / sum, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
+            if (h == 0) lse[((size_t)b * heads + hd) * S + q] = m + __logf(sum);
+        }
     }
 }
 
 template <int NB>
-__global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
-                                                            const bf16_t* __restrict__ dctx, int ld_ctx,
-                                                            const float* __restrict__ lse, int S, int heads,
-                                                            const float* __restrict__ key_bias, float scale,
-                                                            bf16_t* __restrict__ dqkv, int ld_d, DropCfg drop) {
+__global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
+                                                                   const bf16_t* __restrict__ dctx, int ld_ctx,
+                                                                   const float* __restrict__ lse, int S, int heads,
+                                                                   const float* __restrict__ key_bias, float scale,
+                                                                   bf16_t* __restrict__ dqkv, int ld_d, DropCfg drop) {
     constexpr int SP = NB * 32;
-    constexpr int RM = SP * ROWB, TR = 64 * tstride(SP);
-    __shared__ __attribute__((aligned(16))) char smem[2 * RM + 2 * TR + 3 * SP * 4];
-    char* sR0 = smem;            // phase 1: K   | phase 2: Q
-    char* sR1 = smem + RM;       // phase 1: V   | phase 2: dO
-    char* sT0 = smem + 2 * RM;   // phase 1: K^T | phase 2: Q^T
-    char* sT1 = sT0 + TR;        //              | phase 2: dO^T
-    float* sLse = reinterpret_cast<float*>(sT1 + TR);
+    constexpr int RM = SP * ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * RM + 3 * SP * 4];
+    char* sR0 = smem;       // phase 1: K | phase 2: Q
+    char* sR1 = smem + RM;  // phase 1: V | phase 2: dO
+    float* sLse = reinterpret_cast<float*>(smem + 2 * RM);
     float* sDelta = sLse + SP;
     float* sBias = sDelta + SP;
 
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NT = NB * 64;
     const int HW = heads * 64;
     const bf16_t* qb = qkv + (size_t)b * S * ld + hd * 64;
     const bf16_t* kb = qb + HW;
     const bf16_t* vb = kb + HW;
     const bf16_t* dob = dctx + (size_t)b * S * ld_ctx + hd * 64;
     bf16_t* dqb = dqkv + (size_t)b * S * ld_d + hd * 64;
+    const unsigned bh = (unsigned)(b * heads + hd);
 
-    // ---------------- phase 1 staging: K (row-major + transposed), V (row-major), lse, bias ----------------
-    stage_tile<SP>(kb, ld, S, sR0, sT0, tid, NT);
-    stage_tile<SP>(vb, ld, S, sR1, nullptr, tid, NT);
-    for (int k = tid; k < SP; k += NT) {
+    // ---------------- phase 1 staging: K, V row-major, lse, bias ----------------
+    stage_tile<SP>(kb, ld, S, sR0, tid);
+    stage_tile<SP>(vb, ld, S, sR1, tid);
+    for (int k = tid; k < SP; k += ATT_WAVES * 64) {
         sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
         sLse[k] = (k < S) ? lse[((size_t)b * heads + hd) * S + k] : INFINITY;  // padded queries -> p = 0
     }
-    {
-        // ---------------- phase 1: this wave owns queries [q0, q0+32): delta, then dQ ----------------
-        const int q0 = wave * 32;
+    __syncthreads();
+    // ---------------- phase 1: a wave owns queries [q0, q0+32): delta, then dQ ----------------
+#pragma unroll 1
+    for (int blk = wave; blk < NB; blk += ATT_WAVES) {
+        asm volatile("" ::: "memory");  // LDS tiles are loop-invariant: stop LICM from hoisting ~100 fragment registers
+        const int q0 = blk * 32;
         const int qrow = min(q0 + (lane & 31), S - 1);
         bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -234,12 +239,12 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
             qf[ks] = frag_global(qb, ld, qrow, ks, lane);
             dof[ks] = frag_global(dob, ld_ctx, qrow, ks, lane);
         }
-        __syncthreads();
         const float lse_q = sLse[q0 + (lane & 31)];
-        const unsigned dbase = ((unsigned)(b * heads + hd) * S + (unsigned)qrow) * S;  // dropout index of (q, key 0)
+        const unsigned dbase = (bh * S + (unsigned)qrow) * S;  // dropout index of (q, key 0)
         // pass 1: delta_q = sum_key P[q,key] dP[q,key], from the SAME P and dP the gradient uses, so that
-        // sum_key dS[q,key] = 0 holds to f32 rounding (delta from the bf16-rounded O does not: it loses the
-        // cancellation whenever the values of a head are nearly equal across keys).
+        // sum_key dS[q,key] = 0 holds to f32 rounding (delta from the bf16-rounded O does not: it loses the cancellation
+        // whenever the values of a head are nearly equal across keys).  P is recomputed in pass 2 rather than kept:
+        // 7 tiles x 16 registers would push the kernel past 256 VGPRs.
         float dpart = 0.f;
 #pragma unroll 1
         for (int kt = 0; kt < NB; ++kt) {
@@ -288,19 +293,22 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
                 const bf16x8 dsb = pack8(dp, s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = mfma32(frag_t<SP>(sT0, 32 * dt, 32 * kt + 16 * s2, lane), dsb, dq[dt]);  // K^T dS^T
+                    dq[dt] = mfma32(frag_tr(sR0, 32 * dt, 32 * kt + 16 * s2, lane), dsb, dq[dt]);  // K^T dS^T
             }
         }
         const int q = q0 + (lane & 31);
         if (q < S) store_dt(dq, 1.0f, dqb + (size_t)q * ld_d, lane);
     }
     __syncthreads();
-    // ---------------- phase 2 staging: Q, dO (row-major + transposed) ----------------
-    stage_tile<SP>(qb, ld, S, sR0, sT0, tid, NT);
-    stage_tile<SP>(dob, ld_ctx, S, sR1, sT1, tid, NT);
-    {
-        // ---------------- phase 2: this wave owns keys [k0, k0+32): dV, dK ----------------
-        const int k0 = wave * 32;
+    // ---------------- phase 2 staging: Q, dO row-major ----------------
+    stage_tile<SP>(qb, ld, S, sR0, tid);
+    stage_tile<SP>(dob, ld_ctx, S, sR1, tid);
+    __syncthreads();
+    // ---------------- phase 2: a wave owns keys [k0, k0+32): dV, dK ----------------
+#pragma unroll 1
+    for (int blk = wave; blk < NB; blk += ATT_WAVES) {
+        asm volatile("" ::: "memory");  // LDS tiles are loop-invariant: stop LICM from hoisting ~100 fragment registers
+        const int k0 = blk * 32;
         const int krow = min(k0 + (lane & 31), S - 1);
         bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -308,7 +316,6 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
             kf[ks] = frag_global(kb, ld, krow, ks, lane);
             vf[ks] = frag_global(vb, ld, krow, ks, lane);
         }
-        __syncthreads();
         const float bias_k = sBias[k0 + (lane & 31)];
         f32x16 dv[2] = {zero16(), zero16()}, dk[2] = {zero16(), zero16()};
 #pragma unroll 1
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
                     float keep = 1.0f;
                     if (drop.thr16) {
                         const int q = min(32 * qt + 8 * g + 4 * h + i, S - 1);
-                        keep = drop_factor(drop, ((unsigned)(b * heads + hd) * S + (unsigned)q) * S + (unsigned)krow);
+                        keep = drop_factor(drop, (bh * S + (unsigned)q) * S + (unsigned)krow);
                     }
                     s[4 * g + i] = pr * keep;                                        // dropped P (feeds dV)
                     dp[4 * g + i] = pr * (dp[4 * g + i] * keep - d4[i]) * scale;     // dS (scaled)
@@ -340,8 +347,8 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
                 const bf16x8 pb = pack8(s, s2), dsb = pack8(dp, s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = mfma32(frag_t<SP>(sT1, 32 * dt, 32 * qt + 16 * s2, lane), pb, dv[dt]);   // dO^T P
-                    dk[dt] = mfma32(frag_t<SP>(sT0, 32 * dt, 32 * qt + 16 * s2, lane), dsb, dk[dt]);  // Q^T dS
+                    dv[dt] = mfma32(frag_tr(sR1, 32 * dt, 32 * qt + 16 * s2, lane), pb, dv[dt]);   // dO^T P
+                    dk[dt] = mfma32(frag_tr(sR0, 32 * dt, 32 * qt + 16 * s2, lane), dsb, dk[dt]);  // Q^T dS
                 }
             }
         }
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(NB * 64) void attn_bwd_kernel(const bf16_t* __restr
 
 #define ATTN_FWD_CASE(NBV)                                                                                      \
     case NBV:                                                                                                   \
-        hipLaunchKernelGGL((attn_fwd_kernel<NBV>), dim3(B * heads), dim3(NBV * 64), 0, s,                       \
+        hipLaunchKernelGGL((attn_fwd_kernel<NBV>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,                 \
                            static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,                  \
                            static_cast<bf16_t*>(ctx), ld_ctx, lse, drop);                                       \
         break;
@@ -382,7 +389,7 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
 
 #define ATTN_BWD_CASE(NBV)                                                                                       \
     case NBV:                                                                                                    \
-        hipLaunchKernelGGL((attn_bwd_kernel<NBV>), dim3(B * heads), dim3(NBV * 64), 0, s,                        \
+        hipLaunchKernelGGL((attn_bwd_kernel<NBV>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,                  \
                            static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx,    \
                            lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop);           \
         break;
