@@ -28,6 +28,7 @@ SIGNATURES = {
     "bsclip_abi_version": (I, []),
     "bsclip_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P]),
     "bsclip_gemm_set_tile": (I, [I]),
+    "bsclip_gemm_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, P]),
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, F, U, P]),

@@ -46,6 +46,7 @@ struct EpiArgs {
     int ld_aux;
     DropCfg drop;  // RESID only: C = dropout(acc + bias) + resid  (HF BertSelfOutput / BertOutput)
     int n_total;   // logical row width for the dropout element index
+    unsigned long long* diag;  // diagnostic build only: per-workgroup phase stamps (100 MHz wall clock)
 };
 
 // v already holds acc (+ bias).  No data-dependent branch guards a load.
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const bf
 //        of the next tile), i.e. >= 2 barrier instants after the slower group's reads have been waited for.
 //   RAW  every wave waits (vmcnt) for its own DMA pieces of tile t+1 BEFORE the first barrier of phase 3; the first
 //        reads of tile t+1 (phase 0) come after at least one more barrier for both groups.
-template <int EPI, bool HAS_BIAS>
+template <int EPI, bool HAS_BIAS, bool DIAG = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restrict__ A, int lda,
                                                           const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                           int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
@@ -320,6 +321,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 
+    auto stamp = [&](int i) {
+        if constexpr (DIAG) {
+            if (lane == 0 && wc == 0) e.diag[(size_t)blockIdx.x * 8 + g * 4 + i] = wall_clock64();
+        }
+    };
+    stamp(0);
     const int nk = K / BK;
     // ---- prologue: tile 0 complete, plus the first piece of tile 1 (the "phase 3 of tile -1" slot) ----
     dmaA(0, 0, 0);
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     }
     PP_BARRIER();
     if (g == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
+    stamp(1);
 
     for (int t = 0; t < nk; ++t) {
         const int set = t & 1;
@@ -372,6 +380,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     }
     if (g == 0) PP_BARRIER();  // balance group 1's extra barrier
 #undef PP_BARRIER
+    stamp(2);
 
     // ---- epilogue ----
     f32x4 bias[2][2];
@@ -461,12 +470,34 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 if (e.aux) rows_bf16(mi, slab2, e.aux, e.ld_aux);  // gelu'(pre-activation) for the backward pass
             }
             __syncthreads();
-        } else {
-            stage_f32(mi);
-            __syncthreads();
+        }
+    }
+    if constexpr (!(EPI == BSCLIP_EPI_BF16 || EPI == BSCLIP_EPI_GELU_BF16)) {
+        // f32-staged epilogues read a second operand (residual stream / saved gelu') row-wise.  Those loads do not
+        // depend on the accumulators, so they are issued one slab ahead -- before the staging barrier -- and have the
+        // whole LDS round trip to land (issued just-in-time they were 16 serial HBM round trips per wave: 26 us/tile).
+        f32x4 pre[2][16];
+        auto prefetch = [&](int mi, f32x4 (&R)[16]) {
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
-                const int r = it * 4 + wq;                       // one 1-KiB row per wave instruction
+                const int m = min(m0 + 128 * g + 64 * mi + it * 4 + wq, M - 1);
+                const int n = n0 + lane * 4;
+                if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
+                    R[it] = *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
+                } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
+                    const uint2 z = *reinterpret_cast<const uint2*>(e.aux + (size_t)m * e.ld_aux + n);
+                    R[it] = f32x4{bf2f(z.x & 0xffff), bf2f(z.x >> 16), bf2f(z.y & 0xffff), bf2f(z.y >> 16)};
+                } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
+                    R[it] = *reinterpret_cast<const f32x4*>(e.resid + (size_t)(1 + m % 196) * e.ld_resid + n);
+                } else {
+                    R[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        auto consume = [&](int mi, const f32x4 (&R)[16]) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 4 + wq;  // one 1-KiB row per wave instruction
                 const int m = m0 + 128 * g + 64 * mi + r;
                 const int n = n0 + lane * 4;
                 f32x4 v = *reinterpret_cast<const f32x4*>(slab + r * SF + lane * 16);
@@ -475,24 +506,33 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
                     } else if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
                         if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
-                        v += *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
+                        v += R[it];
                         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
                     } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
-                        const uint2 z = *reinterpret_cast<const uint2*>(e.aux + (size_t)m * e.ld_aux + n);
+                        v *= R[it];
                         uint2 o;
-                        o.x = pack_bf2(v[0] * bf2f(z.x & 0xffff), v[1] * bf2f(z.x >> 16));
-                        o.y = pack_bf2(v[2] * bf2f(z.y & 0xffff), v[3] * bf2f(z.y >> 16));
+                        o.x = pack_bf2(v[0], v[1]);
+                        o.y = pack_bf2(v[2], v[3]);
                         *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = o;
                     } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
                         const int b = m / 196, p = m - b * 196;
-                        v += *reinterpret_cast<const f32x4*>(e.resid + (size_t)(1 + p) * e.ld_resid + n);
+                        v += R[it];
                         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = v;
                     }
                 }
             }
-            __syncthreads();
-        }
+        };
+        prefetch(0, pre[0]);
+        stage_f32(0);
+        __syncthreads();
+        prefetch(1, pre[1]);
+        consume(0, pre[0]);
+        __syncthreads();
+        stage_f32(1);
+        __syncthreads();
+        consume(1, pre[1]);
     }
+    stamp(3);
 }
 
 int g_tile_override = 0;
@@ -543,6 +583,45 @@ void launch_bias(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, in
 }
 
 }  // namespace
+
+// Diagnostic: the ping-pong kernel with four phase stamps per workgroup and wave group (start, prologue done, K loop
+// done, end) written to diag[grid*8] (100 MHz ticks).  Used by tools/gemm_phases.py; not on any product path.
+extern "C" int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream) {
+    BSCLIP_REQUIRE(A && B && C && diag && args, "bsclip_gemm_diag: null pointer");
+    BSCLIP_REQUIRE(K % 64 == 0 && N % 256 == 0, "bsclip_gemm_diag: K %% 64, N %% 256");
+    EpiArgs e{};
+    e.bias = args->bias;
+    e.resid = args->resid;
+    e.ld_resid = args->ld_resid;
+    e.aux = static_cast<bf16_t*>(args->aux);
+    e.ld_aux = args->ld_aux;
+    e.drop = make_drop(0.f, 0);
+    e.n_total = N;
+    e.diag = diag;
+    const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
+    const dim3 grid(tiles_m * tiles_n), block(512);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16_t* a = static_cast<const bf16_t*>(A);
+    const bf16_t* b = static_cast<const bf16_t*>(B);
+    switch (epilogue) {
+        case BSCLIP_EPI_BF16:
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<BSCLIP_EPI_BF16, false, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
+            break;
+        case BSCLIP_EPI_GELU_BF16:
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<BSCLIP_EPI_GELU_BF16, true, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
+            break;
+        case BSCLIP_EPI_RESID_F32:
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<BSCLIP_EPI_RESID_F32, true, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
+            break;
+        case BSCLIP_EPI_DGELU_BF16:
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<BSCLIP_EPI_DGELU_BF16, false, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
+            break;
+        default: BSCLIP_REQUIRE(false, "bsclip_gemm_diag: epilogue %d has no diagnostic build", epilogue);
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
 
 extern "C" int bsclip_gemm_set_tile(int tile) {
     BSCLIP_REQUIRE(tile >= 0 && tile <= 4, "bsclip_gemm_set_tile: tile %d not in [0,4]", tile);

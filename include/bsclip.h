@@ -60,6 +60,10 @@ int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, in
                      int epilogue, const bsclip_epi_args* args, void* stream);
 /* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 */
 int bsclip_gemm_set_tile(int tile);
+/* diagnostic build of the 256x256 kernel: per-workgroup phase stamps (start, prologue, K loop, end) in 100 MHz ticks,
+ * diag[grid * 8]; tools/gemm_phases.py.  Never used by the product path. */
+int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream);
 
 /* ---- LayerNorm (timm norm1/norm2/norm eps 1e-6; HF BertLayerNorm eps 1e-12) ------------------------------------
  * fwd: y = LN(x) * gamma + beta for f32 rows x[M,H] (H = 768 or 512).
