@@ -186,10 +186,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs (one-GPU box): BSCLIP_DIST_BACKEND=gloo + BSCLIP_SINGLE_DEVICE=1 runs N ranks on cuda:0 so the whole
+    # multi-rank code path (all-gather loss with row0/n_local, flat-gradient all-reduce) executes without an 8-GPU node.
+    backend = os.environ.get("BSCLIP_DIST_BACKEND", "nccl")
+    if os.environ.get("BSCLIP_SINGLE_DEVICE", "0") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
