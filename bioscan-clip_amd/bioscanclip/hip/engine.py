@@ -198,9 +198,8 @@ class ViTEngine(EncoderEngineBase):
         ws["st2"] = [z(M, 2, dt=F32) for _ in range(L)]
         ws["qkv"] = [z(M, 3 * H) for _ in range(L)]
         ws["ctx"] = [z(M, H) for _ in range(L)]
-        ws["ctx_lo"] = [z(M, H) for _ in range(L)]                    # low half of the attention output (delta in bwd)
         ws["lse"] = [z(B, self.heads, S, dt=F32) for _ in range(L)]
-        ws["z"] = [z(M, FF) for _ in range(L)]                        # gelu'(fc1 pre-activation)
+        ws["z"] = [z(M, FF) for _ in range(L)]                        # fc1 pre-activation
         ws["h2"] = z(M, H)
         ws["act"] = z(M, FF)
         ws["clsn"] = z(B, H)
@@ -237,7 +236,7 @@ class ViTEngine(EncoderEngineBase):
             ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_bf16=ws["h1"][l], lora_a=self.lora_a(l),
                               stats=ws["st1"][l])
             ops.gemm(ws["h1"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
-            ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], ctx_lo=ws["ctx_lo"][l])
+            ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l])
             ops.gemm(ws["ctx"][l], lay.w_proj, x[2 * l + 1], EPI_RESID_F32, bias=lay.b_proj, resid=x[2 * l])
             ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2"], stats=ws["st2"][l])
             ops.gemm(ws["h2"], lay.w_fc1, ws["act"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
@@ -277,8 +276,7 @@ class ViTEngine(EncoderEngineBase):
             ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh"], dx_f32=dx,
                               dx_bf16=dxb)
             ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
-            ops.attn_bwd(ws["qkv"][l], ws["ctx"][l], ws["ctx_lo"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale,
-                         ws["dqkv"])
+            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"])
             lb = self.lora_b(l)
             if lb is not None:
                 gb = self.lora_b(l, grad=True)
@@ -369,7 +367,6 @@ class BertEngine(EncoderEngineBase):
         ws["ymb"] = z(M, H)
         ws["qkv"] = [z(M, 3 * H) for _ in range(L)]
         ws["ctx"] = [z(M, H) for _ in range(L)]
-        ws["ctx_lo"] = [z(M, H) for _ in range(L)]
         ws["lse"] = [z(B, self.heads, S, dt=F32) for _ in range(L)]
         ws["s1"] = [z(M, H, dt=F32) for _ in range(L)]      # pre-LN sums (LN backward inputs)
         ws["s2"] = [z(M, H, dt=F32) for _ in range(L)]
@@ -441,7 +438,7 @@ class BertEngine(EncoderEngineBase):
         for l, lay in enumerate(self.layers):
             ops.gemm(ws["yb"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
             ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], key_bias=key_bias,
-                         dropout=self._drop(ws, self.p_attn, l, 1), ctx_lo=ws["ctx_lo"][l])
+                         dropout=self._drop(ws, self.p_attn, l, 1))
             ops.gemm(ws["ctx"][l], lay.w_o, ws["s1"][l], EPI_RESID_F32, bias=lay.b_o, resid=ws["y"],
                      dropout=self._drop(ws, self.p_hidden, l, 2))
             ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ws["ymb"], y_f32=ws["ym"],
@@ -502,8 +499,8 @@ class BertEngine(EncoderEngineBase):
             ops.layernorm_bwd(ws["s1"][l], ws["sta"][l], lay.ln_a[0], 1, g_resid=ws["ds"], g_gemm=ws["dh"],
                               dx_f32=ws["ds1"], dx_bf16=ws["dsb"], dropout=self._drop(ws, self.p_hidden, l, 2))
             ops.gemm(ws["dsb"], lay.w_o_t, ws["dctx"], EPI_BF16)
-            ops.attn_bwd(ws["qkv"][l], ws["ctx"][l], ws["ctx_lo"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale,
-                         ws["dqkv"], key_bias=ws["key_bias"], dropout=self._drop(ws, self.p_attn, l, 1))
+            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
+                         key_bias=ws["key_bias"], dropout=self._drop(ws, self.p_attn, l, 1))
             lb = self.lora_b(l)
             if lb is not None:
                 gbb = self.lora_b(l, grad=True)

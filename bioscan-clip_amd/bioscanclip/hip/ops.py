@@ -129,33 +129,29 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
                                          0 if dropout is None else int(dropout[1]) & 0xFFFFFFFF, _stream()))
 
 
-def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, ctx_lo=None):
+def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None):
     ld_qkv, ld_ctx = _rowmajor(qkv, "qkv"), _rowmajor(ctx, "ctx")
     _req(qkv.dtype == BF16 and ctx.dtype == BF16 and lse.dtype == F32, "attn_fwd dtypes")
     _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64, "attn_fwd: qkv too small")
     _req(ctx.shape[0] >= B * S and ctx.shape[1] >= heads * 64 and lse.numel() >= B * heads * S, "attn_fwd: outputs too small")
-    if ctx_lo is not None:
-        _req(ctx_lo.dtype == BF16 and ctx_lo.shape == ctx.shape and _rowmajor(ctx_lo, "ctx_lo") == ld_ctx,
-             "attn_fwd: ctx_lo must mirror ctx")
     if key_bias is not None:
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
-    check(_l.load().bsclip_attn_fwd(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), _p(ctx_lo), ld_ctx,
-                                    _p(lse), dp, ds, _stream()))
+    check(_l.load().bsclip_attn_fwd(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), ld_ctx, _p(lse),
+                                    dp, ds, _stream()))
 
 
-def attn_bwd(qkv, ctx, ctx_lo, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None):
+def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None):
     ld_qkv, ld_ctx, ld_d = _rowmajor(qkv, "qkv"), _rowmajor(dctx, "dctx"), _rowmajor(dqkv, "dqkv")
-    _req(all(t.dtype == BF16 for t in (qkv, ctx, ctx_lo, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
-    _req(_rowmajor(ctx, "ctx") == ld_ctx and _rowmajor(ctx_lo, "ctx_lo") == ld_ctx, "attn_bwd: ctx/ctx_lo/dctx share a stride")
-    _req(min(qkv.shape[0], ctx.shape[0], ctx_lo.shape[0], dctx.shape[0], dqkv.shape[0]) >= B * S, "attn_bwd: rows")
+    _req(all(t.dtype == BF16 for t in (qkv, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
+    _req(min(qkv.shape[0], dctx.shape[0], dqkv.shape[0]) >= B * S, "attn_bwd: rows")
     _req(qkv.shape[1] >= 3 * heads * 64 and dqkv.shape[1] >= 3 * heads * 64 and dctx.shape[1] >= heads * 64
-         and ctx.shape[1] >= heads * 64 and ctx_lo.shape[1] >= heads * 64 and lse.numel() >= B * heads * S, "attn_bwd: cols")
+         and lse.numel() >= B * heads * S, "attn_bwd: cols")
     if key_bias is not None:
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
-    check(_l.load().bsclip_attn_bwd(_p(qkv), ld_qkv, _p(ctx), _p(ctx_lo), _p(dctx), ld_ctx, _p(lse), B, S, heads,
-                                    _p(key_bias), float(scale), _p(dqkv), ld_d, dp, ds, _stream()))
+    check(_l.load().bsclip_attn_bwd(_p(qkv), ld_qkv, _p(dctx), ld_ctx, _p(lse), B, S, heads, _p(key_bias),
+                                    float(scale), _p(dqkv), ld_d, dp, ds, _stream()))
 
 
 def im2col_patch16(image, cols):

@@ -12,8 +12,8 @@
 //     next MFMA's operand", cdna_hip_programming.md 3): P^T never goes through LDS.
 // The operand that must be k-strided for that second product (V^T, Q^T, dO^T, K^T) is read TRANSPOSED out of the same
 // row-major image with ds_read_b64_tr_b16 -- no second LDS copy, no 2-byte scatter writes.
-// Backward runs two phases in one launch: query-owner waves produce dQ (delta = dO . O from the forward's hi+lo output),
-// then key-owner waves produce dK/dV, so nothing is accumulated across waves (no atomics, bitwise reproducible).
+// Backward runs two phases in one launch: query-owner waves produce delta = rowsum(P.dP) and dQ, then key-owner waves
+// produce dK/dV, so nothing is accumulated across waves (no atomics, bitwise reproducible).
 #include <math.h>
 
 #include "common.h"
@@ -104,8 +104,7 @@ __device__ __forceinline__ void store_dt(const f32x16 (&acc)[2], float mul, bf16
 template <int NB>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S,
                                                                    int heads, const float* __restrict__ key_bias,
-                                                                   float scale, bf16_t* __restrict__ ctx,
-                                                                   bf16_t* __restrict__ ctx_lo, int ld_ctx,
+                                                                   float scale, bf16_t* __restrict__ ctx, int ld_ctx,
                                                                    float* __restrict__ lse, DropCfg drop) {
     constexpr int SP = NB * 32;
     __shared__ __attribute__((aligned(16))) char smem[2 * SP * ROWB + SP * 4];
@@ -188,18 +187,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
 
         const int q = q0 + (lane & 31);
         if (q < S) {
-            const float inv = 1.0f / sum;
-            store_dt(o, inv, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
-            if (ctx_lo) {  // O = hi + lo to ~2^-17: lets backward form delta = dO . O without recomputing P . dP
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = o[dt][r] * inv;
-                        o[dt][r] = v - bf2f(f2bf(v));
-                    }
-                store_dt(o, 1.0f, ctx_lo + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
-            }
+            store_dt(o, 1.0f / sum, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
             if (h == 0) lse[((size_t)b * heads + hd) * S + q] = m + __logf(sum);
         }
     }
@@ -207,8 +195,6 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
 
 template <int NB>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
-                                                                   const bf16_t* __restrict__ ctx,
-                                                                   const bf16_t* __restrict__ ctx_lo,
                                                                    const bf16_t* __restrict__ dctx, int ld_ctx,
                                                                    const float* __restrict__ lse, int S, int heads,
                                                                    const float* __restrict__ key_bias, float scale,
@@ -240,32 +226,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
         sLse[k] = (k < S) ? lse[((size_t)b * heads + hd) * S + k] : INFINITY;  // padded queries -> p = 0
     }
-    // delta[q] = sum_key P[q,key] dP[q,key] = dO[q] . O[q].  O comes from the forward as hi + lo (two bf16, ~2^-17
-    // relative): with the plain bf16 output the softmax-backward cancellation is lost whenever a head's values are nearly
-    // equal across keys (Q-LoRA gradient error 1.4 on the 12-layer ViT); recomputing P . dP costs a third pass of exps.
-    {
-        const bf16_t* ob = ctx + (size_t)b * S * ld_ctx + hd * 64;
-        const bf16_t* olb = ctx_lo + (size_t)b * S * ld_ctx + hd * 64;
-        for (int it = tid; it < SP * 8; it += ATT_WAVES * 64) {  // 8 consecutive lanes share a row
-            const int row = it >> 3, c = it & 7;
-            float d = 0.f;
-            if (row < S) {
-                const u32x4 a = *reinterpret_cast<const u32x4*>(dob + (size_t)row * ld_ctx + c * 8);
-                const u32x4 o = *reinterpret_cast<const u32x4*>(ob + (size_t)row * ld_ctx + c * 8);
-                const u32x4 l = *reinterpret_cast<const u32x4*>(olb + (size_t)row * ld_ctx + c * 8);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    d += bf2f(a[i] & 0xffff) * (bf2f(o[i] & 0xffff) + bf2f(l[i] & 0xffff)) +
-                         bf2f(a[i] >> 16) * (bf2f(o[i] >> 16) + bf2f(l[i] >> 16));
-            }
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
-            if (c == 0) sDelta[row] = d;
-        }
-    }
     __syncthreads();
-    // ---------------- phase 1: a wave owns queries [q0, q0+32): dQ ----------------
+    // ---------------- phase 1: a wave owns queries [q0, q0+32): delta, then dQ ----------------
 #pragma unroll 1
     for (int blk = wave; blk < NB; blk += ATT_WAVES) {
         asm volatile("" ::: "memory");  // LDS tiles are loop-invariant: stop LICM from hoisting ~100 fragment registers
@@ -279,8 +241,33 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         }
         const float lse_q = sLse[q0 + (lane & 31)];
         const unsigned dbase = (bh * S + (unsigned)qrow) * S;  // dropout index of (q, key 0)
-        const float delta_q = sDelta[q0 + (lane & 31)];
-        // dS^T = P^T (dP^T - delta) * scale;  dQ^T += K^T dS^T
+        // pass 1: delta_q = sum_key P[q,key] dP[q,key], from the SAME P and dP the gradient uses, so that
+        // sum_key dS[q,key] = 0 holds to f32 rounding (delta from the bf16-rounded O does not: it loses the cancellation
+        // whenever the values of a head are nearly equal across keys).  P is recomputed in pass 2 rather than kept:
+        // 7 tiles x 16 registers would push the kernel past 256 VGPRs.
+        float dpart = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < NB; ++kt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);     // S^T[key, q]
+                dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);  // dP^T[key, q]
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float dpm = dp[4 * g + i];
+                    if (drop.thr16) dpm *= drop_factor(drop, dbase + 32 * kt + 8 * g + 4 * h + i);
+                    dpart += __expf(s[4 * g + i] * scale + b4[i] - lse_q) * dpm;
+                }
+            }
+        }
+        const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
+        if (h == 0) sDelta[q0 + (lane & 31)] = delta_q;
+        // pass 2: dS^T = P^T (dP^T - delta) * scale;  dQ^T += K^T dS^T
         f32x16 dq[2] = {zero16(), zero16()};
 #pragma unroll 1
         for (int kt = 0; kt < NB; ++kt) {
@@ -379,12 +366,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
     case NBV:                                                                                                   \
         hipLaunchKernelGGL((attn_fwd_kernel<NBV>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,                 \
                            static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,                  \
-                           static_cast<bf16_t*>(ctx), static_cast<bf16_t*>(ctx_lo), ld_ctx, lse, drop);         \
+                           static_cast<bf16_t*>(ctx), ld_ctx, lse, drop);                                       \
         break;
 
 extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias,
-                               float scale, void* ctx, void* ctx_lo, int ld_ctx, float* lse, float dropout_p,
-                               uint32_t dropout_seed, void* stream) {
+                               float scale, void* ctx, int ld_ctx, float* lse, float dropout_p, uint32_t dropout_seed,
+                               void* stream) {
     BSCLIP_REQUIRE(qkv && ctx && lse, "bsclip_attn_fwd: null pointer");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_fwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_ctx >= heads * 64 && ld_ctx % 4 == 0,
@@ -403,16 +390,14 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
 #define ATTN_BWD_CASE(NBV)                                                                                       \
     case NBV:                                                                                                    \
         hipLaunchKernelGGL((attn_bwd_kernel<NBV>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,                  \
-                           static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(ctx),             \
-                           static_cast<const bf16_t*>(ctx_lo), static_cast<const bf16_t*>(dctx), ld_ctx, lse, S,  \
-                           heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop);                   \
+                           static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx,    \
+                           lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop);           \
         break;
 
-extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* ctx, const void* ctx_lo, const void* dctx,
-                               int ld_ctx, const float* lse, int B, int S, int heads, const float* key_bias,
-                               float scale, void* dqkv, int ld_dqkv, float dropout_p, uint32_t dropout_seed,
-                               void* stream) {
-    BSCLIP_REQUIRE(qkv && ctx && ctx_lo && dctx && lse && dqkv, "bsclip_attn_bwd: null pointer");
+extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
+                               int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
+                               float dropout_p, uint32_t dropout_seed, void* stream) {
+    BSCLIP_REQUIRE(qkv && dctx && lse && dqkv, "bsclip_attn_bwd: null pointer");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_bwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_dqkv >= 3 * heads * 64 && ld_dqkv % 4 == 0 &&
                        ld_ctx >= heads * 64 && ld_ctx % 8 == 0,

@@ -93,15 +93,13 @@ int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats
  * key_bias f32 [B,S] additive per key (HF extended attention mask, language_encoder.py:89) or NULL;
  * lse f32 [B, heads, S] = log-sum-exp of the scaled scores (saved for backward).  head_dim is 64.
  * dropout_p > 0: HF attention_probs_dropout_prob on the normalised probabilities (mask of (b,head,q,k) regenerated in bwd).
- * ctx_lo (bf16, same layout as ctx, nullable in fwd): low half of the output, O = ctx + ctx_lo to ~2^-17, so that bwd can form
- * delta = dO . O accurately (the bf16-rounded ctx alone loses the softmax-backward cancellation).
- * S <= 224.  bwd recomputes P from qkv + lse and writes dqkv in the same layout as qkv. */
+ * S <= 224.  bwd recomputes P from qkv + lse, forms delta = rowsum(P . dP) in f32 from the same tiles (not from the
+ * bf16-rounded ctx: that loses the softmax-backward cancellation), and writes dqkv in the same layout as qkv. */
 int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale,
-                    void* ctx, void* ctx_lo, int ld_ctx, float* lse, float dropout_p, uint32_t dropout_seed,
-                    void* stream);
-int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* ctx, const void* ctx_lo, const void* dctx, int ld_ctx,
-                    const float* lse, int B, int S, int heads, const float* key_bias, float scale, void* dqkv,
-                    int ld_dqkv, float dropout_p, uint32_t dropout_seed, void* stream);
+                    void* ctx, int ld_ctx, float* lse, float dropout_p, uint32_t dropout_seed, void* stream);
+int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
+                    int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, float dropout_p,
+                    uint32_t dropout_seed, void* stream);
 
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column

@@ -193,8 +193,7 @@ def test_attention_fwd_bwd(ops, B, S, heads, masked):
     scale = 0.125
     ctx = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
     lse = torch.empty(B, heads, S, device="cuda")
-    ctx_lo = torch.empty_like(ctx)
-    ops.attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=bias, ctx_lo=ctx_lo)
+    ops.attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=bias)
     qf = qkv.float().reshape(B, S, 3 * H).requires_grad_(True)
     ref, ref_lse = _attn_ref(qf, B, S, heads, scale, bias)
     assert rel_err(ctx.float(), ref) < 6e-3          # P is rounded to bf16 before P.V
@@ -203,7 +202,7 @@ def test_attention_fwd_bwd(ops, B, S, heads, masked):
     dctx = dev(rnd(B * S, H, seed=2).bfloat16())
     (gq,) = torch.autograd.grad(ref, qf, dctx.float())
     dqkv = torch.full((B * S, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
-    ops.attn_bwd(qkv, ctx, ctx_lo, dctx, lse, B, S, heads, scale, dqkv, key_bias=bias)
+    ops.attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=bias)
     gq = gq.reshape(B * S, 3 * H)
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
         assert rel_err(dqkv[:, sl].float(), gq[:, sl]) < 1e-2, name
