@@ -217,6 +217,7 @@ class ViTEngine(EncoderEngineBase):
         ws["dout_t"] = torch.zeros(self.out_dim, Bp, dtype=BF16, device=dev)
         ws["clsn_t"] = torch.zeros(H, Bp, dtype=BF16, device=dev)
         ws["dclsn"] = z(B, H)
+        ws["dz_c"], ws["dh_c"], ws["st_c"] = z(B, FF), z(B, H), z(B, 2, dt=F32)   # last-block token-0 path
         self.ws = ws
         return ws
 
@@ -269,13 +270,29 @@ class ViTEngine(EncoderEngineBase):
         dxb.zero_()
         ops.layernorm_bwd(x[-1].view(B, S * H)[:, :H], ws["st_f"], self.ln_f[0], 0, g_gemm=ws["dclsn"],
                           dx_f32=dx.view(B, S * H)[:, :H], dx_bf16=dxb.view(B, S * H)[:, :H])
-        for l in range(len(self.layers) - 1, -1, -1):
+        L = len(self.layers)
+        for l in range(L - 1, -1, -1):
             lay = self.layers[l]
-            ops.gemm(dxb, lay.w_fc2_t, ws["dz"], EPI_DGELU_BF16, aux=ws["z"][l])
-            ops.gemm(ws["dz"], lay.w_fc1_t, ws["dh"], EPI_BF16)
-            ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh"], dx_f32=dx,
-                              dx_bf16=dxb)
-            ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
+            if l == L - 1:
+                # Only token 0 of the last block feeds the head, so the residual gradient entering this block is zero
+                # on the other 196 rows of every image: its MLP backward, LN2 backward and proj backward run on the B
+                # token-0 rows only (row stride S*H), 1/197 of the work.
+                FF = self.FF
+                dxb_c = dxb.view(B, S * H)[:, :H]
+                ops.gemm(dxb_c, lay.w_fc2_t, ws["dz_c"], EPI_DGELU_BF16, aux=ws["z"][l].view(B, S * FF)[:, :FF])
+                ops.gemm(ws["dz_c"], lay.w_fc1_t, ws["dh_c"], EPI_BF16)
+                ws["st_c"].copy_(ws["st2"][l].view(B, S, 2)[:, 0])
+                dx_c = dx.view(B, S * H)[:, :H]
+                ops.layernorm_bwd(x[2 * l + 1].view(B, S * H)[:, :H], ws["st_c"], lay.ln2[0], 0, g_resid=dx_c,
+                                  g_gemm=ws["dh_c"], dx_f32=dx_c, dx_bf16=dxb_c)
+                ws["dctx"].zero_()
+                ops.gemm(dxb_c, lay.w_proj_t, ws["dctx"].view(B, S * H)[:, :H], EPI_BF16)
+            else:
+                ops.gemm(dxb, lay.w_fc2_t, ws["dz"], EPI_DGELU_BF16, aux=ws["z"][l])
+                ops.gemm(ws["dz"], lay.w_fc1_t, ws["dh"], EPI_BF16)
+                ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh"], dx_f32=dx,
+                                  dx_bf16=dxb)
+                ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
             ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"])
             lb = self.lora_b(l)
             if lb is not None:
