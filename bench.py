@@ -34,6 +34,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md chip table)
 GFLOP_PER_PAIR_ID = 118.3   # fwd 58.8 + LoRA-regime bwd
 GFLOP_PER_TRIPLE_IDT = 119.3
+FC1_TRAFFIC_BYTES_B256 = 901.4e6  # measured, see time_dominant_gemm
 
 
 class _Cfg:
@@ -111,7 +112,13 @@ def time_dominant_gemm(B, device, reps=4):
     flops = sum(2.0 * M * N * K * c for M, N, K, c in shapes) / launches
     achieved = flops / (mean_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            # bytes per launch at the L2's memory side, FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, averaged over the
+            # same launch mix; collected offline with rocprofv3 --pmc (profiles/r01_c_fc1_traffic.txt), valid for B=256
+            "traffic": FC1_TRAFFIC_BYTES_B256 if B == 256 else None,
+            "traffic_note": "rocprofv3 PMC, profiles/r01_c_fc1_traffic.txt; algorithmic bytes per launch: "
+                            "%.1f MB (A + W + 2 outputs)" % (sum((M * K + N * K + 2 * M * N) * 2.0 * c for M, N, K, c in shapes)
+                                                             / launches / 1e6),
             "kernel": "gemm_nt_pp_kernel<2 = EPI_GELU_BF16, true> (fc1 + bias + GELU; 25 launches per step)",
             "launch_mix_MNK_count": [list(x) for x in shapes],
             "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "avg_launch_ms": round(mean_ms, 4)}

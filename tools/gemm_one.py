@@ -6,9 +6,9 @@ import torch
 from bioscanclip.hip import ops
 from bioscanclip.hip.lib import EPI_BF16, EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32
 SH = {"qkv": (2304, 832, EPI_BF16), "dfc1": (768, 3072, EPI_BF16), "fc1": (3072, 768, EPI_GELU_BF16),
-      "dfc2": (3072, 768, EPI_DGELU_BF16), "fc2": (768, 3072, EPI_RESID_F32), "proj": (768, 768, EPI_RESID_F32)}
-M = 256 * 197
+      "dfc2": (3072, 768, EPI_DGELU_BF16), "fc1_dna": (3072, 768, EPI_GELU_BF16), "tr_dna": (768, 768, EPI_GELU_BF16), "fc2": (768, 3072, EPI_RESID_F32), "proj": (768, 768, EPI_RESID_F32)}
 for name in sys.argv[1:]:
+    M = 256 * 133 if name.endswith("_dna") else 256 * 197
     N, K, epi = SH[name]
     a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.03).bfloat16()
     bias = torch.randn(N, device="cuda")
