@@ -116,6 +116,7 @@ class EncoderEngineBase:
             params += [mods[0].weight, mods[1].weight, mods[2].weight, mods[3].weight]
         self._extra_index = len(params)
         params += list(extra_params)
+        ops.init_tables()
         self.flat = FlatParams(params, dev)
         self._zero_a = torch.zeros(8, H, dtype=F32, device=dev)
 

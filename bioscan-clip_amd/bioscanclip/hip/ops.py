@@ -71,6 +71,18 @@ def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, 
     return out
 
 
+_tables_ready = False
+
+
+def init_tables():
+    """One-time device tables, synchronised, so GEMMs launched from several streams all see them."""
+    global _tables_ready
+    if not _tables_ready:
+        check(_l.load().bsclip_init_tables(_stream()))
+        torch.cuda.synchronize()
+        _tables_ready = True
+
+
 def set_gemm_tile(tile):
     check(_l.load().bsclip_gemm_set_tile(tile))
 

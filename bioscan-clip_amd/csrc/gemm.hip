@@ -218,6 +218,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const bf
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// GELU table for the 256x256 kernel's epilogue
+// ---------------------------------------------------------------------------------------------------------------
+// The two-output GELU epilogue (gelu and gelu' of 128 values per lane) was VALU-bound: ~24 instructions per value with
+// exp + rcp, 12 us per tile with no MFMA to hide behind.  Phi and phi are smooth, so a 1/64-spaced table on [-8, 8] with
+// linear interpolation is exact to 7e-6 (h^2/8 max|f''|), far inside the bf16 rounding of the outputs, and costs
+// ~9 VALU + one 16-B LDS read per value.  Entry i (x_i = -8 + i/64): {Phi(x_i), Phi(x_{i+1}) - Phi(x_i), phi(x_i),
+// phi(x_{i+1}) - phi(x_i)}, computed once on the device in f64 with erf().
+constexpr int GELU_LUT_N = 1024;                       // intervals
+constexpr int GELU_LUT_BYTES = (GELU_LUT_N + 1) * 16;  // 16400
+__device__ f32x4 g_gelu_lut[GELU_LUT_N + 1];
+
+__global__ void gelu_lut_init_kernel() {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > GELU_LUT_N) return;
+    auto Phi = [](double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)); };
+    auto phi = [](double x) { return 0.39894228040143267794 * exp(-0.5 * x * x); };
+    const double x0 = -8.0 + i / 64.0, x1 = x0 + 1.0 / 64.0;
+    g_gelu_lut[i] = f32x4{(float)Phi(x0), (float)(Phi(x1) - Phi(x0)), (float)phi(x0), (float)(phi(x1) - phi(x0))};
+}
+
+__device__ __forceinline__ void gelu_lut(const char* lut, float x, float& gl, float& dg) {
+    const float t = fmaf(__builtin_amdgcn_fmed3f(x, -8.0f, 7.998f), 64.0f, 512.0f);  // [0, 1024)
+    const float fi = floorf(t);
+    const float fr = t - fi;
+    const f32x4 e = *reinterpret_cast<const f32x4*>(lut + (int)fi * 16);
+    const float cdf = fmaf(fr, e[1], e[0]);
+    const float pdf = fmaf(fr, e[3], e[2]);
+    gl = x * cdf;
+    dg = fmaf(x, pdf, cdf);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 256x256 ping-pong kernel
 // ---------------------------------------------------------------------------------------------------------------
 // LDS: 2 buffer sets x {A[256][64], B[256][64]} bf16 = 128 KiB; a "half" is 128 rows (16 KiB) = 16 wave-instructions of
@@ -238,7 +270,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                                                           const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                           int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
     constexpr int SET = 65536, HALF = 16384, B_OFF = 32768;
-    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 528];  // 132 KiB: main loop uses 128 KiB; epilogue slabs 2x64x1040 (f32) or 4x64x528 (bf16 x2)
+    // main loop 128 KiB; epilogue slabs 2x64x1040 (f32) or 4x64x528 (bf16 x2) = 132 KiB, + 16 KiB GELU table
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 528 + (EPI == BSCLIP_EPI_GELU_BF16 ? GELU_LUT_BYTES : 0)];
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
@@ -413,6 +446,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     char* slab = smem + g * (64 * SF);
     const int wq = wave & 3;
     __syncthreads();  // every wave is past its last fragment read
+    const char* lut = smem + 4 * 64 * SB;
+    if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {  // 16 KiB table, L2-resident, behind the slabs
+        for (int i = tid; i <= GELU_LUT_N; i += 512)
+            *reinterpret_cast<f32x4*>(smem + 4 * 64 * SB + i * 16) = g_gelu_lut[i];
+        __syncthreads();
+    }
     char* slab2 = smem + 2 * 64 * SB + g * (64 * SB);  // second bf16 slab (GELU: gelu' side band)
     auto stage_bf16 = [&](int mi) {
 #pragma unroll
@@ -427,7 +466,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                     if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
                         float gl[4], dg[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) gelu_both(v[q], gl[q], dg[q]);
+                        for (int q = 0; q < 4; ++q) gelu_lut(lut, v[q], gl[q], dg[q]);
                         o.x = pack_bf2(gl[0], gl[1]);
                         o.y = pack_bf2(gl[2], gl[3]);
                         uint2 d;
@@ -545,9 +584,15 @@ void launch_cfg(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
                        lda, B, ldb, C, ldc, M, N, K, tiles_n, e);
 }
 
+bool g_lut_ready = false;
+
 template <int EPI, bool HB>
 void launch_pp(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
                const EpiArgs& e, hipStream_t s) {
+    if (EPI == BSCLIP_EPI_GELU_BF16 && !g_lut_ready) {  // once per process, stream-ordered ahead of the first consumer
+        hipLaunchKernelGGL(gelu_lut_init_kernel, dim3(ceil_div(GELU_LUT_N + 1, 256)), dim3(256), 0, s);
+        g_lut_ready = true;
+    }
     const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
     hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, HB>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, lda, B, ldb, C, ldc, M,
                        N, K, tiles_n, e);
@@ -620,6 +665,16 @@ extern "C" int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, 
         default: BSCLIP_REQUIRE(false, "bsclip_gemm_diag: epilogue %d has no diagnostic build", epilogue);
     }
     BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+// Fills the device-side GELU table.  Stream-ordered; the GEMM entry point also does this lazily on its own stream, so a
+// single-stream caller never needs it -- callers that launch GEMMs on several streams call it once up front.
+extern "C" int bsclip_init_tables(void* stream) {
+    hipLaunchKernelGGL(gelu_lut_init_kernel, dim3(ceil_div(GELU_LUT_N + 1, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream));
+    BSCLIP_LAUNCH_CHECK();
+    g_lut_ready = true;
     return BSCLIP_OK;
 }
 

@@ -58,6 +58,9 @@ typedef struct bsclip_epi_args {
 } bsclip_epi_args;
 int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      int epilogue, const bsclip_epi_args* args, void* stream);
+/* one-time device tables (GELU Phi/phi table of the 256x256 kernel's epilogue).  bsclip_gemm_bf16 fills them lazily on
+ * its own stream; call this once (and synchronise) before launching GEMMs from several streams. */
+int bsclip_init_tables(void* stream);
 /* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 */
 int bsclip_gemm_set_tile(int tile);
 /* diagnostic build of the 256x256 kernel: per-workgroup phase stamps (start, prologue, K loop, end) in 100 MHz ticks,
