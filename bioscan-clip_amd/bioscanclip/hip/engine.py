@@ -11,8 +11,6 @@ Everything numerical happens in ``libbsclip_hip.so``; this file decides *which* 
     sub-layer, bf16 GEMM operands, attention LSE, LN statistics).
 Reference call shapes: SURVEY.md 2.3 (K1-K15), 3.2; semantics App. A.1-A.3.
 """
-import math
-
 import torch
 
 from . import ops
@@ -75,13 +73,6 @@ class FlatParams:
         for p, o, good in zip(self.params, self.offsets, ok):
             if not good:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
-
-
-class _LoraPack:
-    """Per-layer frozen QKV weight in K-augmented form + views of the trainable LoRA tensors."""
-
-    def __init__(self, H):
-        self.H = H
 
 
 def _pack_qkv(w_qkv, b_qkv, H, dev):
@@ -393,6 +384,7 @@ class BertEngine(EncoderEngineBase):
         ws["z"] = [z(M, FF) for _ in range(L)]
         ws["act"] = z(M, FF)
         ws["key_bias"] = None
+        ws["kb_buf"] = z(B, S, dt=F32)
         # backward temporaries
         ws["ds"] = z(M, H, dt=F32)
         ws["dsb"] = z(M, H)
@@ -447,7 +439,8 @@ class BertEngine(EncoderEngineBase):
         key_bias = None
         if attention_mask is not None:
             # HF extended mask (App. A.3): (1 - m) * finfo.min added to the scores of padded keys.
-            key_bias = ((1.0 - attention_mask.to(F32)) * torch.finfo(F32).min).contiguous()
+            key_bias = ws["kb_buf"]
+            ops.mask_to_bias(attention_mask.to(torch.int64).contiguous(), key_bias)
         ws["key_bias"] = key_bias
         ops.bert_embed(input_ids.contiguous(), None if token_type_ids is None else token_type_ids.contiguous(),
                        self.word, self.posw, self.typew, ws["emb"])

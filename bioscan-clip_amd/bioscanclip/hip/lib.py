@@ -35,6 +35,7 @@ SIGNATURES = {
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, F, U, P]),
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, F, U, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, P]),
+    "bsclip_mask_to_bias": (I, [P, I, P, P]),
     "bsclip_vit_cls_rows": (I, [P, P, P, I, I, I, P]),
     "bsclip_bert_embed": (I, [P, P, I, I, I, P, I, P, P, P, P]),
     "bsclip_softmax_meanpool_fwd": (I, [P, I, I, I, P, P, P]),

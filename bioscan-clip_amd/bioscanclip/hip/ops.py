@@ -173,6 +173,12 @@ def im2col_patch16(image, cols):
     check(_l.load().bsclip_im2col_patch16(_p(image), B, _p(cols), _stream()))
 
 
+def mask_to_bias(mask, bias):
+    _req(mask.dtype == torch.int64 and mask.is_contiguous() and bias.dtype == F32 and bias.is_contiguous()
+         and bias.numel() >= mask.numel(), "mask_to_bias: int64 mask, f32 bias")
+    check(_l.load().bsclip_mask_to_bias(_p(mask), mask.numel(), _p(bias), _stream()))
+
+
 def vit_cls_rows(x, cls_token, pos_embed, B, S, H):
     _req(x.dtype == F32 and x.is_contiguous() and x.numel() >= B * S * H, "x f32 [B*S,H]")
     _req(cls_token.numel() == H and pos_embed.numel() >= H and cls_token.dtype == F32 and pos_embed.dtype == F32, "cls/pos")

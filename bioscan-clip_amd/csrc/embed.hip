@@ -110,7 +110,21 @@ __global__ void waug_set_lora_kernel(bf16_t* __restrict__ w, int ld_w, int H, co
     *reinterpret_cast<uint2*>(dst) = o;
 }
 
+// HF "extended attention mask": (1 - m) * finfo(float32).min, added to the scores of padded keys
+__global__ void mask_to_bias_kernel(const int64_t* __restrict__ mask, int n, float* __restrict__ bias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bias[i] = mask[i] ? 0.0f : -3.4028234663852886e38f;
+}
+
 }  // namespace
+
+extern "C" int bsclip_mask_to_bias(const int64_t* mask, int n, float* bias, void* stream) {
+    BSCLIP_REQUIRE(mask && bias && n > 0, "bsclip_mask_to_bias: bad args");
+    hipLaunchKernelGGL(mask_to_bias_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), mask,
+                       n, bias);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
 
 extern "C" int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16, void* stream) {
     BSCLIP_REQUIRE(image && cols_bf16 && B > 0, "bsclip_im2col_patch16: bad args");

@@ -12,11 +12,6 @@ namespace {
 
 constexpr int LN_BLOCK = 256;  // 4 waves = 4 rows in flight per workgroup
 
-template <int H>
-struct RowVec {
-    static constexpr int NV = H / 256;  // float4 chunks per lane (768 -> 3, 512 -> 2)
-};
-
 // Reduce 8 per-lane partial sums over the 64 lanes with 10 shuffles (halving the live set each step).
 // On return every lane holds, in its return value, the total of index r = ((lane>>5)&1)*4 + ((lane>>4)&1)*2 + ((lane>>3)&1).
 __device__ __forceinline__ float reduce8(float (&p)[8], int lane) {

@@ -109,6 +109,8 @@ int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, c
  * order (c, ky, kx) = conv weight.flatten(1).  cls rows: x[b*197] = cls + pos[0].
  * bert_embed: word[id] + pos[t] + type[tt] -> f32 [B*S, H] (HF BertEmbeddings before LayerNorm). */
 int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16, void* stream);
+/* HF extended attention mask (BertModel, language_encoder.py:89): bias[i] = mask[i] ? 0 : finfo(f32).min */
+int bsclip_mask_to_bias(const int64_t* mask, int n, float* bias, void* stream);
 int bsclip_vit_cls_rows(float* x, const float* cls_token, const float* pos_embed, int B, int S, int H, void* stream);
 int bsclip_bert_embed(const int64_t* ids, const int64_t* type_ids, int B, int S, int H, const float* word,
                       int vocab, const float* pos, const float* type, float* out, void* stream);
