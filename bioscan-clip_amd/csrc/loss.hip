@@ -10,8 +10,8 @@
 // with K = 3*768, relative error ~2^-16.  Per directed pair: pass 1 = logits GEMM + row reduction (LSE, sum T.G);
 // pass 2 (only the rank's own rows) = logits GEMM + dL/dG tile kernel (written directly in split form) + gradient
 // GEMM accumulated in f32.  The second F.normalize (loss_func.py:43-44) and its Jacobian are applied here.
-// Round-1 note: logits are materialised per pair in the caller's workspace (N x N f32); the single-pass LDS-staged
-// variant is the planned replacement.
+// Logits are formed in row slabs of <= 1024 rows ([slab x N] f32 in the caller's workspace), reduced (pass 1) or turned
+// into dL/dG (pass 2) and discarded: the N x N matrix never exists in HBM.
 #include <math.h>
 
 #include "common.h"
@@ -93,14 +93,15 @@ __global__ void loss_count_kernel(const int64_t* __restrict__ labels, int N, flo
 }
 
 // One wave per row i < N of G (cosines, ld = Np): LSE_i of s*G over j < N, and contrib_i = cnt_i*LSE_i - sum_j T_ij s G_ij
-__global__ __launch_bounds__(256) void loss_row_reduce_kernel(const float* __restrict__ G, int N, int Np, float s,
-                                                               const int64_t* __restrict__ labels,
+__global__ __launch_bounds__(256) void loss_row_reduce_kernel(const float* __restrict__ G, int row0, int nrows, int N,
+                                                               int Np, float s, const int64_t* __restrict__ labels,
                                                                const float* __restrict__ cnt, float* __restrict__ lse,
                                                                float* __restrict__ contrib) {
     const int lane = threadIdx.x & 63;
-    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (row >= N) return;
-    const float* g = G + (size_t)row * Np;
+    const int r = (blockIdx.x * 256 + threadIdx.x) >> 6;  // row inside the slab
+    if (r >= nrows) return;
+    const int row = row0 + r;
+    const float* g = G + (size_t)r * Np;
     const int64_t li = labels[row];
     float m = -INFINITY;
     for (int j = lane; j < N; j += 64) m = fmaxf(m, g[j]);
@@ -162,23 +163,26 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict
 
 inline int64_t align4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
+constexpr int SLAB_ROWS = 1024;  // logits are formed [SLAB_ROWS x N] at a time: the N x N matrix never exists in HBM
+
 struct Layout {
-    int Np;
+    int Np, slab;
     int64_t zn, inv, PA, PB, PBt, G, W, lse, contrib, cnt, dacc, total;
 };
 
 Layout make_layout(int N, int nmod, int D) {
     Layout L;
     L.Np = (N + 127) / 128 * 128;
-    const int64_t Np = L.Np;
+    L.slab = L.Np < SLAB_ROWS ? L.Np : SLAB_ROWS;
+    const int64_t Np = L.Np, SL = L.slab;
     int64_t o = 0;
     L.zn = o;      o += align4((int64_t)nmod * Np * D);
     L.inv = o;     o += align4((int64_t)nmod * Np);
     L.PA = o;      o += align4((int64_t)nmod * Np * 3 * D / 2);
     L.PB = o;      o += align4((int64_t)nmod * Np * 3 * D / 2);
     L.PBt = o;     o += align4((int64_t)nmod * D * 3 * Np / 2);
-    L.G = o;       o += align4(Np * Np);
-    L.W = o;       o += align4(Np * 3 * Np / 2);
+    L.G = o;       o += align4(SL * Np);
+    L.W = o;       o += align4(SL * 3 * Np / 2);
     L.lse = o;     o += align4((int64_t)nmod * nmod * Np);
     L.contrib = o; o += align4((int64_t)nmod * nmod * Np);
     L.cnt = o;     o += align4(Np);
@@ -238,12 +242,15 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
     for (int a = 0; a < nmod; ++a)
         for (int b = 0; b < nmod; ++b) {
             if (a == b) continue;
-            int rc = bsclip_gemm_bf16(PA + a * opA, 3 * D, PB + b * opA, 3 * D, G, Np, N, Np, 3 * D, BSCLIP_EPI_F32,
-                                      nullptr, stream);
-            if (rc) return rc;
             const int slot = a * nmod + b;
-            hipLaunchKernelGGL(loss_row_reduce_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, s, G, N, Np, scale, labels,
-                               cnt, lse + (size_t)slot * Np, contrib + (size_t)slot * Np);
+            for (int r0 = 0; r0 < N; r0 += L.slab) {
+                const int nr = N - r0 < L.slab ? N - r0 : L.slab;
+                int rc = bsclip_gemm_bf16(PA + a * opA + (size_t)r0 * 3 * D, 3 * D, PB + b * opA, 3 * D, G, Np, nr, Np,
+                                          3 * D, BSCLIP_EPI_F32, nullptr, stream);
+                if (rc) return rc;
+                hipLaunchKernelGGL(loss_row_reduce_kernel, dim3(ceil_div(nr, 4)), dim3(256), 0, s, G, r0, nr, N, Np, scale,
+                                   labels, cnt, lse + (size_t)slot * Np, contrib + (size_t)slot * Np);
+            }
         }
     // contrib slots of (a,a) are unused: zero them so the final sum can run over the whole array
     for (int a = 0; a < nmod; ++a)
@@ -263,20 +270,25 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
         bool first = true;
         for (int b = 0; b < nmod; ++b) {
             if (a == b) continue;
-            int rc = bsclip_gemm_bf16(PA + a * opA + (size_t)row0 * 3 * D, 3 * D, PB + b * opA, 3 * D, G, Np, n_local,
-                                      Np, 3 * D, BSCLIP_EPI_F32, nullptr, stream);
-            if (rc) return rc;
-            long tot = (long)n_local * Np;
-            long blocks = (tot + 255) / 256;
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(loss_w_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, N, Np, row0, n_local, scale,
-                               coef, labels, cnt, lse + (size_t)(a * nmod + b) * Np, lse + (size_t)(b * nmod + a) * Np, W);
-            bsclip_epi_args ea{};
-            ea.resid = da;
-            ea.ld_resid = D;
-            rc = bsclip_gemm_bf16(W, 3 * Np, PBt + b * opT, 3 * Np, da, D, n_local, D, 3 * Np,
-                                  first ? BSCLIP_EPI_F32 : BSCLIP_EPI_RESID_F32, first ? nullptr : &ea, stream);
-            if (rc) return rc;
+            for (int l0 = 0; l0 < n_local; l0 += L.slab) {  // row slabs of the rank's own rows
+                const int nr = n_local - l0 < L.slab ? n_local - l0 : L.slab;
+                int rc = bsclip_gemm_bf16(PA + a * opA + (size_t)(row0 + l0) * 3 * D, 3 * D, PB + b * opA, 3 * D, G, Np,
+                                          nr, Np, 3 * D, BSCLIP_EPI_F32, nullptr, stream);
+                if (rc) return rc;
+                long tot = (long)nr * Np;
+                long blocks = (tot + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL(loss_w_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, N, Np, row0 + l0, nr, scale,
+                                   coef, labels, cnt, lse + (size_t)(a * nmod + b) * Np, lse + (size_t)(b * nmod + a) * Np,
+                                   W);
+                float* dar = da + (size_t)l0 * D;
+                bsclip_epi_args ea{};
+                ea.resid = dar;
+                ea.ld_resid = D;
+                rc = bsclip_gemm_bf16(W, 3 * Np, PBt + b * opT, 3 * Np, dar, D, nr, D, 3 * Np,
+                                      first ? BSCLIP_EPI_F32 : BSCLIP_EPI_RESID_F32, first ? nullptr : &ea, stream);
+                if (rc) return rc;
+            }
             first = false;
         }
         // Jacobian of the in-loss F.normalize: dz = (g - zn (zn . g)) / ||z||

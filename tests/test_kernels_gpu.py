@@ -279,7 +279,7 @@ def test_meanpool_and_l2norm(ops):
 
 # ------------------------------------------------------------------------------------------------------ loss
 @pytest.mark.parametrize("N,nmod,dup", [(8, 2, False), (8, 3, True), (64, 3, True), (200, 2, True), (256, 2, False),
-                                        (256, 3, True)])
+                                        (256, 3, True), (1300, 2, True)])
 def test_infonce_vs_oracle(ops, N, nmod, dup):
     from oracle import refcpu
     zs = [rnd(N, 768, seed=10 + i) for i in range(nmod)]
