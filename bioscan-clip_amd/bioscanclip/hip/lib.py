@@ -47,6 +47,8 @@ SIGNATURES = {
     "bsclip_l2norm_bwd": (I, [P, P, P, I, I, P, P]),
     "bsclip_infonce_workspace_floats": (L, [I, I]),
     "bsclip_infonce_fwd_bwd": (I, [POINTER(c_void_p), I, P, I, I, F, I, I, P, POINTER(c_void_p), P, P]),
+    "bsclip_topk_ip_workspace_floats": (L, [I, I, I]),
+    "bsclip_topk_ip": (I, [P, I, P, I, I, I, P, P, P, P]),
     "bsclip_lora_grad_workspace_floats": (L, [I]),
     "bsclip_lora_grad": (I, [P, I, P, I, I, I, P, P, P, P, P, P, P]),
     "bsclip_colsum": (I, [P, I, I, I, I, P, P]),

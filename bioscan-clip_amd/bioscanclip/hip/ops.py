@@ -279,6 +279,20 @@ def infonce_fwd_bwd(zs, labels, scale, loss_out, dzs=None, row0=0, n_local=None,
                                            _p(workspace), _stream()))
 
 
+def topk_ip(queries, keys, k):
+    """Top-k inner products of L2-normalised rows: returns (scores f32 [Q,k], indices int64 [Q,k]) on the GPU."""
+    Q, D = queries.shape
+    K = keys.shape[0]
+    _req(queries.dtype == F32 and keys.dtype == F32 and queries.is_contiguous() and keys.is_contiguous()
+         and keys.shape[1] == D and queries.is_cuda and keys.is_cuda, "topk_ip: contiguous f32 GPU [Q,D], [K,D]")
+    _req(1 <= k <= min(16, K) and D % 64 == 0, "topk_ip: 1 <= k <= 16, D % 64 == 0")
+    ws = torch.empty(_l.load().bsclip_topk_ip_workspace_floats(Q, K, D), dtype=F32, device=queries.device)
+    scores = torch.empty(Q, k, dtype=F32, device=queries.device)
+    idx = torch.empty(Q, k, dtype=torch.int64, device=queries.device)
+    check(_l.load().bsclip_topk_ip(_p(queries), Q, _p(keys), K, D, k, _p(scores), _p(idx), _p(ws), _stream()))
+    return scores, idx
+
+
 _LG_WS = {}
 
 

@@ -145,6 +145,14 @@ int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int64_t* label
                            int row0, int n_local, float* loss_out, float* const* dz, float* workspace,
                            void* stream);
 
+/* ---- retrieval --------------------------------------------------------------------------------
+ * make_prediction (scripts/inference_and_eval.py:414-445): faiss IndexFlatIP over L2-normalised keys f32 [K, D], searched
+ * with L2-normalised queries f32 [Q, D] (sklearn normalize, :416-417).  Outputs the top k (<= 16) inner products per query in
+ * descending order (ties: lower key index first): scores_out f32 [Q, k], idx_out int64 [Q, k].  D % 64 == 0. */
+int64_t bsclip_topk_ip_workspace_floats(int Q, int K, int D);
+int bsclip_topk_ip(const float* queries, int Q, const float* keys, int K, int D, int k, float* scores_out,
+                   int64_t* idx_out, float* workspace, void* stream);
+
 /* ---- LoRA / head gradients -------------------------------------------------------------------------------------
  * lora_grad: for one layer, from dqkv (bf16 [M, ld_dqkv], q cols [0,H), v cols [2H,3H)) and the augmented LN
  *   output h (bf16 [M, ld_h]: cols [0,H) = y, [H,H+4) = t_q, [H+4,H+8) = t_v):

@@ -193,13 +193,41 @@ def gen_trajectory(steps=10, B=8, with_text=False, seed=31):
             "weight_seed": seed, "batch_seed0": 100}
 
 
+def gen_retrieval():
+    """The reference's own top_k_micro_accuracy / top_k_macro_accuracy (scripts/inference_and_eval.py:448-511) and
+    convert_label_dict_to_list_of_dict (eval_epoch.py:26-38) on seeded inputs.  make_prediction itself needs faiss, which is
+    not installed, so the search half is not pinned here (see oracle/retrieval.py)."""
+    import importlib.util
+    for name in ["hydra", "omegaconf", "matplotlib", "matplotlib.pyplot", "PIL", "sklearn.metrics"]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = MagicMock()
+    spec = importlib.util.spec_from_file_location("ref_inference_and_eval", "/root/reference/scripts/inference_and_eval.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    from bioscanclip.epoch.eval_epoch import convert_label_dict_to_list_of_dict  # reference
+    from oracle.retrieval import retrieval_case
+    keys_label, gt_list, indices, pred_list = retrieval_case()
+    k_list = [1, 3, 5]
+    micro = ref.top_k_micro_accuracy(pred_list, gt_list, k_list=k_list)
+    macro, per_class = ref.top_k_macro_accuracy(pred_list, gt_list, k_list=k_list)
+    batch = {lv: [d[lv] for d in gt_list[:6]] for lv in ["order", "family", "genus", "species"]}
+    return {"case": {"seed": 5, "n_keys": 60, "n_query": 40, "max_k": 5}, "k_list": k_list,
+            "micro": {str(k): v for k, v in micro.items()}, "macro": {str(k): v for k, v in macro.items()},
+            "per_class": {str(k): v for k, v in per_class.items()},
+            "label_batch": batch, "label_list": convert_label_dict_to_list_of_dict(batch)}
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     meta = {"torch": torch.__version__, "transformers": transformers.__version__,
             "reference": "bioscan-ml/bioscan-clip @ 2024-10-24 (/root/reference)"}
     jobs = {"loss": gen_loss, "encoders": gen_encoders, "state_dict_keys": gen_state_dict_keys,
-            "trajectory_id": gen_trajectory, "trajectory_idt": lambda: gen_trajectory(steps=3, B=4, with_text=True, seed=32)}
+            "trajectory_id": gen_trajectory, "retrieval": gen_retrieval,
+            "trajectory_idt": lambda: gen_trajectory(steps=3, B=4, with_text=True, seed=32)}
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

@@ -1,6 +1,10 @@
 """Pins ``oracle/refcpu.py`` against fixtures produced by the IMPORTED REFERENCE (oracle/gen_golden.py).
 
 CPU only.  If these fail the oracle is wrong and no GPU parity claim means anything."""
+import json
+import os
+import sys
+
 import pytest
 import torch
 
@@ -84,3 +88,50 @@ def test_vit_encoder_matches_reference_wrapper(depth):
     assert set(keys) == set(g["grads"].keys())
     for k in keys:
         check_summary(k, sd[k].grad, g["grads"][k], 5e-5)
+
+
+# ---- retrieval row -----------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _int_keys(d):
+    return {int(k): v for k, v in d.items()}
+
+
+def test_retrieval_accuracy_matches_reference():
+    """oracle + host accuracy helpers == the reference's own functions (fixture from oracle/gen_golden.py)."""
+    from oracle import retrieval as R
+    sys.path.insert(0, os.path.join(ROOT, "bioscan-clip_amd", "scripts"))
+    import inference_and_eval as host
+    from bioscanclip.epoch.eval_epoch import convert_label_dict_to_list_of_dict
+    with open(os.path.join(GOLD, "retrieval.json")) as f:
+        gold = json.load(f)
+    keys_label, gt_list, indices, pred_list = R.retrieval_case(**gold["case"])
+    k_list = gold["k_list"]
+    for impl in (R, host):
+        assert impl.top_k_micro_accuracy(pred_list, gt_list, k_list=k_list) == _int_keys(gold["micro"])
+        macro, per_class = impl.top_k_macro_accuracy(pred_list, gt_list, k_list=k_list)
+        assert macro == _int_keys(gold["macro"])
+        assert per_class == _int_keys(gold["per_class"])
+    assert convert_label_dict_to_list_of_dict(gold["label_batch"]) == gold["label_list"]
+    with pytest.raises(TypeError):  # the reference has no default k_list here either
+        host.top_k_micro_accuracy(pred_list, gt_list)
+
+
+def test_retrieval_oracle_normalize_is_sklearn():
+    """oracle.l2_normalize_rows == sklearn.preprocessing.normalize (the dependency the reference calls, :416-417)."""
+    import numpy as np
+    from sklearn.preprocessing import normalize
+    from oracle import retrieval as R
+    rng = np.random.RandomState(0)
+    x = rng.randn(37, 768)
+    x[5] = 0.0
+    assert np.array_equal(R.l2_normalize_rows(x), normalize(x, norm="l2", axis=1).astype(np.float32))
+    sims, idx = R.topk_ip(x[:9], x, 5)
+    assert (idx[:5, 0] == np.arange(5)).all() and np.allclose(sims[:5, 0], 1.0, atol=1e-6)
+    assert (np.diff(sims, axis=1) <= 0).all()
+    # ties go to the lower index
+    keys = np.concatenate([x[:4], x[:4]])
+    _, idx2 = R.topk_ip(x[:4], keys, 2)
+    assert (idx2 == np.stack([np.arange(4), np.arange(4) + 4], 1)).all()
