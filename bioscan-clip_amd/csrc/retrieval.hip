@@ -56,14 +56,85 @@ __global__ __launch_bounds__(256) void normalize_split4_kernel(const float* __re
     }
 }
 
+constexpr int TOPK_CAND = 256;  // candidate slots per row in LDS before the exact fallback scan takes over
+
+// descending (value, then lower index first) insertion into a per-lane sorted list held in registers
+template <int MAXK>
+__device__ __forceinline__ void topk_insert(float (&v)[MAXK], int (&ix)[MAXK], float x, int xi) {
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        const bool better = x > v[j] || (x == v[j] && xi < ix[j]);
+        const float tv = better ? v[j] : x;
+        const int ti = better ? ix[j] : xi;
+        v[j] = better ? x : v[j];
+        ix[j] = better ? xi : ix[j];
+        x = tv;
+        xi = ti;
+    }
+}
+
+// One wave per query row.  Pass 1: every lane takes the maximum of its strided share (16-B loads, 4 in flight); the
+// k-th largest of the 64 lane maxima is a threshold T with at least k elements >= T, so the row's top k all pass it.
+// Pass 2: re-scan (the slab is L2 / Infinity-Cache resident) and compact the few elements >= T into LDS.  Pass 3: exact
+// top-k of the candidates -- per-lane sorted lists in registers, then k rounds of a wavefront arg-max.  A row with more
+// than TOPK_CAND candidates (many equal scores) falls back to inserting every element, which is exact for any input.
 template <int MAXK>
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ scores, int ld, int nrows, int K, int k,
                                                          float* __restrict__ out_s, int64_t* __restrict__ out_i,
                                                          int out_ld) {
-    const int lane = threadIdx.x & 63;
-    const int r = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (r >= nrows) return;
+    __shared__ float cand_v[4][TOPK_CAND];
+    __shared__ int cand_i[4][TOPK_CAND];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + w;
+    if (r >= nrows) return;  // whole waves leave; no block-wide barrier below
     const float* row = scores + (size_t)r * ld;
+    const int K4 = (K + 3) & ~3;  // ld is a multiple of 128, so the last 16-B chunk is readable; columns >= K are masked
+
+    float m = -INFINITY;
+    for (int c0 = lane * 4; c0 < K4; c0 += 1024) {
+        f32x4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 256;
+            x[u] = c < K4 ? *reinterpret_cast<const f32x4*>(row + c) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + u * 256 + e < K) m = fmaxf(m, x[u][e]);
+    }
+    // T = k-th largest lane maximum (rank by value, ties by lane)
+    int rank = 0;
+    for (int j = 0; j < 64; ++j) {
+        const float o = __shfl(m, j, 64);
+        rank += (o > m || (o == m && j < lane)) ? 1 : 0;
+    }
+    const int kk = k < 64 ? k : 64;
+    const unsigned long long sel = __ballot(rank == kk - 1);
+    const float T = __shfl(m, __ffsll((long long)sel) - 1, 64);
+
+    int count = 0;  // wave-uniform: every lane runs every trip and takes part in every ballot
+    for (int base = 0; base < K4 && count <= TOPK_CAND; base += 256) {
+        const int c0 = base + lane * 4;
+        f32x4 x = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (c0 < K4) x = *reinterpret_cast<const f32x4*>(row + c0);
+        bool hit = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hit |= (c0 + e < K) && x[e] >= T;
+        if (__ballot(hit) == 0ull) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool h = (c0 + e < K) && x[e] >= T;
+            const unsigned long long b = __ballot(h);
+            const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
+            if (h && pos < TOPK_CAND) {
+                cand_v[w][pos] = x[e];
+                cand_i[w][pos] = c0 + e;
+            }
+            count += __popcll(b);
+        }
+    }
     float v[MAXK];
     int ix[MAXK];
 #pragma unroll
@@ -71,22 +142,12 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
         v[j] = -INFINITY;
         ix[j] = 0x7fffffff;
     }
-    for (int c = lane; c < K; c += 64) {
-        float x = row[c];
-        int xi = c;
-        // insertion into the descending list (ties keep the earlier = lower index ahead)
-#pragma unroll
-        for (int j = 0; j < MAXK; ++j) {
-            const bool better = x > v[j];
-            const float tv = better ? v[j] : x;
-            const int ti = better ? ix[j] : xi;
-            v[j] = better ? x : v[j];
-            ix[j] = better ? xi : ix[j];
-            x = tv;
-            xi = ti;
-        }
+    if (count <= TOPK_CAND) {
+        __builtin_amdgcn_wave_barrier();
+        for (int c = lane; c < count; c += 64) topk_insert<MAXK>(v, ix, cand_v[w][c], cand_i[w][c]);
+    } else {
+        for (int c = lane; c < K; c += 64) topk_insert<MAXK>(v, ix, row[c], c);
     }
-    // merge: k rounds of wavefront arg-max over the list heads
     for (int o = 0; o < k; ++o) {
         float bv = v[0];
         int bi = ix[0];

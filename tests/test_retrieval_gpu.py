@@ -66,6 +66,23 @@ def test_topk_ties_zero_rows_and_self_retrieval():
     _check(np.concatenate([base[:5], np.zeros((1, 768), np.float32)]), keys, 5)  # a zero query scores 0 everywhere
 
 
+def test_topk_many_equal_scores_takes_exact_fallback():
+    """All keys identical: every score ties, the candidate buffer overflows and the full-insertion path must still return
+    the k lowest indices in order; then a row where 300 keys tie for first place ahead of distinct ones."""
+    from bioscanclip.hip import ops
+    rng = np.random.RandomState(4)
+    one = rng.randn(1, 768).astype(np.float32)
+    q = rng.randn(9, 768).astype(np.float32)
+    keys = np.repeat(one, 700, axis=0)
+    _, idx = ops.topk_ip(torch.from_numpy(q).cuda(), torch.from_numpy(keys).cuda(), 16)
+    assert (idx.cpu().numpy() == np.arange(16)[None]).all()
+    keys2 = rng.randn(900, 768).astype(np.float32)
+    keys2[5:900:3] = q[0] * 2.0  # 299 keys parallel to query 0
+    _check(q, keys2, 5)
+    _, idx2 = ops.topk_ip(torch.from_numpy(q[:1].copy()).cuda(), torch.from_numpy(keys2).cuda(), 5)
+    assert idx2.cpu().numpy().tolist() == [[5, 8, 11, 14, 17]]
+
+
 def test_topk_full_size_self_retrieval():
     """BIOSCAN-1M key-set size (21 118 keys): size-independent property -- every key retrieves itself first with
     similarity 1, and the scores are sorted."""

@@ -42,17 +42,31 @@ def run(M, N, K, epi, iters):
             torch.cuda.synchronize()
             res.setdefault(tile, []).append(e0.elapsed_time(e1) / iters)
     ops.set_gemm_tile(0)
+    # library reference (hipBLASLt / rocBLAS through torch): plain bf16 NT GEMM without any epilogue
+    o2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    wt = w.t()
+    lib = []
+    for rnd in range(3):
+        torch.matmul(a, wt, out=o2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            torch.matmul(a, wt, out=o2)
+        e1.record()
+        torch.cuda.synchronize()
+        lib.append(e0.elapsed_time(e1) / iters)
+    res["lib"] = lib
     return {t: min(v) for t, v in res.items()}
 
 
-tot = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0, "best": 0.0}
+tot = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0, "best": 0.0, "lib": 0.0}
 for name, M, N, K, epi in SHAPES:
     r = run(M, N, K, epi, 10)
     fl = 2.0 * M * N * K
-    best = min(r, key=r.get)
+    best = min((t for t in r if t != 'lib'), key=r.get)
     print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}  " + "  ".join(
-        f"t{t}: {r[t]*1e3:7.1f}us {fl/r[t]/1e9:7.1f}TF" for t in (1, 2, 3, 4)) + f"   best=t{best}", flush=True)
-    for t in (1, 2, 3, 4):
+        f"t{t}: {r[t]*1e3:7.1f}us {fl/r[t]/1e9:7.1f}TF" for t in (1, 2, 3, 4, "lib")) + f"   best=t{best}", flush=True)
+    for t in (1, 2, 3, 4, 'lib'):
         tot[t] += r[t]
     tot["best"] += r[best]
 print("sum per layer (ms):", {k: round(v, 3) for k, v in tot.items()})
