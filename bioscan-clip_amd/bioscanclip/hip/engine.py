@@ -523,6 +523,27 @@ class BertEngine(EncoderEngineBase):
 
 
 # ====================================================================================== autograd integration
+_PARENT_STREAM = []  # stack: the stream a tower's side stream was forked from (set by SimpleCLIP.forward)
+
+
+class forked_from:
+    """``with forked_from(stream):`` -- encoders run inside (on a side stream) make ``stream`` wait for their BACKWARD.
+
+    Autograd replays a node on the stream of its forward and, when backward() returns, only joins the streams on which it
+    accumulated leaf gradients itself.  The encoder nodes write their parameter gradients from inside the kernels (they
+    return ``None`` for the parameters), so autograd would not join the tower streams: the optimizer on the main stream
+    could read the flat gradient buffer while the last blocks' backward kernels are still running."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        _PARENT_STREAM.append(self.stream)
+
+    def __exit__(self, *exc):
+        _PARENT_STREAM.pop()
+
+
 class _EncoderFn(torch.autograd.Function):
     """One autograd node per encoder: forward and backward are whole kernel sequences.  Trainable parameters are
     passed only so autograd records the node; their gradients are accumulated in place by the kernels (into the
@@ -531,11 +552,16 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, fwd_args, *params):
         ctx.engine = engine
+        ctx.parent = _PARENT_STREAM[-1] if _PARENT_STREAM else None
         return engine.forward(*fwd_args)
 
     @staticmethod
     def backward(ctx, dout):
         ctx.engine.backward(dout.contiguous())
+        here = torch.cuda.current_stream()
+        for parent in {ctx.parent, torch.cuda.default_stream(here.device)}:
+            if parent is not None and parent != here:
+                parent.wait_stream(here)  # gradients are complete before anything queued on the parent afterwards
         return (None, None) + (None,) * len(ctx.engine.flat.params)
 
 

@@ -297,7 +297,8 @@ _LG_WS = {}
 
 
 def _lora_grad_workspace(H, device):
-    key = (H, str(device))
+    # one workspace per launching stream: the towers run concurrently on their own streams (SimpleCLIP.forward)
+    key = (H, str(device), torch.cuda.current_stream().cuda_stream)
     ws = _LG_WS.get(key)
     if ws is None:
         ws = torch.empty(_l.load().bsclip_lora_grad_workspace_floats(H), dtype=F32, device=device)

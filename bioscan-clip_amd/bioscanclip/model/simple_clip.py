@@ -8,6 +8,7 @@ and raises.
 import torch
 import torch.nn as nn
 
+from bioscanclip.hip.engine import forked_from
 from bioscanclip.hip.functional import l2_normalize
 from bioscanclip.model.arch import vit_base_patch16_224
 from bioscanclip.model.dna_encoder import Freeze_DNA_Encoder, LoRA_barcode_bert, load_pre_trained_bioscan_bert
@@ -56,7 +57,7 @@ class SimpleCLIP(nn.Module):
             if use_streams and not isinstance(enc, Freeze_DNA_Encoder):
                 side = _tower_stream(k, cur.device)
                 side.wait_stream(cur)
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(side), forked_from(cur):
                     y = l2_normalize(enc(x))
                 y.record_stream(cur)
                 outs[k] = (y, side)

@@ -41,6 +41,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
     return __builtin_bit_cast(bf16x8, u);
 }
 
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr int ROWB = 128;  // bytes per row of a row-major [rows][64] bf16 tile
 constexpr int ATT_WAVES = 4;  // waves per workgroup; wave w owns 32-row blocks w, w+4, ...
 
@@ -101,7 +102,20 @@ __device__ __forceinline__ void store_dt(const f32x16 (&acc)[2], float mul, bf16
         }
 }
 
-template <int NB>
+// keep-factors (0 or 1/(1-p)) of the 4 consecutive keys idx .. idx+3 of one query row (idx % 4 == 0): two hashes
+__device__ __forceinline__ f32x4 keep4(const DropCfg& d, unsigned idx) {
+    const unsigned b0 = drop_pair_bits(d, idx), b1 = drop_pair_bits(d, idx + 2);
+    f32x4 k;
+    k[0] = (b0 & 0xffffU) >= d.thr16 ? d.scale : 0.f;
+    k[1] = (b0 >> 16) >= d.thr16 ? d.scale : 0.f;
+    k[2] = (b1 & 0xffffU) >= d.thr16 ? d.scale : 0.f;
+    k[3] = (b1 >> 16) >= d.thr16 ? d.scale : 0.f;
+    return k;
+}
+// Dropout element index of P[q, key] for head-instance bh: ((bh * S + q) * SP + key), SP = padded length (multiple of
+// 32), so a lane's 4 consecutive keys share two hash pairs.
+
+template <int NB, bool DROP>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S,
                                                                    int heads, const float* __restrict__ key_bias,
                                                                    float scale, bf16_t* __restrict__ ctx, int ld_ctx,
@@ -122,9 +136,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
 
     stage_tile<SP>(kb, ld, S, sK, tid);
     stage_tile<SP>(vb, ld, S, sV, tid);
+    // scores are kept in the log2 domain: s2 = (q.k * scale + bias) * log2(e), so p = exp2(s2 - m2) is one v_exp_f32
     for (int k = tid; k < SP; k += ATT_WAVES * 64)
-        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
+        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] * LOG2E : 0.f) : -INFINITY;
     __syncthreads();
+    const float scale2 = scale * LOG2E;
 
 #pragma unroll 1
     for (int blk = wave; blk < NB; blk += ATT_WAVES) {
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float s = acc[4 * g + i] * scale + bias[i];
+                    const float s = fmaf(acc[4 * g + i], scale2, bias[i]);
                     acc[4 * g + i] = s;
                     m = fmaxf(m, s);
                 }
@@ -161,17 +177,21 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
         for (int kt = 0; kt < NB; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __expf(p[kt][r] - m);
+                const float e = __builtin_amdgcn_exp2f(p[kt][r] - m);
                 p[kt][r] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 32, 64);
-        if (drop.thr16) {  // HF: dropout on the normalised probabilities (the row sum above is taken before it)
-            const unsigned base = ((unsigned)(b * heads + hd) * S + (unsigned)qrow) * S;
+        if constexpr (DROP) {  // HF: dropout on the normalised probabilities (the row sum above is taken before it)
+            const unsigned base = ((unsigned)(b * heads + hd) * S + (unsigned)qrow) * SP + 4 * h;
 #pragma unroll
             for (int kt = 0; kt < NB; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[kt][r] *= drop_factor(drop, base + 32 * kt + acc_row(r, h));
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 k4 = keep4(drop, base + 32 * kt + 8 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) p[kt][4 * g + i] *= k4[i];
+                }
         }
 
         // O^T[d, query] = sum_key V^T[d, key] P^T[key, query]
@@ -188,12 +208,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
         const int q = q0 + (lane & 31);
         if (q < S) {
             store_dt(o, 1.0f / sum, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
-            if (h == 0) lse[((size_t)b * heads + hd) * S + q] = m + __logf(sum);
+            if (h == 0) lse[((size_t)b * heads + hd) * S + q] = (m + __log2f(sum)) * LN2;  // natural-log LSE
         }
     }
 }
 
-template <int NB>
+template <int NB, bool DROP>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
                                                                    const bf16_t* __restrict__ dctx, int ld_ctx,
                                                                    const float* __restrict__ lse, int S, int heads,
@@ -223,10 +243,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
     stage_tile<SP>(kb, ld, S, sR0, tid);
     stage_tile<SP>(vb, ld, S, sR1, tid);
     for (int k = tid; k < SP; k += ATT_WAVES * 64) {
-        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
-        sLse[k] = (k < S) ? lse[((size_t)b * heads + hd) * S + k] : INFINITY;  // padded queries -> p = 0
+        // log2 domain: p = exp2(q.k * scale2 + bias2 - lse2)
+        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] * LOG2E : 0.f) : -INFINITY;
+        sLse[k] = (k < S) ? lse[((size_t)b * heads + hd) * S + k] * LOG2E : INFINITY;  // padded queries -> p = 0
     }
     __syncthreads();
+    const float scale2 = scale * LOG2E;
     // ---------------- phase 1: a wave owns queries [q0, q0+32): delta, then dQ ----------------
 #pragma unroll 1
     for (int blk = wave; blk < NB; blk += ATT_WAVES) {
@@ -239,8 +261,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             qf[ks] = frag_global(qb, ld, qrow, ks, lane);
             dof[ks] = frag_global(dob, ld_ctx, qrow, ks, lane);
         }
-        const float lse_q = sLse[q0 + (lane & 31)];
-        const unsigned dbase = (bh * S + (unsigned)qrow) * S;  // dropout index of (q, key 0)
+        const float nlse_q = -sLse[q0 + (lane & 31)];
+        const unsigned dbase = (bh * S + (unsigned)qrow) * SP + 4 * h;  // dropout index of (q, key 4h)
         // pass 1: delta_q = sum_key P[q,key] dP[q,key], from the SAME P and dP the gradient uses, so that
         // sum_key dS[q,key] = 0 holds to f32 rounding (delta from the bf16-rounded O does not: it loses the cancellation
         // whenever the values of a head are nearly equal across keys).  P is recomputed in pass 2 rather than kept:
@@ -257,17 +279,19 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+                f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float dpm = dp[4 * g + i];
-                    if (drop.thr16) dpm *= drop_factor(drop, dbase + 32 * kt + 8 * g + 4 * h + i);
-                    dpart += __expf(s[4 * g + i] * scale + b4[i] - lse_q) * dpm;
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, b4[i]) + nlse_q);
+                    if constexpr (DROP) dpart = fmaf(pr, dp[4 * g + i] * k4[i], dpart);
+                    else dpart = fmaf(pr, dp[4 * g + i], dpart);
                 }
             }
         }
         const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
         if (h == 0) sDelta[q0 + (lane & 31)] = delta_q;
-        // pass 2: dS^T = P^T (dP^T - delta) * scale;  dQ^T += K^T dS^T
+        // pass 2: dS^T = P^T (dP^T - delta);  dQ^T += K^T dS^T, scaled once at the end
         f32x16 dq[2] = {zero16(), zero16()};
 #pragma unroll 1
         for (int kt = 0; kt < NB; ++kt) {
@@ -280,12 +304,13 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+                f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float pr = __expf(s[4 * g + i] * scale + b4[i] - lse_q);
-                    float dpm = dp[4 * g + i];
-                    if (drop.thr16) dpm *= drop_factor(drop, dbase + 32 * kt + 8 * g + 4 * h + i);
-                    dp[4 * g + i] = pr * (dpm - delta_q) * scale;
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, b4[i]) + nlse_q);
+                    if constexpr (DROP) dp[4 * g + i] = pr * (dp[4 * g + i] * k4[i] - delta_q);
+                    else dp[4 * g + i] = pr * (dp[4 * g + i] - delta_q);
                 }
             }
 #pragma unroll
@@ -297,7 +322,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             }
         }
         const int q = q0 + (lane & 31);
-        if (q < S) store_dt(dq, 1.0f, dqb + (size_t)q * ld_d, lane);
+        if (q < S) store_dt(dq, scale, dqb + (size_t)q * ld_d, lane);
     }
     __syncthreads();
     // ---------------- phase 2 staging: Q, dO row-major ----------------
@@ -332,14 +357,16 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + 32 * qt + 8 * g + 4 * h);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float pr = __expf(s[4 * g + i] * scale + bias_k - l4[i]);
-                    float keep = 1.0f;
-                    if (drop.thr16) {
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, bias_k) - l4[i]);
+                    if constexpr (DROP) {
                         const int q = min(32 * qt + 8 * g + 4 * h + i, S - 1);
-                        keep = drop_factor(drop, (bh * S + (unsigned)q) * S + (unsigned)krow);
+                        const float keep = drop_factor(drop, (bh * S + (unsigned)q) * SP + (unsigned)krow);
+                        s[4 * g + i] = pr * keep;                               // dropped P (feeds dV)
+                        dp[4 * g + i] = pr * (dp[4 * g + i] * keep - d4[i]);    // dS (scale applied to dK at the end)
+                    } else {
+                        s[4 * g + i] = pr;
+                        dp[4 * g + i] = pr * (dp[4 * g + i] - d4[i]);
                     }
-                    s[4 * g + i] = pr * keep;                                        // dropped P (feeds dV)
-                    dp[4 * g + i] = pr * (dp[4 * g + i] * keep - d4[i]) * scale;     // dS (scaled)
                 }
             }
 #pragma unroll
@@ -354,7 +381,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         }
         const int key = k0 + (lane & 31);
         if (key < S) {
-            store_dt(dk, 1.0f, dqb + (size_t)key * ld_d + HW, lane);
+            store_dt(dk, scale, dqb + (size_t)key * ld_d + HW, lane);
             store_dt(dv, 1.0f, dqb + (size_t)key * ld_d + 2 * HW, lane);
         }
     }
@@ -364,9 +391,14 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
 
 #define ATTN_FWD_CASE(NBV)                                                                                      \
     case NBV:                                                                                                   \
-        hipLaunchKernelGGL((attn_fwd_kernel<NBV>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,                 \
-                           static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,                  \
-                           static_cast<bf16_t*>(ctx), ld_ctx, lse, drop);                                       \
+        if (drop.thr16)                                                                                         \
+            hipLaunchKernelGGL((attn_fwd_kernel<NBV, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
+                               static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,              \
+                               static_cast<bf16_t*>(ctx), ld_ctx, lse, drop);                                   \
+        else                                                                                                    \
+            hipLaunchKernelGGL((attn_fwd_kernel<NBV, false>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,      \
+                               static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,              \
+                               static_cast<bf16_t*>(ctx), ld_ctx, lse, drop);                                   \
         break;
 
 extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias,
@@ -389,9 +421,14 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
 
 #define ATTN_BWD_CASE(NBV)                                                                                       \
     case NBV:                                                                                                    \
-        hipLaunchKernelGGL((attn_bwd_kernel<NBV>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,                  \
-                           static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx,    \
-                           lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop);           \
+        if (drop.thr16)                                                                                          \
+            hipLaunchKernelGGL((attn_bwd_kernel<NBV, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,        \
+                               static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, \
+                               lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop);       \
+        else                                                                                                     \
+            hipLaunchKernelGGL((attn_bwd_kernel<NBV, false>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
+                               static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, \
+                               lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop);       \
         break;
 
 extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,

@@ -203,19 +203,35 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __re
     }
 }
 
-// out[n] += sum over a stripe of rows; thread per column
+// out[n] += sum_r g[r, n].  One workgroup per 32 columns: 8 row groups x 32 columns, every thread sums rows rg, rg+8, ...
+// (4 loads in flight), the 8 partials are added in a fixed order through LDS.  No atomics: bitwise reproducible.
 template <bool BF16>
-__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ g, int ld, int M, int N, int rows_per,
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ g, int ld, int M, int N,
                                                       float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        if constexpr (BF16) s += bf2f(static_cast<const bf16_t*>(g)[(size_t)r * ld + n]);
-        else s += static_cast<const float*>(g)[(size_t)r * ld + n];
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        auto at = [&](int r) -> float {
+            if constexpr (BF16) return bf2f(static_cast<const bf16_t*>(g)[(size_t)r * ld + n]);
+            else return static_cast<const float*>(g)[(size_t)r * ld + n];
+        };
+        int r = rg;
+        for (; r + 24 < M; r += 32) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += at(r + 8 * u);
+        }
+        for (; r < M; r += 8) s[0] += at(r);
     }
-    atomicAdd(out + n, s);
+    part[rg][c] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][c];
+        out[n] += t;
+    }
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -276,13 +292,10 @@ extern "C" int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, in
 
 extern "C" int bsclip_colsum(const void* g, int ld_g, int g_is_bf16, int M, int N, float* out, void* stream) {
     BSCLIP_REQUIRE(g && out && M > 0 && N > 0 && ld_g >= N, "bsclip_colsum: bad args");
-    int stripes = ceil_div(M, 256);
-    if (stripes > 256) stripes = 256;
-    const int rows_per = ceil_div(M, stripes);
-    const dim3 grid(ceil_div(N, 256), ceil_div(M, rows_per));
+    const dim3 grid(ceil_div(N, 32));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (g_is_bf16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, s, g, ld_g, M, N, rows_per, out);
-    else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, s, g, ld_g, M, N, rows_per, out);
+    if (g_is_bf16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, s, g, ld_g, M, N, out);
+    else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, s, g, ld_g, M, N, out);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }
