@@ -101,6 +101,14 @@ def allreduce_grads(model_or_buffers, group=None):
 def broadcast_trainable(model_or_buffers, src=0, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    bufs = model_or_buffers if isinstance(model_or_buffers, (list, tuple)) else [f.data for f in flat_buffers(model_or_buffers)]
+    if isinstance(model_or_buffers, (list, tuple)):
+        bufs = list(model_or_buffers)
+    else:
+        # one broadcast per flat trainable buffer once the engines exist; trainable tensors not (yet) re-homed into a flat
+        # buffer -- i.e. before the first forward, when the reference broadcasts (train_cl.py:149) -- go one by one
+        flats = flat_buffers(model_or_buffers)
+        covered = {id(p) for f in flats for p in f.params}
+        bufs = [f.data for f in flats] + [p.data for p in model_or_buffers.parameters()
+                                          if p.requires_grad and id(p) not in covered]
     for b in bufs:
         dist.broadcast(b, src=src, group=group)

@@ -565,13 +565,24 @@ class _EncoderFn(torch.autograd.Function):
         return (None, None) + (None,) * len(ctx.engine.flat.params)
 
 
+def _frozen_signature(module, eng):
+    """(storage address, in-place version) of every tensor the engine packed into its own bf16 layouts.  An in-place
+    ``load_state_dict`` / ``copy_`` after the engine was built bumps the version, ``.to()`` moves the storage."""
+    mine = {id(p) for p in eng.flat.params}
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers())
+                 if id(t) not in mine)
+
+
 def _engine_for(module, build):
     eng = getattr(module, "_engine", None)
+    if eng is not None and eng.flat.valid() and _frozen_signature(module, eng) != eng._frozen_sig:
+        eng = None  # frozen weights were overwritten (checkpoint loaded after the first forward): repack
     if eng is None or not eng.flat.valid():
         if not torch.cuda.is_available():
             raise RuntimeError("bioscanclip needs a ROCm GPU: all arithmetic runs in libbsclip_hip.so "
                                "(there is no CPU/torch fallback)")
         eng = build()
+        eng._frozen_sig = _frozen_signature(module, eng)
         module._engine = eng
     return eng
 

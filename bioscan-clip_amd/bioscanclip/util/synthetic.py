@@ -33,3 +33,20 @@ class SyntheticCLIPLoader:
             label = torch.arange(B) + (s * self.world + self.rank) * B
             pid = [f"SYN{self.rank}_{s}_{i}" for i in range(B)]
             yield pid, image, dna, ids, tt, am, label
+
+
+class SyntheticEvalLoader(SyntheticCLIPLoader):
+    """Evaluation-split stand-in: same tensors, but ``label`` is the dict of taxonomy-name lists that the reference's
+    evaluation loaders collate (``for_training=False``, dataset.py:267-275) and ``convert_label_dict_to_list_of_dict`` expects."""
+
+    def __init__(self, batch_size, steps, with_text=False, seed=4321):
+        super().__init__(batch_size, steps, with_text=with_text, seed=seed)
+
+    def __iter__(self):
+        for s, (pid, image, dna, ids, tt, am, label) in enumerate(super().__iter__()):
+            if ids is None:  # the reference's 7-tuple always carries token tensors
+                ids = tt = am = torch.zeros(len(pid), 20, dtype=torch.int64)
+            sp = [int(v) % 11 for v in label]
+            lab = {"order": [f"o{v % 2}" for v in sp], "family": [f"f{v % 3}" for v in sp],
+                   "genus": [f"g{v % 5}" for v in sp], "species": [f"s{v}" for v in sp]}
+            yield pid, image, dna, ids, tt, am, lab

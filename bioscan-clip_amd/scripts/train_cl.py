@@ -33,7 +33,7 @@ from bioscanclip.hip.optim import FusedAdamW  # noqa: E402
 from bioscanclip.model.loss_func import ContrastiveLoss, GlobalBatchContrastiveLoss  # noqa: E402
 from bioscanclip.model.simple_clip import load_clip_model  # noqa: E402
 from bioscanclip.util.config import load_config  # noqa: E402
-from bioscanclip.util.synthetic import SyntheticCLIPLoader  # noqa: E402
+from bioscanclip.util.synthetic import SyntheticCLIPLoader, SyntheticEvalLoader  # noqa: E402
 
 
 def print_when_rank_zero(message, rank=0):
@@ -42,9 +42,25 @@ def print_when_rank_zero(message, rank=0):
 
 
 def broadcast_model(model, rank):
-    """Reference train_cl.py:29-31, as one broadcast per flat trainable buffer (frozen weights are identical by
-    construction: same checkpoint / same seed on every rank)."""
+    """Reference train_cl.py:29-31, restricted to the trainable tensors (frozen weights are identical by construction:
+    same checkpoint / same seed on every rank): per tensor before the first forward, one broadcast per flat buffer after."""
     hdist.broadcast_trainable(model, src=0)
+
+
+def eval_phase(model, device, all_keys_dataloader, seen_val_dataloader, unseen_val_dataloader, k_list, args,
+               species_to_drop=None, rank=None, for_open_clip=False):
+    """Reference train_cl.py:70-83: features of the key / seen / unseen splits on the HIP encoders, then the retrieval
+    accuracy table (``bsclip_topk_ip`` in place of faiss)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    from inference_and_eval import get_features_and_label, inference_and_print_result
+    keys_dict = get_features_and_label(all_keys_dataloader, model, device, for_key_set=True, for_open_clip=for_open_clip)
+    seen_val_dict = get_features_and_label(seen_val_dataloader, model, device, for_open_clip=for_open_clip)
+    unseen_val_dict = get_features_and_label(unseen_val_dataloader, model, device, for_open_clip=for_open_clip)
+    acc_dict, _, pred_dict = inference_and_print_result(keys_dict, seen_val_dict, unseen_val_dict, args=args,
+                                                        small_species_list=None, k_list=k_list)
+    return acc_dict, pred_dict
 
 
 def ddp_setup(rank: int, world_size: int, port):
@@ -130,22 +146,34 @@ def main_process(rank: int, world_size: int, args):
                                    str(getattr(mc, "model_output_name", "bioscan_clip_hip")), stamp)
         os.makedirs(folder_path, exist_ok=True)
 
-    broadcast_done = False
+    broadcast_model(model, rank)  # before the first step, like the reference (train_cl.py:149)
+    eval_loaders = None
+    if getattr(args, "synthetic_eval", False):
+        n_eval = int(getattr(args, "synthetic_eval_batches", 2))
+        eval_loaders = [SyntheticEvalLoader(min(int(mc.batch_size), 24), n_eval, with_text=with_text, seed=s_)
+                        for s_ in (7001, 7002, 7003)]  # keys, seen, unseen
+    k_list = [1, 3, 5]
+    best_epoch, best_overall_acc = None, None
     losses = []
     for epoch in range(mc.epochs):
-        if not broadcast_done and world_size > 1:
-            # engines (and their flat buffers) are created by the first forward; run one step's worth of setup first
-            model.train()
         losses.append(train_epoch(getattr(args, "activate_wandb", False), mc.epochs, epoch, pre_train_dataloader, model,
                                   optimizer, criterion, device, rank=rank, scheduler=scheduler,
                                   for_open_clip=False))
-        if not broadcast_done:
-            broadcast_model(model, rank)
-            broadcast_done = True
-        if folder_path is not None and rank == 0:
-            last_ckpt_path = os.path.join(folder_path, 'last.pth')
-            torch.save(model.state_dict(), last_ckpt_path)  # reference key names: loadable by the reference
-            print(f'Last ckpt: {last_ckpt_path}')
+        period = int(getattr(mc, "evaluation_period", 1))
+        if (epoch % period == 0 or epoch == mc.epochs - 1) and rank == 0:
+            if folder_path is not None:
+                last_ckpt_path = os.path.join(folder_path, 'last.pth')
+                torch.save(model.state_dict(), last_ckpt_path)  # reference key names: loadable by the reference
+                print(f'Last ckpt: {last_ckpt_path}')
+            if eval_loaders is not None:
+                acc_dict, _ = eval_phase(model, device, *eval_loaders, k_list, args=args, rank=rank)
+                cell = acc_dict['encoded_image_feature']['encoded_image_feature']
+                overall_acc = (cell['seen']['micro_acc'][1]['species'] + cell['unseen']['micro_acc'][1]['species']) / 2
+                if best_overall_acc is None or best_overall_acc < overall_acc:
+                    best_epoch, best_overall_acc = epoch, overall_acc
+                    if folder_path is not None:
+                        torch.save(model.state_dict(), os.path.join(folder_path, 'best.pth'))
+                print(f'epoch {epoch}: overall_acc {overall_acc:.4f} (best {best_overall_acc:.4f} @ {best_epoch})')
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

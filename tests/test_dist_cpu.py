@@ -60,6 +60,17 @@ def _worker(rank, world, port, B, tmp):
     buf = torch.full((7,), float(rank))
     hdist.broadcast_trainable([buf], src=0)
     assert (buf == 0).all()
+    # before the first forward there are no flat buffers: a model's trainable tensors are broadcast one by one, the frozen
+    # ones are left alone (they are identical by construction)
+    from bioscanclip.model import arch
+    from bioscanclip.model.language_encoder import LoRA_bert
+    torch.manual_seed(100 + rank)
+    txt = LoRA_bert(arch.BertModelParams(arch.bert_small_config(num_hidden_layers=1)), r=4, num_classes=768)
+    frozen_before = {k: v.clone() for k, v in txt.named_parameters() if not v.requires_grad}
+    hdist.broadcast_trainable(txt, src=0)
+    torch.save({k: v.detach().clone() for k, v in txt.named_parameters() if v.requires_grad},
+               os.path.join(tmp, f"trainable{rank}.pt"))
+    assert all(torch.equal(v, frozen_before[k]) for k, v in txt.named_parameters() if not v.requires_grad)
     torch.save({"loss": loss.detach(), "flat": flat}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -82,6 +93,8 @@ def test_two_rank_global_batch_step_equals_single_process(tmp_path):
     assert torch.allclose(r0["loss"], loss.detach(), rtol=1e-6, atol=0)
     assert torch.allclose(r1["loss"], loss.detach(), rtol=1e-6, atol=0)
     assert torch.equal(r0["flat"], r1["flat"])
+    t0, t1 = (torch.load(os.path.join(str(tmp_path), f"trainable{r}.pt")) for r in (0, 1))
+    assert len(t0) >= 6 and all(torch.equal(t0[k], t1[k]) for k in t0)
     err = ((r0["flat"] - flat).norm() / flat.norm()).item()
     assert err < 1e-5, err
 

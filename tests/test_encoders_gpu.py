@@ -211,6 +211,50 @@ def test_tower_streams_join_before_gradients_are_read():
         assert torch.equal(g, grads[False][0])
 
 
+def test_checkpoint_loaded_after_first_forward_repacks_frozen_weights():
+    """The engines pack the frozen weights into their own bf16 layouts at the first forward.  Loading a checkpoint
+    afterwards (in place) must not leave those copies stale."""
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+
+    def build(seed):
+        m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2, **NODROP)), r=4,
+                              num_classes=768)
+        _load(m, "dna_encoder.", seed)
+        return m.to("cuda").eval()
+
+    _, dna, _, _ = synth.synth_batch(4, seed=3)
+    dna = dna.cuda()
+    a, b = build(21), build(22)
+    with torch.no_grad():
+        ya, yb = a(dna).clone(), b(dna).clone()
+        assert not torch.allclose(ya, yb)
+        b.load_state_dict(a.state_dict())  # in place, after b's engine exists
+        assert torch.equal(b(dna), ya)
+        fresh = build(22)
+        fresh.load_state_dict({k: v.cpu() for k, v in a.state_dict().items()})  # before any forward
+        assert torch.equal(fresh(dna), ya)
+
+
+def test_train_cl_epoch_with_eval_phase(tmp_path, capsys):
+    """scripts/train_cl.py end to end on synthetic data: one short epoch, checkpoint written with the reference's key
+    names, eval_phase (feature extraction + GPU top-k retrieval + accuracy table) runs natively."""
+    import sys as _sys
+    scripts = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bioscan-clip_amd", "scripts")
+    _sys.path.insert(0, scripts)
+    import train_cl
+    losses = train_cl.main(["model_config=lora_vit_lora_barcode_bert_ssl", "model_config.batch_size=8",
+                            "model_config.epochs=1", "synthetic_steps_per_epoch=2", "synthetic_eval=true",
+                            "synthetic_eval_batches=1", "save_ckpt=true", "debug_flag=false",
+                            f"project_root_path={tmp_path}"])
+    out = capsys.readouterr().out
+    assert len(losses) == 1 and "overall_acc" in out and "Query_feature: encoded_image_feature" in out
+    ck = [os.path.join(r, f) for r, _, fs in os.walk(str(tmp_path)) for f in fs if f.endswith(".pth")]
+    assert any(p.endswith("last.pth") for p in ck) and any(p.endswith("best.pth") for p in ck)
+    keys = set(torch.load(ck[0], map_location="cpu").keys())
+    assert keys == {k for k in load_golden("state_dict_keys")["keys"] if not k.startswith("language_encoder.")}
+
+
 def test_requires_gpu_inputs():
     from bioscanclip.model import arch
     from bioscanclip.model.image_encoder import LoRA_ViT_timm

@@ -126,3 +126,27 @@ def test_synthetic_loader_layout():
     assert image.shape == (4, 3, 224, 224) and 0 <= image.min() and image.max() < 1
     assert dna.shape == (4, 133) and (dna[:, 0] == 0).all() and dna[:, 1:].min() >= 3 and dna.max() <= 1026
     assert ids.shape == (4, 20) and (ids[:, 0] == 101).all() and am.sum(1).min() >= 6 and len(pid) == 4
+
+
+def test_checkpoint_helpers_and_roundtrip(tmp_path):
+    """Reference util.py:72-84 semantics + a state_dict written by one model loads strictly into another (same keys)."""
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert, load_pre_trained_bioscan_bert
+    from bioscanclip.util.util import load_bert_model, remove_extra_pre_fix
+    assert remove_extra_pre_fix({"module.a.b": 1, "c": 2, "module.module.d": 3}) == {"a.b": 1, "c": 2, "module.d": 3}
+    torch.manual_seed(0)
+    bert = arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=1))
+    path = str(tmp_path / "bert.pth")
+    torch.save({"module." + k: v for k, v in bert.state_dict().items()}, path)
+    torch.manual_seed(1)
+    other = arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=1))
+    load_bert_model(other, path)
+    assert all(torch.equal(v, other.state_dict()[k]) for k, v in bert.state_dict().items())
+    with pytest.raises(RuntimeError):
+        load_bert_model(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2)), path)  # strict
+    a = LoRA_barcode_bert(bert, r=4, num_classes=768)
+    b = LoRA_barcode_bert(other, r=4, num_classes=768)
+    ck = str(tmp_path / "last.pth")
+    torch.save(a.state_dict(), ck)
+    b.load_state_dict(torch.load(ck))
+    assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
