@@ -71,15 +71,29 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t*
             av[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-    for (int row = wave; row < M; row += nwaves) {
+    // Rows are software-pipelined: the loads of the wave's next row are in flight while the current row is reduced (one row
+    // per iteration exposed a full HBM round trip per row: 83 us for 155 MB).
+    uint2 rq[NV], rv[NV];
+    u32x4 rt = {0u, 0u, 0u, 0u};
+    auto fetch = [&](int row) {
         const bf16_t* g = dqkv + (size_t)row * ld;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            rq[j] = *reinterpret_cast<const uint2*>(g + j * 256 + lane * 4);
+            rv[j] = *reinterpret_cast<const uint2*>(g + 2 * H + j * 256 + lane * 4);
+        }
+        rt = *reinterpret_cast<const u32x4*>(haug + (size_t)row * ld_h + H);  // t_q(4) t_v(4), broadcast
+    };
+    if (wave < M) fetch(wave);
+    for (int row = wave; row < M; row += nwaves) {
         f32x4 dq[NV], dv[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            dq[j] = ld_bf4(g + j * 256 + lane * 4);
-            dv[j] = ld_bf4(g + 2 * H + j * 256 + lane * 4);
+            dq[j] = f32x4{bf2f(rq[j].x & 0xffff), bf2f(rq[j].x >> 16), bf2f(rq[j].y & 0xffff), bf2f(rq[j].y >> 16)};
+            dv[j] = f32x4{bf2f(rv[j].x & 0xffff), bf2f(rv[j].x >> 16), bf2f(rv[j].y & 0xffff), bf2f(rv[j].y >> 16)};
         }
-        const u32x4 tu = *reinterpret_cast<const u32x4*>(haug + (size_t)row * ld_h + H);  // t_q(4) t_v(4), broadcast
+        const u32x4 tu = rt;
+        if (row + nwaves < M) fetch(row + nwaves);
         const f32x4 tq = {bf2f(tu[0] & 0xffff), bf2f(tu[0] >> 16), bf2f(tu[1] & 0xffff), bf2f(tu[1] >> 16)};
         const f32x4 tv = {bf2f(tu[2] & 0xffff), bf2f(tu[2] >> 16), bf2f(tu[3] & 0xffff), bf2f(tu[3] >> 16)};
         f32x4 pq = {0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f};
@@ -203,8 +217,63 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __re
     }
 }
 
-// out[n] += sum_r g[r, n].  One workgroup per 32 columns: 8 row groups x 32 columns, every thread sums rows rg, rg+8, ...
-// (4 loads in flight), the 8 partials are added in a fixed order through LDS.  No atomics: bitwise reproducible.
+// out[n] += sum_r g[r, n] without atomics (bitwise reproducible) and without a workspace.
+// Wide version (N % 8 == 0): one workgroup per 8 columns, thread t sums rows t, t+256, ... with one 16-B (bf16) / 2x16-B
+// (f32) load per row, 4 rows in flight; the 256 partials are combined in a fixed order through LDS.  N/8 workgroups (96
+// for N = 768) keep enough CUs busy for the one large caller, the MLM decoder bias gradient ([B*133, 768] bf16).
+template <bool BF16>
+__global__ __launch_bounds__(256) void colsum8_kernel(const void* __restrict__ g, int ld, int M, int N,
+                                                       float* __restrict__ out) {
+    __shared__ float part[256][9];
+    __shared__ float part2[8][8];
+    const int t = threadIdx.x;
+    const int n0 = blockIdx.x * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto add_row = [&](int r) {
+        if constexpr (BF16) {
+            const u32x4 u = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(g) + (size_t)r * ld + n0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[2 * k] += bf2f(u[k] & 0xffff);
+                s[2 * k + 1] += bf2f(u[k] >> 16);
+            }
+        } else {
+            const float* p = static_cast<const float*>(g) + (size_t)r * ld + n0;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[k] += a[k];
+                s[4 + k] += b[k];
+            }
+        }
+    };
+    int r = t;
+    for (; r + 768 < M; r += 1024) {
+        add_row(r);
+        add_row(r + 256);
+        add_row(r + 512);
+        add_row(r + 768);
+    }
+    for (; r < M; r += 256) add_row(r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[t][k] = s[k];
+    __syncthreads();
+    if (t < 64) {  // 8 columns x 8 row-octets: thread (c, o) sums partials 32*o .. 32*o+31 in order
+        const int c = t & 7, o = t >> 3;
+        float a = 0.f;
+        for (int i = 0; i < 32; ++i) a += part[32 * o + i][c];
+        part2[o][c] = a;
+    }
+    __syncthreads();
+    if (t < 8) {
+        float a = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) a += part2[o][t];
+        out[n0 + t] += a;
+    }
+}
+
+// Narrow fallback (any N): one workgroup per 32 columns, 8 row groups x 32 columns.
 template <bool BF16>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ g, int ld, int M, int N,
                                                       float* __restrict__ out) {
@@ -292,10 +361,16 @@ extern "C" int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, in
 
 extern "C" int bsclip_colsum(const void* g, int ld_g, int g_is_bf16, int M, int N, float* out, void* stream) {
     BSCLIP_REQUIRE(g && out && M > 0 && N > 0 && ld_g >= N, "bsclip_colsum: bad args");
-    const dim3 grid(ceil_div(N, 32));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (g_is_bf16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, s, g, ld_g, M, N, out);
-    else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, s, g, ld_g, M, N, out);
+    const bool wide = N % 8 == 0 && ld_g % 8 == 0 && (((uintptr_t)g) & 15) == 0;
+    if (wide) {
+        if (g_is_bf16) hipLaunchKernelGGL((colsum8_kernel<true>), dim3(N / 8), dim3(256), 0, s, g, ld_g, M, N, out);
+        else hipLaunchKernelGGL((colsum8_kernel<false>), dim3(N / 8), dim3(256), 0, s, g, ld_g, M, N, out);
+    } else {
+        const dim3 grid(ceil_div(N, 32));
+        if (g_is_bf16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, s, g, ld_g, M, N, out);
+        else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, s, g, ld_g, M, N, out);
+    }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

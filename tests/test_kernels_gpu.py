@@ -342,6 +342,16 @@ def test_small_ops(ops):
     out = torch.ones(512, device="cuda")
     ops.colsum(g32, 77, 512, out)
     assert rel_err(out, 1 + g32.sum(0)) < 1e-5
+    # narrow fallback (N not a multiple of 8, strided view) and a large bf16 case twice: bitwise reproducible
+    g3 = dev(rnd(333, 40, seed=5))[:, :36]
+    out = torch.zeros(36, device="cuda")
+    ops.colsum(g3, 333, 36, out)
+    assert rel_err(out, g3.sum(0)) < 1e-5
+    big = dev(rnd(34048, 768, seed=6).bfloat16())
+    o1, o2 = torch.zeros(768, device="cuda"), torch.zeros(768, device="cuda")
+    ops.colsum(big, 34048, 768, o1)
+    ops.colsum(big, 34048, 768, o2)
+    assert torch.equal(o1, o2) and rel_err(o1, big.double().sum(0)) < 1e-5
     src = dev(rnd(300, 200, seed=3).bfloat16())
     dst = torch.zeros(200, 304, device="cuda", dtype=torch.bfloat16)
     ops.transpose_bf16(src, 300, 200, dst)
