@@ -206,10 +206,14 @@ def main():
     backend = os.environ.get("BSCLIP_DIST_BACKEND", "nccl")
     if os.environ.get("BSCLIP_SINGLE_DEVICE", "0") == "1":
         local_rank = 0
-    if world > 1:
+    force_dist = os.environ.get("BSCLIP_FORCE_DIST", "0") == "1"  # world_size 1 through the real collectives (rehearsal)
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
@@ -223,7 +227,7 @@ def main():
     B = a.batch
     image, dna, text = synthetic_batch(B, a.text, device, seed=1234 + rank)
     label = (torch.arange(B) + rank * B).to(device)
-    crit = (GlobalBatchContrastiveLoss if world > 1 else ContrastiveLoss)(torch.nn.CrossEntropyLoss(), 1 / 0.07)
+    crit = (GlobalBatchContrastiveLoss if world > 1 or force_dist else ContrastiveLoss)(torch.nn.CrossEntropyLoss(), 1 / 0.07)
     opt = FusedAdamW(model.parameters(), lr=1e-3)
 
     def step():
@@ -246,7 +250,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -259,7 +263,7 @@ def main():
     t_enq = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -296,7 +300,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

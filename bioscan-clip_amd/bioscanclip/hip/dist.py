@@ -31,6 +31,15 @@ class _InsertLocal(torch.autograd.Function):
 
 
 _side_stream = {}
+# Rehearsal knob: BSCLIP_FORCE_DIST=1 sends a world_size-1 job through the collectives as well, so that a one-GPU box
+# exercises the real RCCL calls (all-gather on the side stream, flat all-reduce, broadcast) of the multi-GPU step.
+_FORCE = __import__("os").environ.get("BSCLIP_FORCE_DIST", "0") == "1"
+
+
+def _inactive(group=None):
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and not _FORCE
 
 
 def _comm_stream(device):
@@ -45,7 +54,7 @@ def _comm_stream(device):
 
 def gather_features_and_labels(feats, label, group=None):
     """feats: list of [B, D] f32 (autograd); label: [B] int64.  Returns ([W*B, D] per modality, [W*B] labels, row0)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _inactive(group):
         return feats, label, 0
     W, rank = dist.get_world_size(group), dist.get_rank(group)
     B = feats[0].shape[0]
@@ -90,7 +99,7 @@ def flat_buffers(model):
 
 
 def allreduce_grads(model_or_buffers, group=None):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _inactive(group):
         return
     bufs = model_or_buffers if isinstance(model_or_buffers, (list, tuple)) else [f.grad for f in flat_buffers(model_or_buffers)]
     works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in bufs]
@@ -99,7 +108,7 @@ def allreduce_grads(model_or_buffers, group=None):
 
 
 def broadcast_trainable(model_or_buffers, src=0, group=None):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _inactive(group):
         return
     if isinstance(model_or_buffers, (list, tuple)):
         bufs = list(model_or_buffers)
