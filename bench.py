@@ -212,8 +212,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
-        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
