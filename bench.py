@@ -223,6 +223,9 @@ def main():
 
     model = build_model(a.text, device)
     model.train()
+    nodrop = os.environ.get("BSCLIP_BENCH_NODROP", "0") == "1"  # diagnostic: what the dropout masks cost (not a valid bench line)
+    if nodrop:
+        model.eval()
     B = a.batch
     image, dna, text = synthetic_batch(B, a.text, device, seed=1234 + rank)
     label = (torch.arange(B) + rank * B).to(device)
@@ -287,7 +290,8 @@ def main():
                                    % (2 if a.text else 1, "+Text" if a.text else "", " + BERT-small" if a.text else "", B,
                                       "RCCL all-gather global-batch" if world > 1 else "local-batch"),
                        "local_batch": B, "global_batch": N, "parallelism": f"dp{world}",
-                       "dropout": "HF defaults active (BERT hidden 0.1, attention-probs 0.1; timm ViT drop 0), train mode",
+                       "dropout": ("DISABLED (diagnostic run, not the benchmark configuration)" if nodrop else
+                                   "HF defaults active (BERT hidden 0.1, attention-probs 0.1; timm ViT drop 0), train mode"),
                        "final_loss": round(final_loss, 6)},
             "step_roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),

@@ -210,6 +210,7 @@ class ViTEngine(EncoderEngineBase):
         ws["clsn_t"] = torch.zeros(H, Bp, dtype=BF16, device=dev)
         ws["dclsn"] = z(B, H)
         ws["dz_c"], ws["dh_c"], ws["st_c"] = z(B, FF), z(B, H), z(B, 2, dt=F32)   # last-block token-0 path
+        ws["h2_c"], ws["act_c"], ws["z_c"] = z(B, H), z(B, FF), z(B, FF)
         self.ws = ws
         return ws
 
@@ -225,10 +226,25 @@ class ViTEngine(EncoderEngineBase):
         ops.im2col_patch16(image, ws["cols"])
         ops.gemm(ws["cols"], self.w_patch, x[0], EPI_PATCH_F32, bias=self.b_patch, resid=self.pos)
         ops.vit_cls_rows(x[0], self.cls, self.pos, B, S, H)
+        L = len(self.layers)
         for l, lay in enumerate(self.layers):
             ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_bf16=ws["h1"][l], lora_a=self.lora_a(l),
                               stats=ws["st1"][l])
             ops.gemm(ws["h1"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
+            if l == L - 1:
+                # The head reads token 0 of the last block only (timm global_pool='token'), and within a block a token's
+                # output depends on the other tokens through K and V alone: attention for query 0, then proj / LN2 / MLP on
+                # the B token-0 rows (row stride S*H) instead of all B*197.  Same values, 1/197 of the GEMM work.
+                tok0 = lambda t, w: t.view(B, S * w)[:, :w]
+                ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], q_rows=1)
+                ops.gemm(tok0(ws["ctx"][l], H), lay.w_proj, tok0(x[2 * l + 1], H), EPI_RESID_F32, bias=lay.b_proj,
+                         resid=tok0(x[2 * l], H))
+                ops.layernorm_fwd(tok0(x[2 * l + 1], H), lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2_c"],
+                                  stats=ws["st_c"])
+                ops.gemm(ws["h2_c"], lay.w_fc1, ws["act_c"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z_c"])
+                ops.gemm(ws["act_c"], lay.w_fc2, tok0(x[2 * l + 2], H), EPI_RESID_F32, bias=lay.b_fc2,
+                         resid=tok0(x[2 * l + 1], H))
+                continue
             ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l])
             ops.gemm(ws["ctx"][l], lay.w_proj, x[2 * l + 1], EPI_RESID_F32, bias=lay.b_proj, resid=x[2 * l])
             ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2"], stats=ws["st2"][l])
@@ -271,9 +287,8 @@ class ViTEngine(EncoderEngineBase):
                 # token-0 rows only (row stride S*H), 1/197 of the work.
                 FF = self.FF
                 dxb_c = dxb.view(B, S * H)[:, :H]
-                ops.gemm(dxb_c, lay.w_fc2_t, ws["dz_c"], EPI_DGELU_BF16, aux=ws["z"][l].view(B, S * FF)[:, :FF])
+                ops.gemm(dxb_c, lay.w_fc2_t, ws["dz_c"], EPI_DGELU_BF16, aux=ws["z_c"])
                 ops.gemm(ws["dz_c"], lay.w_fc1_t, ws["dh_c"], EPI_BF16)
-                ws["st_c"].copy_(ws["st2"][l].view(B, S, 2)[:, 0])
                 dx_c = dx.view(B, S * H)[:, :H]
                 ops.layernorm_bwd(x[2 * l + 1].view(B, S * H)[:, :H], ws["st_c"], lay.ln2[0], 0, g_resid=dx_c,
                                   g_gemm=ws["dh_c"], dx_f32=dx_c, dx_bf16=dxb_c)
@@ -285,7 +300,8 @@ class ViTEngine(EncoderEngineBase):
                 ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh"], dx_f32=dx,
                                   dx_bf16=dxb)
                 ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
-            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"])
+            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
+                         q_rows=1 if l == L - 1 else 0)
             lb = self.lora_b(l)
             if lb is not None:
                 gb = self.lora_b(l, grad=True)

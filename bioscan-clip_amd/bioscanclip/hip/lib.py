@@ -32,8 +32,8 @@ SIGNATURES = {
     "bsclip_gemm_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, P]),
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, P]),
-    "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, F, U, P]),
-    "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, F, U, P]),
+    "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),
+    "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, P]),
     "bsclip_mask_to_bias": (I, [P, I, P, P]),
     "bsclip_vit_cls_rows": (I, [P, P, P, I, I, I, P]),

@@ -141,7 +141,7 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
                                          0 if dropout is None else int(dropout[1]) & 0xFFFFFFFF, _stream()))
 
 
-def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None):
+def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, q_rows=0):
     ld_qkv, ld_ctx = _rowmajor(qkv, "qkv"), _rowmajor(ctx, "ctx")
     _req(qkv.dtype == BF16 and ctx.dtype == BF16 and lse.dtype == F32, "attn_fwd dtypes")
     _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64, "attn_fwd: qkv too small")
@@ -150,10 +150,10 @@ def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None):
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_attn_fwd(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), ld_ctx, _p(lse),
-                                    dp, ds, _stream()))
+                                    int(q_rows), dp, ds, _stream()))
 
 
-def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None):
+def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None, q_rows=0):
     ld_qkv, ld_ctx, ld_d = _rowmajor(qkv, "qkv"), _rowmajor(dctx, "dctx"), _rowmajor(dqkv, "dqkv")
     _req(all(t.dtype == BF16 for t in (qkv, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
     _req(min(qkv.shape[0], dctx.shape[0], dqkv.shape[0]) >= B * S, "attn_bwd: rows")
@@ -163,7 +163,7 @@ def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=No
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_attn_bwd(_p(qkv), ld_qkv, _p(dctx), ld_ctx, _p(lse), B, S, heads, _p(key_bias),
-                                    float(scale), _p(dqkv), ld_d, dp, ds, _stream()))
+                                    float(scale), _p(dqkv), ld_d, int(q_rows), dp, ds, _stream()))
 
 
 def im2col_patch16(image, cols):

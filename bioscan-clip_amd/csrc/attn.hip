@@ -119,7 +119,7 @@ template <int NB, bool DROP>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S,
                                                                    int heads, const float* __restrict__ key_bias,
                                                                    float scale, bf16_t* __restrict__ ctx, int ld_ctx,
-                                                                   float* __restrict__ lse, DropCfg drop) {
+                                                                   float* __restrict__ lse, DropCfg drop, int nqb) {
     constexpr int SP = NB * 32;
     __shared__ __attribute__((aligned(16))) char smem[2 * SP * ROWB + SP * 4];
     char* sK = smem;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
     const float scale2 = scale * LOG2E;
 
 #pragma unroll 1
-    for (int blk = wave; blk < NB; blk += ATT_WAVES) {
+    for (int blk = wave; blk < nqb; blk += ATT_WAVES) {  // nqb <= NB: only the leading query blocks are wanted
         asm volatile("" ::: "memory");  // LDS tiles are loop-invariant: stop LICM from hoisting ~100 fragment registers
         const int q0 = blk * 32;
         const int qrow = min(q0 + (lane & 31), S - 1);
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                                                                    const bf16_t* __restrict__ dctx, int ld_ctx,
                                                                    const float* __restrict__ lse, int S, int heads,
                                                                    const float* __restrict__ key_bias, float scale,
-                                                                   bf16_t* __restrict__ dqkv, int ld_d, DropCfg drop) {
+                                                                   bf16_t* __restrict__ dqkv, int ld_d, DropCfg drop,
+                                                                   int nqb) {
     constexpr int SP = NB * 32;
     constexpr int RM = SP * ROWB;
     __shared__ __attribute__((aligned(16))) char smem[2 * RM + 3 * SP * 4];
@@ -250,8 +251,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
     __syncthreads();
     const float scale2 = scale * LOG2E;
     // ---------------- phase 1: a wave owns queries [q0, q0+32): delta, then dQ ----------------
+    // Query blocks >= nqb carry a zero upstream gradient by contract (last ViT block: only token 0 feeds the head): their
+    // dQ rows are written as zeros and they are skipped in both phases.
+    for (int blk = nqb + wave; blk < NB; blk += ATT_WAVES) {
+        const int q = blk * 32 + (lane & 31);
+        if (q < S) {
+            bf16_t* o = dqb + (size_t)q * ld_d + 32 * (lane >> 5);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(o + 8 * c) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
 #pragma unroll 1
-    for (int blk = wave; blk < NB; blk += ATT_WAVES) {
+    for (int blk = wave; blk < nqb; blk += ATT_WAVES) {
         asm volatile("" ::: "memory");  // LDS tiles are loop-invariant: stop LICM from hoisting ~100 fragment registers
         const int q0 = blk * 32;
         const int qrow = min(q0 + (lane & 31), S - 1);
@@ -344,7 +355,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         const float bias_k = sBias[k0 + (lane & 31)];
         f32x16 dv[2] = {zero16(), zero16()}, dk[2] = {zero16(), zero16()};
 #pragma unroll 1
-        for (int qt = 0; qt < NB; ++qt) {
+        for (int qt = 0; qt < nqb; ++qt) {
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -394,21 +405,23 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         if (drop.thr16)                                                                                         \
             hipLaunchKernelGGL((attn_fwd_kernel<NBV, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
                                static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,              \
-                               static_cast<bf16_t*>(ctx), ld_ctx, lse, drop);                                   \
+                               static_cast<bf16_t*>(ctx), ld_ctx, lse, drop, nqb);                                   \
         else                                                                                                    \
             hipLaunchKernelGGL((attn_fwd_kernel<NBV, false>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,      \
                                static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,              \
-                               static_cast<bf16_t*>(ctx), ld_ctx, lse, drop);                                   \
+                               static_cast<bf16_t*>(ctx), ld_ctx, lse, drop, nqb);                                   \
         break;
 
 extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias,
-                               float scale, void* ctx, int ld_ctx, float* lse, float dropout_p, uint32_t dropout_seed,
-                               void* stream) {
+                               float scale, void* ctx, int ld_ctx, float* lse, int q_rows, float dropout_p,
+                               uint32_t dropout_seed, void* stream) {
     BSCLIP_REQUIRE(qkv && ctx && lse, "bsclip_attn_fwd: null pointer");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_fwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_ctx >= heads * 64 && ld_ctx % 4 == 0,
                    "bsclip_attn_fwd: ld_qkv=%d ld_ctx=%d", ld_qkv, ld_ctx);
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_fwd: dropout_p=%f", dropout_p);
+    BSCLIP_REQUIRE(q_rows >= 0 && q_rows <= S, "bsclip_attn_fwd: q_rows=%d (0 = all, <= S)", q_rows);
+    const int nqb = q_rows > 0 ? (q_rows + 31) / 32 : (S + 31) / 32;
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch ((S + 31) / 32) {
@@ -424,15 +437,15 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
         if (drop.thr16)                                                                                          \
             hipLaunchKernelGGL((attn_bwd_kernel<NBV, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,        \
                                static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, \
-                               lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop);       \
+                               lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, nqb);       \
         else                                                                                                     \
             hipLaunchKernelGGL((attn_bwd_kernel<NBV, false>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
                                static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, \
-                               lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop);       \
+                               lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, nqb);       \
         break;
 
 extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
-                               int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
+                               int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
                                float dropout_p, uint32_t dropout_seed, void* stream) {
     BSCLIP_REQUIRE(qkv && dctx && lse && dqkv, "bsclip_attn_bwd: null pointer");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_bwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
@@ -440,6 +453,8 @@ extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, in
                        ld_ctx >= heads * 64 && ld_ctx % 8 == 0,
                    "bsclip_attn_bwd: ld_qkv=%d ld_dqkv=%d ld_ctx=%d", ld_qkv, ld_dqkv, ld_ctx);
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_bwd: dropout_p=%f", dropout_p);
+    BSCLIP_REQUIRE(q_rows >= 0 && q_rows <= S, "bsclip_attn_bwd: q_rows=%d (0 = all, <= S)", q_rows);
+    const int nqb = q_rows > 0 ? (q_rows + 31) / 32 : (S + 31) / 32;
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch ((S + 31) / 32) {

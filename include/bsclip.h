@@ -96,13 +96,16 @@ int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats
  * key_bias f32 [B,S] additive per key (HF extended attention mask, language_encoder.py:89) or NULL;
  * lse f32 [B, heads, S] = log-sum-exp of the scaled scores (saved for backward).  head_dim is 64.
  * dropout_p > 0: HF attention_probs_dropout_prob on the normalised probabilities (mask of (b,head,q,k) regenerated in bwd).
+ * q_rows: 0 = every query; n > 0 = only the first n query rows of each sequence matter (rounded up to a block of 32):
+ * fwd writes ctx/lse for those rows only, bwd takes dctx as zero on the others and writes zeros into their dq rows (the last
+ * ViT block, whose output is read at token 0 only: image_encoder.py:108-109 -> timm global_pool='token').
  * S <= 224.  bwd recomputes P from qkv + lse, forms delta = rowsum(P . dP) in f32 from the same tiles (not from the
  * bf16-rounded ctx: that loses the softmax-backward cancellation), and writes dqkv in the same layout as qkv. */
 int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale,
-                    void* ctx, int ld_ctx, float* lse, float dropout_p, uint32_t dropout_seed, void* stream);
+                    void* ctx, int ld_ctx, float* lse, int q_rows, float dropout_p, uint32_t dropout_seed, void* stream);
 int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
-                    int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, float dropout_p,
-                    uint32_t dropout_seed, void* stream);
+                    int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
+                    float dropout_p, uint32_t dropout_seed, void* stream);
 
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column

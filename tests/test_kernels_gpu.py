@@ -208,6 +208,35 @@ def test_attention_fwd_bwd(ops, B, S, heads, masked):
         assert rel_err(dqkv[:, sl].float(), gq[:, sl]) < 1e-2, name
 
 
+@pytest.mark.parametrize("B,S,heads,q_rows", [(3, 197, 12, 1), (2, 133, 4, 40), (2, 20, 2, 1)])
+def test_attention_leading_query_rows_only(ops, B, S, heads, q_rows):
+    """q_rows: only the first rows of each sequence are wanted (last ViT block: token 0).  Forward must give the same ctx / lse
+    on those rows; backward with dctx zero elsewhere must equal the full backward and write zeros into the other dq rows."""
+    H = heads * 64
+    qkv = dev(rnd(B * S, 3 * H, seed=4).bfloat16())
+    ctx_full = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
+    lse_full = torch.empty(B, heads, S, device="cuda")
+    ops.attn_fwd(qkv, B, S, heads, 0.125, ctx_full, lse_full)
+    ctx = torch.full((B * S, H), 7.0, device="cuda", dtype=torch.bfloat16)
+    lse = torch.full((B, heads, S), 7.0, device="cuda")
+    ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse, q_rows=q_rows)
+    rows = torch.arange(B)[:, None] * S + torch.arange(q_rows)[None]
+    assert torch.equal(ctx[rows.reshape(-1)], ctx_full[rows.reshape(-1)])
+    assert torch.equal(lse[:, :, :q_rows], lse_full[:, :, :q_rows])
+    nq = min(S, (q_rows + 31) // 32 * 32)  # whole 32-row blocks are computed, nothing beyond them is touched
+    assert (ctx.view(B, S, H)[:, nq:] == 7.0).all()
+    dctx = torch.zeros(B * S, H, device="cuda", dtype=torch.bfloat16)
+    dctx[rows.reshape(-1)] = dev(rnd(B * q_rows, H, seed=5).bfloat16())
+    full = torch.empty(B * S, 3 * H, device="cuda", dtype=torch.bfloat16)
+    ops.attn_bwd(qkv, dctx, lse_full, B, S, heads, 0.125, full)
+    part = torch.full((B * S, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, part, q_rows=q_rows)  # lse holds 7.0 outside the wanted blocks
+    assert torch.equal(part, full)
+    assert (part.view(B, S, 3 * H)[:, nq:, :H] == 0).all()
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse, q_rows=S + 1)
+
+
 # ------------------------------------------------------------------------------------------ embeddings / misc
 def test_im2col_and_cls(ops):
     B = 3
