@@ -176,13 +176,13 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 }
 
 inline int64_t al4(int64_t x) { return (x + 3) & ~(int64_t)3; }
-inline int pad128(int n) { return (n + 127) / 128 * 128; }
+inline int pad_keys(int n) { return (n + 255) / 256 * 256; }  // multiple of 256: the 256x256 ping-pong GEMM tile
 
 }  // namespace
 
 extern "C" int64_t bsclip_topk_ip_workspace_floats(int Q, int K, int D) {
     if (Q <= 0 || K <= 0 || D <= 0) return -1;
-    const int64_t Kp = pad128(K), Qs = Q < TOPK_SLAB ? Q : TOPK_SLAB;
+    const int64_t Kp = pad_keys(K), Qs = Q < TOPK_SLAB ? Q : TOPK_SLAB;
     // key operand bf16 [Kp, 4D] + query operand bf16 [Qs, 4D] + one f32 score slab [Qs, Kp]
     return al4(Kp * 2 * D) + al4(Qs * 2 * D) + al4(Qs * Kp);
 }
@@ -194,7 +194,7 @@ extern "C" int bsclip_topk_ip(const float* queries, int Q, const float* keys, in
     BSCLIP_REQUIRE(k >= 1 && k <= 16 && k <= K, "bsclip_topk_ip: k=%d (1..16, <= K)", k);
     BSCLIP_REQUIRE((((uintptr_t)workspace) & 15) == 0, "bsclip_topk_ip: workspace must be 16-B aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int Kp = pad128(K);
+    const int Kp = pad_keys(K);
     const int Qs = Q < TOPK_SLAB ? Q : TOPK_SLAB;
     float* ws = workspace;
     bf16_t* kP = reinterpret_cast<bf16_t*>(ws); ws += al4((int64_t)Kp * 2 * D);
