@@ -33,6 +33,7 @@ SIGNATURES = {
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),
+    "bsclip_attn_bwd_diag": (I, [P, I, P, I, P, I, I, I, F, P, I, P, P]),
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, P]),
     "bsclip_mask_to_bias": (I, [P, I, P, P]),

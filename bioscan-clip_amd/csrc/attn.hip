@@ -48,16 +48,27 @@ constexpr int ATT_WAVES = 4;  // waves per workgroup; wave w owns 32-row blocks 
 // Row-major tile, 16-B chunk index XOR-swizzled with (row>>1)&7: conflict-free ds_read_b128 for the 32x32x16 A operand.
 __device__ __forceinline__ int rm_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// Stage rows [0,S) of a [S][64] bf16 matrix (row stride ld elements) into a row-major LDS tile; rows >= S are zero.
+// Stage a [S][64] bf16 matrix (row stride ld elements) into a row-major, XOR-swizzled LDS tile of SP rows with LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, every piece in flight at once; the register-staged version issued its
+// 7 loads per thread one HBM round trip after the other: 11 us per K+V staging, a fifth of the backward kernel).
+// One wave-instruction fills 1 KiB = 8 rows; the swizzle is applied on the source side (LDS destination is lane-linear).
+// Rows >= S repeat row S-1: padded keys / queries always carry probability 0, so their content only has to be finite.
+// The caller waits (vmcnt(0)) and synchronises.
 template <int SP>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int S, char* dst_rm, int tid) {
-    for (int it = tid; it < SP * 8; it += ATT_WAVES * 64) {
-        const int row = it >> 3, c = it & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < S) v = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + c * 8);
-        *reinterpret_cast<u32x4*>(dst_rm + rm_off(row, c)) = v;
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int S, char* dst_rm, int wave,
+                                           int lane) {
+    const int r8 = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int c = 0; c < (SP / 8 + ATT_WAVES - 1) / ATT_WAVES; ++c) {
+        const int chunk = wave + ATT_WAVES * c;
+        if (chunk < SP / 8) {
+            const int row = 8 * chunk + r8;
+            const int lc = pc ^ ((row >> 1) & 7);
+            glds16(src + (size_t)min(row, S - 1) * ld + lc * 8, dst_rm + chunk * 1024);
+        }
     }
 }
+__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // A-operand fragment of a row-major tile: rows r0 + (lane&31), k = 16*ks + 8*(lane>>5) + j
 __device__ __forceinline__ bf16x8 frag_rm(const char* tile, int r0, int ks, int lane) {
@@ -134,11 +145,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
     const bf16_t* kb = qb + HW;
     const bf16_t* vb = kb + HW;
 
-    stage_tile<SP>(kb, ld, S, sK, tid);
-    stage_tile<SP>(vb, ld, S, sV, tid);
-    // scores are kept in the log2 domain: s2 = (q.k * scale + bias) * log2(e), so p = exp2(s2 - m2) is one v_exp_f32
+    stage_tile<SP>(kb, ld, S, sK, wave, lane);
+    stage_tile<SP>(vb, ld, S, sV, wave, lane);
+    // The additive key bias rides in the MFMA accumulator: the score tile starts from bias / scale instead of zero, so
+    // acc = q.k + bias / scale and p = exp2(acc * scale2 - m * scale2) is one fma + one v_exp_f32 per score (scale2 = scale *
+    // log2 e).  Padded keys start from -inf (HF's finfo.min mask overflows to -inf as well: probability exactly 0).
+    const float inv_scale = 1.0f / scale;
     for (int k = tid; k < SP; k += ATT_WAVES * 64)
-        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] * LOG2E : 0.f) : -INFINITY;
+        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] * inv_scale : 0.f) : -INFINITY;
+    stage_wait();
     __syncthreads();
     const float scale2 = scale * LOG2E;
 
@@ -156,28 +171,27 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NB; ++kt) {
-            f32x16 acc = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = mfma32(frag_rm(sK, 32 * kt, ks, lane), qf[ks], acc);
+            f32x16 acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float s = fmaf(acc[4 * g + i], scale2, bias[i]);
-                    acc[4 * g + i] = s;
-                    m = fmaxf(m, s);
-                }
+                for (int i = 0; i < 4; ++i) acc[4 * g + i] = bias[i];
             }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = mfma32(frag_rm(sK, 32 * kt, ks, lane), qf[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r]);
             p[kt] = acc;
         }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));  // raw-score units
+        const float nm2 = -m * scale2;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NB; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(p[kt][r] - m);
+                const float e = __builtin_amdgcn_exp2f(fmaf(p[kt][r], scale2, nm2));
                 p[kt][r] = e;
                 sum += e;
             }
@@ -208,20 +222,26 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
         const int q = q0 + (lane & 31);
         if (q < S) {
             store_dt(o, 1.0f / sum, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
-            if (h == 0) lse[((size_t)b * heads + hd) * S + q] = (m + __log2f(sum)) * LN2;  // natural-log LSE
+            if (h == 0) lse[((size_t)b * heads + hd) * S + q] = (__log2f(sum) - nm2) * LN2;  // natural-log LSE
         }
     }
 }
 
-template <int NB, bool DROP>
+template <int NB, bool DROP, bool DIAG = false>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
                                                                    const bf16_t* __restrict__ dctx, int ld_ctx,
                                                                    const float* __restrict__ lse, int S, int heads,
                                                                    const float* __restrict__ key_bias, float scale,
                                                                    bf16_t* __restrict__ dqkv, int ld_d, DropCfg drop,
-                                                                   int nqb) {
+                                                                   int nqb, unsigned long long* diag = nullptr) {
     constexpr int SP = NB * 32;
     constexpr int RM = SP * ROWB;
+    auto stamp = [&](int i) {  // diagnostic build: per-wave section times (100 MHz wall clock); tools/attn_phases.py
+        if constexpr (DIAG) {
+            if ((threadIdx.x & 63) == 0) diag[((size_t)blockIdx.x * ATT_WAVES + (threadIdx.x >> 6)) * 8 + i] = wall_clock64();
+        }
+    };
+    stamp(0);
     __shared__ __attribute__((aligned(16))) char smem[2 * RM + 3 * SP * 4];
     char* sR0 = smem;       // phase 1: K | phase 2: Q
     char* sR1 = smem + RM;  // phase 1: V | phase 2: dO
@@ -241,14 +261,16 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
     const unsigned bh = (unsigned)(b * heads + hd);
 
     // ---------------- phase 1 staging: K, V row-major, lse, bias ----------------
-    stage_tile<SP>(kb, ld, S, sR0, tid);
-    stage_tile<SP>(vb, ld, S, sR1, tid);
+    stage_tile<SP>(kb, ld, S, sR0, wave, lane);
+    stage_tile<SP>(vb, ld, S, sR1, wave, lane);
     for (int k = tid; k < SP; k += ATT_WAVES * 64) {
-        // log2 domain: p = exp2(q.k * scale2 + bias2 - lse2)
-        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] * LOG2E : 0.f) : -INFINITY;
+        // log2 domain: p = exp2(acc * scale2 - lse2) with acc = q.k + bias / scale (the bias is the accumulator's start value)
+        sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] * (1.0f / scale) : 0.f) : -INFINITY;
         sLse[k] = (k < S) ? lse[((size_t)b * heads + hd) * S + k] * LOG2E : INFINITY;  // padded queries -> p = 0
     }
+    stage_wait();
     __syncthreads();
+    stamp(1);
     const float scale2 = scale * LOG2E;
     // ---------------- phase 1: a wave owns queries [q0, q0+32): delta, then dQ ----------------
     // Query blocks >= nqb carry a zero upstream gradient by contract (last ViT block: only token 0 feeds the head): their
@@ -281,20 +303,25 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         float dpart = 0.f;
 #pragma unroll 1
         for (int kt = 0; kt < NB; ++kt) {
-            f32x16 s = zero16(), dp = zero16();
+            f32x16 s, dp = zero16();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[4 * g + i] = b4[i];
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);     // S^T[key, q]
+                s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);     // S^T[key, q] + bias / scale
                 dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);  // dP^T[key, q]
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
                 f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, b4[i]) + nlse_q);
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, nlse_q));
                     if constexpr (DROP) dpart = fmaf(pr, dp[4 * g + i] * k4[i], dpart);
                     else dpart = fmaf(pr, dp[4 * g + i], dpart);
                 }
@@ -302,11 +329,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         }
         const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
         if (h == 0) sDelta[q0 + (lane & 31)] = delta_q;
+        if (blk == wave) stamp(6);
         // pass 2: dS^T = P^T (dP^T - delta);  dQ^T += K^T dS^T, scaled once at the end
         f32x16 dq[2] = {zero16(), zero16()};
 #pragma unroll 1
         for (int kt = 0; kt < NB; ++kt) {
-            f32x16 s = zero16(), dp = zero16();
+            f32x16 s, dp = zero16();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[4 * g + i] = b4[i];
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);
@@ -314,12 +348,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
                 f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, b4[i]) + nlse_q);
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, nlse_q));
                     if constexpr (DROP) dp[4 * g + i] = pr * (dp[4 * g + i] * k4[i] - delta_q);
                     else dp[4 * g + i] = pr * (dp[4 * g + i] - delta_q);
                 }
@@ -334,12 +367,17 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         }
         const int q = q0 + (lane & 31);
         if (q < S) store_dt(dq, scale, dqb + (size_t)q * ld_d, lane);
+        if (blk == wave) stamp(7);
     }
+    stamp(2);
     __syncthreads();
+    stamp(3);
     // ---------------- phase 2 staging: Q, dO row-major ----------------
-    stage_tile<SP>(qb, ld, S, sR0, tid);
-    stage_tile<SP>(dob, ld_ctx, S, sR1, tid);
+    stage_tile<SP>(qb, ld, S, sR0, wave, lane);
+    stage_tile<SP>(dob, ld_ctx, S, sR1, wave, lane);
+    stage_wait();
     __syncthreads();
+    stamp(4);
     // ---------------- phase 2: a wave owns keys [k0, k0+32): dV, dK ----------------
 #pragma unroll 1
     for (int blk = wave; blk < NB; blk += ATT_WAVES) {
@@ -352,14 +390,19 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             kf[ks] = frag_global(kb, ld, krow, ks, lane);
             vf[ks] = frag_global(vb, ld, krow, ks, lane);
         }
-        const float bias_k = sBias[k0 + (lane & 31)];
+        f32x16 bk16;  // the key's bias / scale as the score accumulator's start value (same for every query row)
+        {
+            const float bias_k = sBias[k0 + (lane & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bk16[r] = bias_k;
+        }
         f32x16 dv[2] = {zero16(), zero16()}, dk[2] = {zero16(), zero16()};
 #pragma unroll 1
         for (int qt = 0; qt < nqb; ++qt) {
-            f32x16 s = zero16(), dp = zero16();
+            f32x16 s = bk16, dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = mfma32(frag_rm(sR0, 32 * qt, ks, lane), kf[ks], s);    // S[q, key]
+                s = mfma32(frag_rm(sR0, 32 * qt, ks, lane), kf[ks], s);    // S[q, key] + bias / scale
                 dp = mfma32(frag_rm(sR1, 32 * qt, ks, lane), vf[ks], dp);  // dP[q, key]
             }
 #pragma unroll
@@ -368,7 +411,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + 32 * qt + 8 * g + 4 * h);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, bias_k) - l4[i]);
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, -l4[i]));
                     if constexpr (DROP) {
                         const int q = min(32 * qt + 8 * g + 4 * h + i, S - 1);
                         const float keep = drop_factor(drop, (bh * S + (unsigned)q) * SP + (unsigned)krow);
@@ -396,6 +439,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             store_dt(dv, 1.0f, dqb + (size_t)key * ld_d + 2 * HW, lane);
         }
     }
+    stamp(5);
 }
 
 }  // namespace
@@ -461,6 +505,27 @@ extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, in
         ATTN_BWD_CASE(1) ATTN_BWD_CASE(2) ATTN_BWD_CASE(3) ATTN_BWD_CASE(4) ATTN_BWD_CASE(5) ATTN_BWD_CASE(6)
         ATTN_BWD_CASE(7)
     }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+// Diagnostic build of the backward kernel (S = 197 / 133 instances): per-wave wall-clock stamps
+// [start, K/V staged, phase 1 done, barrier passed, Q/dO staged, end] in diag[(B*heads) * 4 waves * 8].  Never used by the product.
+extern "C" int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
+                                    int S, int heads, float scale, void* dqkv, int ld_dqkv, unsigned long long* diag,
+                                    void* stream) {
+    BSCLIP_REQUIRE(qkv && dctx && lse && dqkv && diag, "bsclip_attn_bwd_diag: null pointer");
+    BSCLIP_REQUIRE(S == 197 || S == 133, "bsclip_attn_bwd_diag: S=%d (197 or 133)", S);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DropCfg drop = make_drop(0.f, 0);
+    if (S == 197)
+        hipLaunchKernelGGL((attn_bwd_kernel<7, false, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,
+                           static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, lse, S, heads,
+                           (const float*)nullptr, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, 7, diag);
+    else
+        hipLaunchKernelGGL((attn_bwd_kernel<5, false, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,
+                           static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, lse, S, heads,
+                           (const float*)nullptr, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, 5, diag);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

@@ -107,6 +107,11 @@ int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, c
                     int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
                     float dropout_p, uint32_t dropout_seed, void* stream);
 
+/* diagnostic build of the backward kernel (S = 197 or 133, no mask, no dropout): per-wave section stamps in 100 MHz ticks,
+ * diag[B*heads*4*8]; tools/attn_phases.py.  Never used by the product path. */
+int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
+                         int heads, float scale, void* dqkv, int ld_dqkv, unsigned long long* diag, void* stream);
+
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column
  * order (c, ky, kx) = conv weight.flatten(1).  cls rows: x[b*197] = cls + pos[0].
