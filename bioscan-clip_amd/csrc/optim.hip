@@ -71,29 +71,34 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t*
             av[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-    // Rows are software-pipelined: the loads of the wave's next row are in flight while the current row is reduced (one row
-    // per iteration exposed a full HBM round trip per row: 83 us for 155 MB).
-    uint2 rq[NV], rv[NV];
-    u32x4 rt = {0u, 0u, 0u, 0u};
-    auto fetch = [&](int row) {
+    // Rows are software-pipelined three deep: with one row per iteration every row paid a full HBM round trip (83 us for
+    // 155 MB); a wave now keeps the loads of its next PF rows (3 KiB each) in flight while it reduces the current one.
+    constexpr int PF = 3;
+    uint2 rq[PF][NV], rv[PF][NV];
+    u32x4 rt[PF];
+    auto fetch = [&](int slot, int row) {
         const bf16_t* g = dqkv + (size_t)row * ld;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            rq[j] = *reinterpret_cast<const uint2*>(g + j * 256 + lane * 4);
-            rv[j] = *reinterpret_cast<const uint2*>(g + 2 * H + j * 256 + lane * 4);
+            rq[slot][j] = *reinterpret_cast<const uint2*>(g + j * 256 + lane * 4);
+            rv[slot][j] = *reinterpret_cast<const uint2*>(g + 2 * H + j * 256 + lane * 4);
         }
-        rt = *reinterpret_cast<const u32x4*>(haug + (size_t)row * ld_h + H);  // t_q(4) t_v(4), broadcast
+        rt[slot] = *reinterpret_cast<const u32x4*>(haug + (size_t)row * ld_h + H);  // t_q(4) t_v(4), broadcast
     };
-    if (wave < M) fetch(wave);
-    for (int row = wave; row < M; row += nwaves) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (wave + p * nwaves < M) fetch(p, wave + p * nwaves);
+    auto body = [&](int slot, int row) {
         f32x4 dq[NV], dv[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            dq[j] = f32x4{bf2f(rq[j].x & 0xffff), bf2f(rq[j].x >> 16), bf2f(rq[j].y & 0xffff), bf2f(rq[j].y >> 16)};
-            dv[j] = f32x4{bf2f(rv[j].x & 0xffff), bf2f(rv[j].x >> 16), bf2f(rv[j].y & 0xffff), bf2f(rv[j].y >> 16)};
+            dq[j] = f32x4{bf2f(rq[slot][j].x & 0xffff), bf2f(rq[slot][j].x >> 16), bf2f(rq[slot][j].y & 0xffff),
+                          bf2f(rq[slot][j].y >> 16)};
+            dv[j] = f32x4{bf2f(rv[slot][j].x & 0xffff), bf2f(rv[slot][j].x >> 16), bf2f(rv[slot][j].y & 0xffff),
+                          bf2f(rv[slot][j].y >> 16)};
         }
-        const u32x4 tu = rt;
-        if (row + nwaves < M) fetch(row + nwaves);
+        const u32x4 tu = rt[slot];
+        if (row + PF * nwaves < M) fetch(slot, row + PF * nwaves);
         const f32x4 tq = {bf2f(tu[0] & 0xffff), bf2f(tu[0] >> 16), bf2f(tu[1] & 0xffff), bf2f(tu[1] >> 16)};
         const f32x4 tv = {bf2f(tu[2] & 0xffff), bf2f(tu[2] >> 16), bf2f(tu[3] & 0xffff), bf2f(tu[3] >> 16)};
         f32x4 pq = {0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f};
@@ -111,6 +116,11 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t*
         const int src = ((lane >> 2) & 1) * 32 + ((lane >> 1) & 1) * 16 + (lane & 1) * 8;
         const float tl = __shfl(tot, src, 64);
         if (lane < 8) dt[(size_t)row * 8 + lane] = tl;
+    };
+    for (int row = wave; row < M; row += PF * nwaves) {  // slots are compile-time indices: registers, not scratch
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (row + p * nwaves < M) body(p, row + p * nwaves);
     }
     // cross-wave sum in wave order (no LDS atomics: the order of float adds is fixed)
     const int wib = threadIdx.x >> 6;
@@ -150,16 +160,32 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __
     for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int j = 0; j < NV; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int row = wave; row < M; row += nwaves) {
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8);
-        const f32x4 d1 = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8 + 4);
+    // three rows per iteration: all their loads are issued before the first is consumed
+    constexpr int PF = 3;
+    for (int row0 = wave; row0 < M; row0 += PF * nwaves) {
+        f32x4 d0[PF], d1[PF];
+        uint2 yr[PF][NV];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const f32x4 y = ld_bf4(haug + (size_t)row * ld_h + j * 256 + lane * 4);
+        for (int p = 0; p < PF; ++p) {
+            const int row = min(row0 + p * nwaves, M - 1);
+            d0[p] = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8);
+            d1[p] = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8 + 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[r][j] += d0[r] * y;
-                acc[4 + r][j] += d1[r] * y;
+            for (int j = 0; j < NV; ++j)
+                yr[p][j] = *reinterpret_cast<const uint2*>(haug + (size_t)row * ld_h + j * 256 + lane * 4);
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            if (row0 + p * nwaves >= M) break;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const f32x4 y = {bf2f(yr[p][j].x & 0xffff), bf2f(yr[p][j].x >> 16), bf2f(yr[p][j].y & 0xffff),
+                                 bf2f(yr[p][j].y >> 16)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[r][j] += d0[p][r] * y;
+                    acc[4 + r][j] += d1[p][r] * y;
+                }
             }
         }
     }
