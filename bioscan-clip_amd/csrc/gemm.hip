@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 
     auto stamp = [&](int i) {
         if constexpr (DIAG) {
-            if (lane == 0 && wc == 0) e.diag[(size_t)blockIdx.x * 8 + g * 4 + i] = wall_clock64();
+            if (lane == 0 && wc == 0) e.diag[(size_t)blockIdx.x * 16 + g * 8 + i] = wall_clock64();
         }
     };
     stamp(0);
@@ -504,11 +504,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         if constexpr (EPI == BSCLIP_EPI_BF16 || EPI == BSCLIP_EPI_GELU_BF16) {
             stage_bf16(mi);
             __syncthreads();
+            stamp(4 + 2 * mi);
             rows_bf16(mi, smem + g * (64 * SB), static_cast<bf16_t*>(C), ldc);
             if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
                 if (e.aux) rows_bf16(mi, slab2, e.aux, e.ld_aux);  // gelu'(pre-activation) for the backward pass
             }
             __syncthreads();
+            stamp(5 + 2 * mi);
         }
     }
     if constexpr (!(EPI == BSCLIP_EPI_BF16 || EPI == BSCLIP_EPI_GELU_BF16)) {
@@ -564,12 +566,16 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         prefetch(0, pre[0]);
         stage_f32(0);
         __syncthreads();
+        stamp(4);
         prefetch(1, pre[1]);
         consume(0, pre[0]);
         __syncthreads();
+        stamp(5);
         stage_f32(1);
         __syncthreads();
+        stamp(6);
         consume(1, pre[1]);
+        stamp(7);
     }
     stamp(3);
 }
@@ -630,7 +636,7 @@ void launch_bias(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, in
 }  // namespace
 
 // Diagnostic: the ping-pong kernel with four phase stamps per workgroup and wave group (start, prologue done, K loop
-// done, end) written to diag[grid*8] (100 MHz ticks).  Used by tools/gemm_phases.py; not on any product path.
+// done, end) written to diag[grid*16] (8 per wave group: start, prologue, K loop, end, 4 epilogue sections) (100 MHz ticks).  Used by tools/gemm_phases.py; not on any product path.
 extern "C" int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                 int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream) {
     BSCLIP_REQUIRE(A && B && C && diag && args, "bsclip_gemm_diag: null pointer");

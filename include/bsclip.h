@@ -64,7 +64,7 @@ int bsclip_init_tables(void* stream);
 /* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 */
 int bsclip_gemm_set_tile(int tile);
 /* diagnostic build of the 256x256 kernel: per-workgroup phase stamps (start, prologue, K loop, end) in 100 MHz ticks,
- * diag[grid * 8]; tools/gemm_phases.py.  Never used by the product path. */
+ * diag[grid * 16]; tools/gemm_phases.py.  Never used by the product path. */
 int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream);
 
