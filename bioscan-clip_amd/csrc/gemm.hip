@@ -220,33 +220,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const bf
 // ---------------------------------------------------------------------------------------------------------------
 // GELU table for the 256x256 kernel's epilogue
 // ---------------------------------------------------------------------------------------------------------------
-// The two-output GELU epilogue (gelu and gelu' of 128 values per lane) was VALU-bound: ~24 instructions per value with
-// exp + rcp, 12 us per tile with no MFMA to hide behind.  Phi and phi are smooth, so a 1/64-spaced table on [-8, 8] with
-// linear interpolation is exact to 7e-6 (h^2/8 max|f''|), far inside the bf16 rounding of the outputs, and costs
-// ~9 VALU + one 16-B LDS read per value.  Entry i (x_i = -8 + i/64): {Phi(x_i), Phi(x_{i+1}) - Phi(x_i), phi(x_i),
-// phi(x_{i+1}) - phi(x_i)}, computed once on the device in f64 with erf().
-constexpr int GELU_LUT_N = 1024;                       // intervals
-constexpr int GELU_LUT_BYTES = (GELU_LUT_N + 1) * 16;  // 16400
-__device__ f32x4 g_gelu_lut[GELU_LUT_N + 1];
+// The two-output GELU epilogue (gelu and gelu' of 128 values per lane) computed with exp + rcp was VALU-bound (~24
+// instructions per value, 12 us per tile with no MFMA to hide behind), and a 16-B-per-entry interpolation table was bound by
+// the LDS array instead: 64 lanes gathering random 16-B entries conflict ~3x per 16-lane group (phase stamps: 4.4 us per
+// 64-row slab).  Entries are therefore 8 B -- {Phi(x_i), phi(x_i)} on a 1/64 grid over [-8, 8], nearest grid point, one
+// ds_read_b64 per value -- and the neighbourhood comes from the derivatives, which are free: Phi' = phi, phi' = -x phi, so
+//   Phi(x_i + d) = Phi_i + d phi_i (1 - x_i d / 2) + O(d^3 |phi''| / 6)   <= 2e-8   for |d| <= 1/128,
+//   phi(x_i + d) = phi_i (1 - x_i d)               + O(d^2 |phi''| / 2)   <= 1.3e-5,
+// both far inside the bf16 rounding of the outputs.  Computed once on the device in f64 with erf().
+constexpr int GELU_LUT_N = 1024;                      // intervals
+constexpr int GELU_LUT_BYTES = (GELU_LUT_N + 1) * 8;  // 8200
+__device__ float2 g_gelu_lut[GELU_LUT_N + 1];
 
 __global__ void gelu_lut_init_kernel() {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > GELU_LUT_N) return;
-    auto Phi = [](double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)); };
-    auto phi = [](double x) { return 0.39894228040143267794 * exp(-0.5 * x * x); };
-    const double x0 = -8.0 + i / 64.0, x1 = x0 + 1.0 / 64.0;
-    g_gelu_lut[i] = f32x4{(float)Phi(x0), (float)(Phi(x1) - Phi(x0)), (float)phi(x0), (float)(phi(x1) - phi(x0))};
+    const double x = -8.0 + i / 64.0;
+    g_gelu_lut[i] = float2{(float)(0.5 * (1.0 + erf(x * 0.70710678118654752440))),
+                           (float)(0.39894228040143267794 * exp(-0.5 * x * x))};
 }
 
-__device__ __forceinline__ void gelu_lut(const char* lut, float x, float& gl, float& dg) {
-    const float t = fmaf(__builtin_amdgcn_fmed3f(x, -8.0f, 7.998f), 64.0f, 512.0f);  // [0, 1024)
-    const float fi = floorf(t);
-    const float fr = t - fi;
-    const f32x4 e = *reinterpret_cast<const f32x4*>(lut + (int)fi * 16);
-    const float cdf = fmaf(fr, e[1], e[0]);
-    const float pdf = fmaf(fr, e[3], e[2]);
+// Two values per call so that the arithmetic runs on the packed-f32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32);
+// the clamp, the float<->int conversions and the table address stay per value.  Phi is taken to first order as well
+// (error d^2 |phi'| / 2 <= 7.4e-6 for |d| <= 1/128).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_lut2(const char* lut, f32x2 x, f32x2& gl, f32x2& dg) {
+    f32x2 xc, fi, Phi, phi;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) xc[k] = __builtin_amdgcn_fmed3f(x[k], -8.0f, 8.0f);
+    const f32x2 t = xc * 64.0f + 512.5f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = (int)t[k];  // t in [0.5, 1024.5]: truncation = nearest grid point
+        const float2 e = *reinterpret_cast<const float2*>(lut + i * 8);
+        fi[k] = (float)i;
+        Phi[k] = e.x;
+        phi[k] = e.y;
+    }
+    const f32x2 xi = fi * 0.015625f - 8.0f;
+    const f32x2 d = xc - xi;
+    const f32x2 cdf = d * phi + Phi;
+    const f32x2 pdf = phi - (xi * d) * phi;
     gl = x * cdf;
-    dg = fmaf(x, pdf, cdf);
+    dg = x * pdf + cdf;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -449,7 +465,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     const char* lut = smem + 4 * 64 * SB;
     if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {  // 16 KiB table, L2-resident, behind the slabs
         for (int i = tid; i <= GELU_LUT_N; i += 512)
-            *reinterpret_cast<f32x4*>(smem + 4 * 64 * SB + i * 16) = g_gelu_lut[i];
+            *reinterpret_cast<float2*>(smem + 4 * 64 * SB + i * 8) = g_gelu_lut[i];
         __syncthreads();
     }
     char* slab2 = smem + 2 * 64 * SB + g * (64 * SB);  // second bf16 slab (GELU: gelu' side band)
@@ -464,14 +480,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                     const int off = (16 * i + fr) * SB + (64 * wc + 32 * ni + 16 * j + 4 * fq) * 2;
                     uint2 o;
                     if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
-                        float gl[4], dg[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) gelu_lut(lut, v[q], gl[q], dg[q]);
-                        o.x = pack_bf2(gl[0], gl[1]);
-                        o.y = pack_bf2(gl[2], gl[3]);
+                        f32x2 gl0, dg0, gl1, dg1;
+                        gelu_lut2(lut, f32x2{v[0], v[1]}, gl0, dg0);
+                        gelu_lut2(lut, f32x2{v[2], v[3]}, gl1, dg1);
+                        o.x = pack_bf2(gl0[0], gl0[1]);
+                        o.y = pack_bf2(gl1[0], gl1[1]);
                         uint2 d;
-                        d.x = pack_bf2(dg[0], dg[1]);
-                        d.y = pack_bf2(dg[2], dg[3]);
+                        d.x = pack_bf2(dg0[0], dg0[1]);
+                        d.y = pack_bf2(dg1[0], dg1[1]);
                         *reinterpret_cast<uint2*>(slab2 + off) = d;
                     } else {
                         o.x = pack_bf2(v[0], v[1]);
