@@ -220,6 +220,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
+    if world > 1:
+        torch.set_num_threads(2)  # N ranks share the host: the step has no CPU tensor math worth a wide intra-op pool
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
