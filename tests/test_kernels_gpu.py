@@ -181,7 +181,8 @@ def _attn_ref(qkv, B, S, heads, scale, bias):
 
 
 @pytest.mark.parametrize("B,S,heads,masked", [(3, 197, 12, False), (2, 133, 12, False), (5, 20, 8, True),
-                                              (2, 64, 2, False), (1, 33, 1, False), (2, 7, 3, True)])
+                                              (2, 64, 2, False), (1, 33, 1, False), (2, 7, 3, True),
+                                              (2, 224, 2, True), (3, 1, 2, False), (1, 193, 1, True)])  # max S, S = 1
 def test_attention_fwd_bwd(ops, B, S, heads, masked):
     H = heads * 64
     qkv = dev(rnd(B * S, 3 * H + 64, seed=1).bfloat16())[:, :3 * H]
@@ -235,6 +236,16 @@ def test_attention_leading_query_rows_only(ops, B, S, heads, q_rows):
     assert (part.view(B, S, 3 * H)[:, nq:, :H] == 0).all()
     with pytest.raises(RuntimeError):
         ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse, q_rows=S + 1)
+
+
+def test_attention_rejects_unsupported_shapes(ops):
+    qkv = dev(rnd(2 * 225, 3 * 64, seed=1).bfloat16())
+    ctx = torch.empty(2 * 225, 64, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(2, 1, 225, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd(qkv, 2, 225, 1, 0.125, ctx, lse)  # S > 224
+    with pytest.raises(ValueError):
+        ops.attn_fwd(qkv.float(), 2, 225, 1, 0.125, ctx, lse)  # dtype
 
 
 # ------------------------------------------------------------------------------------------ embeddings / misc
