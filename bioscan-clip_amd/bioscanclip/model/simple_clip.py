@@ -17,6 +17,8 @@ from bioscanclip.model.language_encoder import LoRA_bert, load_pre_trained_bert
 
 
 _TOWER_STREAMS = __import__("os").environ.get("BSCLIP_TOWER_STREAMS", "1") != "0"
+# host enqueue order of the towers: the longer (image) tower first measured 45.40 vs 45.72 ms/step with DNA first
+_IMAGE_FIRST = __import__("os").environ.get("BSCLIP_IMAGE_FIRST", "1") == "1"
 _streams = {}
 
 
@@ -51,7 +53,9 @@ class SimpleCLIP(nn.Module):
         outs = [None, None, None]
         use_streams = _TOWER_STREAMS and sum(enc is not None for enc, _ in towers) > 1 and torch.cuda.is_available()
         cur = torch.cuda.current_stream() if use_streams else None
-        for k, (enc, x) in enumerate(towers):
+        order = (1, 0, 2) if _IMAGE_FIRST else (0, 1, 2)
+        for k in order:
+            enc, x = towers[k]
             if enc is None:
                 continue
             if use_streams and not isinstance(enc, Freeze_DNA_Encoder):
