@@ -1,5 +1,10 @@
+"""Runs the same training step with the tower streams on and off and lists every gradient tensor that is not bitwise equal
+between runs (how the shared lora_grad workspace race was found).  Diagnostic; the pytest version is
+tests/test_encoders_gpu.py::test_tower_streams_join_before_gradients_are_read."""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/bioscan-clip_amd"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "bioscan-clip_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
 import torch
 import test_encoders_gpu as T
 from oracle import synth
