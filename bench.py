@@ -196,6 +196,12 @@ def cpu_baseline(seconds_budget=20.0):
 
 
 def main():
+    # stdout carries exactly one line, the JSON result.  Native libraries print there too (RCCL writes a version banner to
+    # fd 1 when the first communicator is created), so fd 1 is pointed at stderr for the duration of the run and the result
+    # is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -316,7 +322,8 @@ def main():
               f"host cpu {host_cpu_s / a.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
