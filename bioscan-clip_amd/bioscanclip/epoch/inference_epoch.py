@@ -36,7 +36,10 @@ def get_feature_and_label(dataloader, model, device, type_of_feature="dna", for_
             else:
                 out = encoder({"input_ids": input_ids.to(device), "token_type_ids": token_type_ids.to(device),
                                "attention_mask": attention_mask.to(device)})
-            features.append(HF.l2_normalize(out.float()))
+            # the reference normalises only on its single-process branch; under multi_gpu=True it keeps model.module's raw
+            # output for dna / image (inference_epoch.py:36-54) -- the text branch always normalises (:58)
+            raw = multi_gpu and type_of_feature != "text"
+            features.append(out.float() if raw else HF.l2_normalize(out.float()))
             label_list += convert_label_dict_to_list_of_dict(label_batch)
             file_name_list += list(processid_batch)
     if not features:
