@@ -14,6 +14,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from bioscanclip.model.arch import BertForMaskedLMParams, barcode_bert_config
+from bioscanclip.model.lora import LoRAContainer
 
 
 def kmer_vocab(k=5):
@@ -70,62 +71,30 @@ class _LoRALayer(nn.Module):
         raise RuntimeError("_LoRALayer is evaluated inside the fused HIP QKV GEMM; call the LoRA_* encoder instead")
 
 
-def _lora_surgery(owner, layers, r, lora_layer):
-    """Shared by ``LoRA_barcode_bert`` / ``LoRA_bert`` (dna_encoder.py:73-88, language_encoder.py:56-72)."""
-    for layer_idx, layer in enumerate(layers):
-        if layer_idx not in lora_layer:
-            continue
-        w_q_linear = layer.attention.self.query
-        w_v_linear = layer.attention.self.value
-        dim = layer.attention.self.query.in_features
-        w_a_linear_q = nn.Linear(dim, r, bias=False)
-        w_b_linear_q = nn.Linear(r, dim, bias=False)
-        w_a_linear_v = nn.Linear(dim, r, bias=False)
-        w_b_linear_v = nn.Linear(r, dim, bias=False)
-        owner.w_As.append(w_a_linear_q)
-        owner.w_Bs.append(w_b_linear_q)
-        owner.w_As.append(w_a_linear_v)
-        owner.w_Bs.append(w_b_linear_v)
-        layer.attention.self.query = _LoRALayer(w_q_linear, w_a_linear_q, w_b_linear_q)
-        layer.attention.self.value = _LoRALayer(w_v_linear, w_a_linear_v, w_b_linear_v)
+def _lora_surgery(owner, layers):
+    """Wrap ``attention.self.query`` / ``.value`` of the adapted BERT layers (dna_encoder.py:73-88, language_encoder.py:56-72)."""
+    for index, layer in enumerate(layers):
+        if index in owner.lora_layer:
+            attn = layer.attention.self
+            a_q, b_q, a_v, b_v = owner._adapt(attn.query.in_features)
+            attn.query = _LoRALayer(attn.query, a_q, b_q)
+            attn.value = _LoRALayer(attn.value, a_v, b_v)
 
 
-class LoRA_barcode_bert(nn.Module):
+class LoRA_barcode_bert(LoRAContainer):
+    """``LoRA_barcode_bert(model, r, num_classes, lora_layer)`` of the reference (dna_encoder.py:52-105)."""
+
     def __init__(self, model, r: int, num_classes: int = 0, lora_layer=None):
-        super(LoRA_barcode_bert, self).__init__()
-
-        assert r > 0
-        self.r = r
-        # reference dna_encoder.py:57-60 -- ``is not None`` so ``[]`` means "no LoRA" (SURVEY App. B-3)
-        if lora_layer is not None:
-            self.lora_layer = lora_layer
-        else:
-            self.lora_layer = list(range(len(model.bert.encoder.layer)))
-
-        self.w_As = []
-        self.w_Bs = []
-
-        for param in model.parameters():
-            param.requires_grad = False
-
-        _lora_surgery(self, model.bert.encoder.layer, r, self.lora_layer)
+        super().__init__()
+        layers = model.bert.encoder.layer
+        # only ``None`` means "every layer" here; ``[]`` adapts none (dna_encoder.py:57-60, SURVEY App. B-3)
+        self._begin(model, r, lora_layer if lora_layer is not None else list(range(len(layers))))
+        _lora_surgery(self, layers)
         self.reset_parameters()
         self.lora_barcode_bert = model
-
-        if num_classes > 0:
-            self.lora_barcode_bert.cls.predictions.decoder = nn.Linear(
-                self.lora_barcode_bert.cls.predictions.decoder.in_features, num_classes)
-        self._engine = None
-
-    def reset_parameters(self) -> None:
-        for w_A in self.w_As:
-            nn.init.kaiming_uniform_(w_A.weight, a=math.sqrt(5))
-        for w_B in self.w_Bs:
-            nn.init.zeros_(w_B.weight)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._engine = None
-        return super()._load_from_state_dict(*args, **kwargs)
+        if num_classes > 0:  # a fresh trainable decoder replaces the tied MLM decoder (dna_encoder.py:93-95)
+            head = model.cls.predictions
+            head.decoder = nn.Linear(head.decoder.in_features, num_classes)
 
     def forward(self, x: Tensor) -> Tensor:
         from bioscanclip.hip.bert_engine import barcode_bert_forward

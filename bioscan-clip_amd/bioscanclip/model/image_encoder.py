@@ -7,11 +7,10 @@ branch folded into the QKV GEMM's K dimension -> LN -> token 0 -> head) to the h
 (``bioscanclip.hip``).  There is no torch fallback: on a machine without the built HIP library the call
 raises.
 """
-import math
-
-import torch
 import torch.nn as nn
 from torch import Tensor
+
+from bioscanclip.model.lora import LoRAContainer
 
 
 class _LoRA_qkv_timm(nn.Module):
@@ -34,57 +33,26 @@ class _LoRA_qkv_timm(nn.Module):
         raise RuntimeError("_LoRA_qkv_timm is evaluated inside the fused HIP QKV GEMM; call LoRA_ViT_timm instead")
 
 
-class LoRA_ViT_timm(nn.Module):
+class LoRA_ViT_timm(LoRAContainer):
+    """``LoRA_ViT_timm(vit_model, r, num_classes, lora_layer)`` of the reference (image_encoder.py:51-109)."""
+
     def __init__(self, vit_model, r: int, num_classes: int = 0, lora_layer=None):
-        super(LoRA_ViT_timm, self).__init__()
-
-        assert r > 0
-        self.r = r
-        # reference image_encoder.py:56-59 -- NB ``if lora_layer:`` so ``[]`` means "all layers" 
-        if lora_layer:
-            self.lora_layer = lora_layer
-        else:
-            self.lora_layer = list(range(len(vit_model.blocks)))
-
-        self.w_As = []  # plain lists, as in the reference (not ModuleList; App. A.5)
-        self.w_Bs = []
-
-        for param in vit_model.parameters():
-            param.requires_grad = False
-
-        for t_layer_i, blk in enumerate(vit_model.blocks):
-            if t_layer_i not in self.lora_layer:
-                continue
-            w_qkv_linear = blk.attn.qkv
-            self.dim = w_qkv_linear.in_features
-            w_a_linear_q = nn.Linear(self.dim, r, bias=False)
-            w_b_linear_q = nn.Linear(r, self.dim, bias=False)
-            w_a_linear_v = nn.Linear(self.dim, r, bias=False)
-            w_b_linear_v = nn.Linear(r, self.dim, bias=False)
-            self.w_As.append(w_a_linear_q)
-            self.w_Bs.append(w_b_linear_q)
-            self.w_As.append(w_a_linear_v)
-            self.w_Bs.append(w_b_linear_v)
-            blk.attn.qkv = _LoRA_qkv_timm(w_qkv_linear, w_a_linear_q, w_b_linear_q, w_a_linear_v, w_b_linear_v)
+        super().__init__()
+        # a falsy ``lora_layer`` (None or []) adapts every block (image_encoder.py:56-59, SURVEY App. B-3)
+        self._begin(vit_model, r, lora_layer if lora_layer else list(range(len(vit_model.blocks))))
+        for index, block in enumerate(vit_model.blocks):
+            if index in self.lora_layer:
+                fused_qkv = block.attn.qkv
+                self.dim = fused_qkv.in_features
+                block.attn.qkv = _LoRA_qkv_timm(fused_qkv, *self._adapt(self.dim))
         self.reset_parameters()
         self.lora_vit = vit_model
         if num_classes > 0:
-            self.lora_vit.reset_classifier(num_classes=num_classes)
-        self._engine = None
+            self.reset_classifier(num_classes)
 
     def reset_classifier(self, num_classes):
         self.lora_vit.reset_classifier(num_classes=num_classes)
         self._engine = None
-
-    def reset_parameters(self) -> None:
-        for w_A in self.w_As:
-            nn.init.kaiming_uniform_(w_A.weight, a=math.sqrt(5))
-        for w_B in self.w_Bs:
-            nn.init.zeros_(w_B.weight)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._engine = None  # frozen weights are re-packed to bf16 on the next forward
-        return super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x: Tensor) -> Tensor:
         from bioscanclip.hip.vit_engine import vit_forward

@@ -12,6 +12,7 @@ from torch import Tensor
 
 from bioscanclip.model.arch import BertModelParams, bert_small_config
 from bioscanclip.model.dna_encoder import _LoRALayer, _lora_surgery  # noqa: F401  (same class in the reference)
+from bioscanclip.model.lora import LoRAContainer
 
 
 def load_pre_trained_bert(checkpoint=None):
@@ -28,40 +29,18 @@ def load_pre_trained_bert(checkpoint=None):
     return None, model
 
 
-class LoRA_bert(nn.Module):
+class LoRA_bert(LoRAContainer):
+    """``LoRA_bert(model, r, num_classes, lora_layer)`` of the reference (language_encoder.py:36-89)."""
+
     def __init__(self, model, r: int, num_classes: int = 0, lora_layer=None):
-        super(LoRA_bert, self).__init__()
-
-        assert r > 0
-        self.r = r
-        if lora_layer is not None:
-            self.lora_layer = lora_layer
-        else:
-            self.lora_layer = list(range(len(model.encoder.layer)))
-
-        self.w_As = []
-        self.w_Bs = []
-
-        for param in model.parameters():
-            param.requires_grad = False
-
-        _lora_surgery(self, model.encoder.layer, r, self.lora_layer)
+        super().__init__()
+        layers = model.encoder.layer
+        self._begin(model, r, lora_layer if lora_layer is not None else list(range(len(layers))))
+        _lora_surgery(self, layers)
         self.reset_parameters()
         self.lora_bert = model
-
-        if num_classes > 0:
-            self.proj = nn.Linear(self.lora_bert.pooler.dense.out_features, num_classes)
-        self._engine = None
-
-    def reset_parameters(self) -> None:
-        for w_A in self.w_As:
-            nn.init.kaiming_uniform_(w_A.weight, a=math.sqrt(5))
-        for w_B in self.w_Bs:
-            nn.init.zeros_(w_B.weight)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._engine = None
-        return super()._load_from_state_dict(*args, **kwargs)
+        if num_classes > 0:  # trainable projection of the token mean into the shared space (language_encoder.py:76-77)
+            self.proj = nn.Linear(model.pooler.dense.out_features, num_classes)
 
     def forward(self, x) -> Tensor:
         from bioscanclip.hip.bert_engine import bert_text_forward
