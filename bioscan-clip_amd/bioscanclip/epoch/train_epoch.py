@@ -1,13 +1,14 @@
-"""Training epoch driver -- drop-in for reference ``bioscanclip/epoch/train_epoch.py:11-61`` (same signature and
-loop body: H2D, zero_grad, forward, loss, backward, optimizer.step, scheduler.step per iteration).
+"""Training epoch driver with the reference's signature (``bioscanclip/epoch/train_epoch.py:11-61``).
 
-Differences, all deliberate: autograd anomaly mode is not switched on; ``loss.item()`` is read once
-per step (the reference syncs three times); wandb/tqdm are optional; with a process group of world_size > 1 the
-flat trainable gradients are all-reduced (SUM) before the optimizer step.
+Per batch, in the reference's order: inputs to the device, ``optimizer.zero_grad()``, ``model(image, dna, text)``,
+``criterion(...)``, ``backward()``, ``optimizer.step()``, ``scheduler.step()``.  What differs, deliberately:
+autograd anomaly mode stays off, the loss is read back once per step (the reference synchronises three times), tqdm / wandb
+are optional, and under a process group of more than one rank the flat trainable gradients are all-reduced (SUM) before the
+optimizer step.  Returns the mean loss of the epoch.
 """
 import torch
 
-try:  # optional, as in SURVEY 5 (neither ships in this image)
+try:  # neither ships in this image
     from tqdm import tqdm
 except Exception:  # pragma: no cover
     tqdm = None
@@ -17,54 +18,50 @@ except Exception:  # pragma: no cover
     wandb = None
 
 
+def _to_device(batch, device):
+    """The reference's 7-tuple ``(processid, image, dna, input_ids, token_type_ids, attention_mask, label)`` -> model inputs."""
+    _, image, dna, input_ids, token_type_ids, attention_mask, label = batch
+    text = None
+    if input_ids is not None:
+        text = {"input_ids": input_ids.to(device), "token_type_ids": token_type_ids.to(device),
+                "attention_mask": attention_mask.to(device)}
+    image = None if image is None else image.to(device)
+    dna = None if dna is None else dna.to(device)
+    return image, dna, text, label.to(device)
+
+
 def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimizer, criterion, device, scheduler=None,
                 for_open_clip=False, rank=None, check_cuda_memory=False):
     from bioscanclip.hip import dist as hdist
     if for_open_clip:
         raise NotImplementedError("the open_clip branch is not part of the HIP-accelerated path")
-    if rank == 0 and tqdm is not None:
-        pbar = tqdm(enumerate(dataloader), total=len(dataloader))
-    else:
-        pbar = enumerate(dataloader)
-    epoch_loss = 0.0
-    total_step = len(dataloader)
+    n_steps = len(dataloader)
+    show = rank == 0 and tqdm is not None
+    steps = tqdm(enumerate(dataloader), total=n_steps) if show else enumerate(dataloader)
+    running = 0.0
 
     model.train()
-    for step, batch in pbar:
-        processid_batch, image_input_batch, dna_input_batch, input_ids, token_type_ids, attention_mask, label_for_train_batch = batch
-        language_input = None
-        if input_ids is not None:
-            language_input = {'input_ids': input_ids.to(device), 'token_type_ids': token_type_ids.to(device),
-                              'attention_mask': attention_mask.to(device)}
+    for step, batch in steps:
+        image, dna, text, label = _to_device(batch, device)
         optimizer.zero_grad()
-        image_input_batch = image_input_batch.to(device) if image_input_batch is not None else None
-        dna_input_batch = dna_input_batch.to(device) if dna_input_batch is not None else None
-        image_output, dna_output, language_output = model(image_input_batch, dna_input_batch, language_input)
-
-        label_for_train_batch = label_for_train_batch.to(device)
-
-        loss = criterion(image_output, dna_output, language_output, label_for_train_batch)
+        loss = criterion(*model(image, dna, text), label)
         loss.backward()
-        hdist.allreduce_grads(model)
-
+        hdist.allreduce_grads(model)  # no-op without a multi-rank process group
         if hasattr(optimizer, "attach") and not getattr(optimizer, "_flats", None):
-            optimizer.attach(model)
+            optimizer.attach(model)  # FusedAdamW: adopt the engines' flat buffers once they exist
         optimizer.step()
         if scheduler is not None:
             scheduler.step()
 
-        loss_value = loss.item()
-        epoch_loss = epoch_loss + loss_value
-        current_lr = optimizer.param_groups[0]['lr']
-
-        if rank == 0 and tqdm is not None:
-            mem = ""
-            if check_cuda_memory:
-                mem = f" || Allocated: {torch.cuda.memory_allocated() / (1024 ** 3):.2f} GB"
-            pbar.set_description(f'Epoch: {epoch}||Step: {step}/{total_step}||Loss: {loss_value}{mem} || Current LR: {current_lr}')
-
+        value = loss.item()  # the step's only host synchronisation
+        running += value
+        lr = optimizer.param_groups[0]["lr"]
+        if show:
+            mem = f" || Allocated: {torch.cuda.memory_allocated() / 2 ** 30:.2f} GB" if check_cuda_memory else ""
+            steps.set_description(f"Epoch: {epoch}||Step: {step}/{n_steps}||Loss: {value}{mem} || Current LR: {lr}")
         if activate_wandb and wandb is not None:
-            wandb.log({"loss": loss_value, "step": step + epoch * len(dataloader), "learning_rate": current_lr})
+            wandb.log({"loss": value, "step": step + epoch * n_steps, "learning_rate": lr})
 
-    print(f'Epoch [{epoch}/{total_epochs}], Loss: {epoch_loss / max(len(dataloader), 1)}')
-    return epoch_loss / max(len(dataloader), 1)
+    mean_loss = running / max(n_steps, 1)
+    print(f"Epoch [{epoch}/{total_epochs}], Loss: {mean_loss}")
+    return mean_loss
