@@ -1,0 +1,1 @@
+"""model package of the MI355X-native BIOSCAN-CLIP hot path."""

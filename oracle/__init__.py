@@ -1,0 +1,1 @@
+"""oracle package of the MI355X-native BIOSCAN-CLIP hot path."""
