@@ -29,6 +29,7 @@ SIGNATURES = {
     "bsclip_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P]),
     "bsclip_init_tables": (I, [P]),
     "bsclip_gemm_set_tile": (I, [I]),
+    "bsclip_gemm_diag_ablate": (I, [I]),
     "bsclip_gemm_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, P]),
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, P]),

@@ -281,7 +281,9 @@ __device__ __forceinline__ void gelu_lut2(const char* lut, f32x2 x, f32x2& gl, f
 //        of the next tile), i.e. >= 2 barrier instants after the slower group's reads have been waited for.
 //   RAW  every wave waits (vmcnt) for its own DMA pieces of tile t+1 BEFORE the first barrier of phase 3; the first
 //        reads of tile t+1 (phase 0) come after at least one more barrier for both groups.
-template <int EPI, bool HAS_BIAS, bool DIAG = false>
+// ABL (diagnostic builds only): ablation mask for tools/gemm_ablate.py -- 1: no MFMA, 2: no LDS fragment reads, 4: no DMA,
+// 8: no barriers.  Results are garbage then; only the K-loop time is of interest.
+template <int EPI, bool HAS_BIAS, bool DIAG = false, int ABL = 0, bool DEEP = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restrict__ A, int lda,
                                                           const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                           int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
@@ -310,11 +312,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         }
     const int dma_off = wave * 1024;  // + i*8192 + half*HALF (+ B_OFF) + set*SET
     auto dmaA = [&](int set, int h, int k0) {
+        if constexpr (ABL & 4) return;
         char* d = smem + set * SET + h * HALF + dma_off;
         glds16(srcA[h][0] + k0, d);
         glds16(srcA[h][1] + k0, d + 8192);
     };
     auto dmaB = [&](int set, int h, int k0) {
+        if constexpr (ABL & 4) return;
         char* d = smem + set * SET + B_OFF + h * HALF + dma_off;
         glds16(srcB[h][0] + k0, d);
         glds16(srcB[h][1] + k0, d + 8192);
@@ -338,7 +342,19 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 
     bf16x8 fa[2][2][4];  // [m block][ks][row tile]
     bf16x8 fb[2][2][2];  // [n block][ks][col tile]
+    if constexpr (ABL & 2) {  // fragments must still hold something defined
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[a][k][i] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[a][k][j] = bf16x8{8, 7, 6, 5, 4, 3, 2, 1};
+            }
+    }
     auto readA = [&](const char* base, int mi) {
+        if constexpr (ABL & 2) return;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -346,6 +362,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 fa[mi][ks][i] = *reinterpret_cast<const bf16x8*>(base + ((a_off ^ (ks << 6)) + (64 * mi + 16 * i) * ROW_BYTES));
     };
     auto readB = [&](const char* base, int ni) {
+        if constexpr (ABL & 2) return;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -353,6 +370,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 fb[ni][ks][j] = *reinterpret_cast<const bf16x8*>(base + ((b_off ^ (ks << 6)) + (32 * ni + 16 * j) * ROW_BYTES));
     };
     auto mma = [&](int mi, int ni) {
+        if constexpr (ABL & 1) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -363,11 +381,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                     acc[mi][ni][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni][ks][j], fa[mi][ks][i], acc[mi][ni][i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-#define PP_BARRIER()                          \
-    do {                                      \
-        __builtin_amdgcn_sched_barrier(0);    \
-        __builtin_amdgcn_s_barrier();         \
-        __builtin_amdgcn_sched_barrier(0);    \
+#define PP_BARRIER()                                           \
+    do {                                                       \
+        __builtin_amdgcn_sched_barrier(0);                     \
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier(); \
+        __builtin_amdgcn_sched_barrier(0);                     \
     } while (0)
 
     auto stamp = [&](int i) {
@@ -377,55 +395,123 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     };
     stamp(0);
     const int nk = K / BK;
-    // ---- prologue: tile 0 complete, plus the first piece of tile 1 (the "phase 3 of tile -1" slot) ----
-    dmaA(0, 0, 0);
-    dmaA(0, 1, 0);
-    dmaB(0, 0, 0);
-    dmaB(0, 1, 0);
-    if (nk > 1) {
-        dmaA(1, 0, BK);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    PP_BARRIER();
-    if (g == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
-    stamp(1);
-
-    for (int t = 0; t < nk; ++t) {
-        const int set = t & 1;
-        const char* base = smem + set * SET;
-        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
-        const int k1 = (t + 1) * BK, k2 = (t + 2) * BK;
-        // ---- phase 0 ----
-        if (has1) dmaA(set ^ 1, 1, k1);
-        readA(base, 0);
-        readB(base, 0);
-        PP_BARRIER();
-        mma(0, 0);
-        PP_BARRIER();
-        // ---- phase 1 ----
-        if (has1) dmaB(set ^ 1, 0, k1);
-        readA(base, 1);
-        PP_BARRIER();
-        mma(1, 0);
-        PP_BARRIER();
-        // ---- phase 2 ----
-        if (has1) dmaB(set ^ 1, 1, k1);
-        readB(base, 1);
-        PP_BARRIER();
-        mma(1, 1);
-        PP_BARRIER();
-        // ---- phase 3 ----
-        if (has2) {
-            dmaA(set, 0, k2);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // everything of tile t+1 has landed; A-half0(t+2) may fly
+    if constexpr (DEEP) {
+        // Deep-prefetch variant, kept for comparison (bsclip_gemm_set_tile(6)); NOT the default.  tools/gemm_ablate.py shows the
+        // K loop bound as much by the LDS-DMA stream as by the matrix pipe (DMA + barriers alone 1.1 us per K-tile, MFMA +
+        // barriers alone 1.0, both 1.45).  If the DMA side were latency x bytes in flight, refilling a set with tile t+2 as
+        // soon as tile t has been read out of it -- A after phase 1, B after phase 2, ~100 KB per CU in flight instead of ~40 --
+        // would fix it.  It does not: DMA + barriers alone stay at 1.05 us per K-tile (a throughput limit of the L2 -> LDS path,
+        // ~61 GB/s per CU) and the full loop gets slower (1.56 us), so the one-tile-ahead schedule below remains in use.
+        // WAR: group 1 runs one barrier instant behind group 0.  A[set] is last read in phase 1; group 1's reads are waited for
+        //      before its mma(1,0), i.e. before global instant b4 (the barrier group 0 passes after its phase-2 reads), and A
+        //      DMAs are issued after that barrier (group 1: after its own, one instant later).  B[set] is last read in phase 2,
+        //      complete by b6; B DMAs are issued after the phase-3 barrier.
+        // RAW: before the phase-3 barrier every wave waits until only its 4 newest DMA instructions (A of tile t+2) are
+        //      outstanding: VMEM returns in order, so all its pieces of tile t+1 have landed; tile t+1 is first read after at
+        //      least one more barrier by either group.
+        dmaA(0, 0, 0);
+        dmaA(0, 1, 0);
+        dmaB(0, 0, 0);
+        dmaB(0, 1, 0);
+        if (nk > 1) {
+            dmaA(1, 0, BK);
+            dmaA(1, 1, BK);
+            dmaB(1, 0, BK);
+            dmaB(1, 1, BK);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         PP_BARRIER();
-        mma(0, 1);
+        if (g == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
+        stamp(1);
+        for (int t = 0; t < nk; ++t) {
+            const int set = t & 1;
+            const char* base = smem + set * SET;
+            const bool has2 = t + 2 < nk;
+            const int k2 = (t + 2) * BK;
+            // ---- phase 0 ----
+            readA(base, 0);
+            readB(base, 0);
+            PP_BARRIER();
+            mma(0, 0);
+            PP_BARRIER();
+            // ---- phase 1 ----
+            readA(base, 1);
+            PP_BARRIER();
+            mma(1, 0);
+            PP_BARRIER();
+            // ---- phase 2 ----
+            readB(base, 1);
+            PP_BARRIER();
+            if (has2) {
+                dmaA(set, 0, k2);
+                dmaA(set, 1, k2);
+            }
+            mma(1, 1);
+            PP_BARRIER();
+            // ---- phase 3 ----
+            if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile t+1 complete; A of tile t+2 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            if (has2) {
+                dmaB(set, 0, k2);
+                dmaB(set, 1, k2);
+            }
+            mma(0, 1);
+            PP_BARRIER();
+        }
+    } else {
+        // ---- prologue: tile 0 complete, plus the first piece of tile 1 (the "phase 3 of tile -1" slot) ----
+        dmaA(0, 0, 0);
+        dmaA(0, 1, 0);
+        dmaB(0, 0, 0);
+        dmaB(0, 1, 0);
+        if (nk > 1) {
+            dmaA(1, 0, BK);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         PP_BARRIER();
+        if (g == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
+        stamp(1);
+
+        for (int t = 0; t < nk; ++t) {
+            const int set = t & 1;
+            const char* base = smem + set * SET;
+            const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            const int k1 = (t + 1) * BK, k2 = (t + 2) * BK;
+            // ---- phase 0 ----
+            if (has1) dmaA(set ^ 1, 1, k1);
+            readA(base, 0);
+            readB(base, 0);
+            PP_BARRIER();
+            mma(0, 0);
+            PP_BARRIER();
+            // ---- phase 1 ----
+            if (has1) dmaB(set ^ 1, 0, k1);
+            readA(base, 1);
+            PP_BARRIER();
+            mma(1, 0);
+            PP_BARRIER();
+            // ---- phase 2 ----
+            if (has1) dmaB(set ^ 1, 1, k1);
+            readB(base, 1);
+            PP_BARRIER();
+            mma(1, 1);
+            PP_BARRIER();
+            // ---- phase 3 ----
+            if (has2) {
+                dmaA(set, 0, k2);
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // everything of tile t+1 has landed; A-half0(t+2) may fly
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PP_BARRIER();
+            mma(0, 1);
+            PP_BARRIER();
+        }
     }
     if (g == 0) PP_BARRIER();  // balance group 1's extra barrier
 #undef PP_BARRIER
@@ -597,6 +683,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 }
 
 int g_tile_override = 0;
+int g_diag_ablate = 0;  // tools/gemm_ablate.py: which parts of the K loop the diagnostic EPI_BF16 build leaves out
 
 template <int BM, int BN, int WM, int WN, int EPI, bool HB>
 void launch_cfg(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -608,7 +695,7 @@ void launch_cfg(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
 
 bool g_lut_ready = false;
 
-template <int EPI, bool HB>
+template <int EPI, bool HB, bool DEEP = false>
 void launch_pp(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
                const EpiArgs& e, hipStream_t s) {
     if (EPI == BSCLIP_EPI_GELU_BF16 && !g_lut_ready) {  // once per process, stream-ordered ahead of the first consumer
@@ -616,8 +703,8 @@ void launch_pp(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int 
         g_lut_ready = true;
     }
     const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, HB>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, lda, B, ldb, C, ldc, M,
-                       N, K, tiles_n, e);
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, HB, false, 0, DEEP>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, lda, B,
+                       ldb, C, ldc, M, N, K, tiles_n, e);
 }
 
 template <int EPI, bool HB>
@@ -633,9 +720,10 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
         if (N % 256 == 0 && t256 >= 192) tile = 4;
         else tile = 1;
     }
-    if ((tile == 3 || tile == 4) && N % 256 != 0) tile = 2;
+    if ((tile == 3 || tile == 4 || tile == 6) && N % 256 != 0) tile = 2;
     switch (tile) {
         case 4: launch_pp<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
+        case 6: launch_pp<EPI, HB, true>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // two-tiles-ahead DMA (comparison)
         case 3: launch_cfg<256, 256, 2, 4, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
         case 2: launch_cfg<256, 128, 4, 2, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
         default: launch_cfg<128, 128, 2, 2, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
@@ -673,7 +761,16 @@ extern "C" int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, 
     const bf16_t* b = static_cast<const bf16_t*>(B);
     switch (epilogue) {
         case BSCLIP_EPI_BF16:
-            hipLaunchKernelGGL((gemm_nt_pp_kernel<BSCLIP_EPI_BF16, false, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
+#define DIAG_ABL(mask)                                                                                                      \
+    case mask:                                                                                                             \
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<BSCLIP_EPI_BF16, false, true, mask>), grid, block, 0, s, a, lda, b, ldb, C, ldc, \
+                           M, N, K, tiles_n, e);                                                                           \
+        break;
+            switch (g_diag_ablate) {
+                DIAG_ABL(0) DIAG_ABL(1) DIAG_ABL(2) DIAG_ABL(4) DIAG_ABL(8) DIAG_ABL(6) DIAG_ABL(3) DIAG_ABL(5) DIAG_ABL(9)
+                default: BSCLIP_REQUIRE(false, "bsclip_gemm_diag: ablation mask %d not instantiated", g_diag_ablate);
+            }
+#undef DIAG_ABL
             break;
         case BSCLIP_EPI_GELU_BF16:
             hipLaunchKernelGGL((gemm_nt_pp_kernel<BSCLIP_EPI_GELU_BF16, true, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
@@ -701,8 +798,14 @@ extern "C" int bsclip_init_tables(void* stream) {
 }
 
 extern "C" int bsclip_gemm_set_tile(int tile) {
-    BSCLIP_REQUIRE(tile >= 0 && tile <= 4, "bsclip_gemm_set_tile: tile %d not in [0,4]", tile);
+    BSCLIP_REQUIRE(tile >= 0 && tile <= 6 && tile != 5, "bsclip_gemm_set_tile: tile %d not in {0,1,2,3,4,6}", tile);
     g_tile_override = tile;
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_gemm_diag_ablate(int mask) {
+    BSCLIP_REQUIRE(mask >= 0 && mask < 16, "bsclip_gemm_diag_ablate: mask %d", mask);
+    g_diag_ablate = mask;
     return BSCLIP_OK;
 }
 

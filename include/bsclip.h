@@ -61,10 +61,14 @@ int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, in
 /* one-time device tables (GELU Phi/phi table of the 256x256 kernel's epilogue).  bsclip_gemm_bf16 fills them lazily on
  * its own stream; call this once (and synchronise) before launching GEMMs from several streams. */
 int bsclip_init_tables(void* stream);
-/* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 */
+/* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x256 ping-pong, 6 = the same with
+ * the LDS-DMA two K-tiles ahead instead of one (slower; kept for comparison) */
 int bsclip_gemm_set_tile(int tile);
 /* diagnostic build of the 256x256 kernel: per-workgroup phase stamps (start, prologue, K loop, end) in 100 MHz ticks,
  * diag[grid * 16]; tools/gemm_phases.py.  Never used by the product path. */
+/* which parts of the K loop the diagnostic EPI_BF16 build leaves out (1 MFMA, 2 LDS reads, 4 DMA, 8 barriers; sums of two
+ * for the instantiated pairs): timing experiments only, results are garbage.  tools/gemm_ablate.py */
+int bsclip_gemm_diag_ablate(int mask);
 int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream);
 
