@@ -255,6 +255,41 @@ def test_train_cl_epoch_with_eval_phase(tmp_path, capsys):
     assert keys == {k for k in load_golden("state_dict_keys")["keys"] if not k.startswith("language_encoder.")}
 
 
+def test_training_on_a_fixed_batch_drives_the_loss_down():
+    """End-to-end sanity beyond step-wise parity: 60 AdamW steps on one fixed synthetic batch (dropout at the HF defaults, i.e.
+    the benchmark configuration) must overfit it -- the loss falls well below its start and no gradient or activation turns
+    non-finite; the flat buffers and workspaces are reused from step to step (allocated memory stays put)."""
+    from bioscanclip.hip.optim import FusedAdamW
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from bioscanclip.model.loss_func import ContrastiveLoss
+    from bioscanclip.model.simple_clip import SimpleCLIP
+    torch.manual_seed(5)
+    model = SimpleCLIP(LoRA_ViT_timm(arch.VisionTransformerParams(depth=4), r=4, num_classes=768),
+                       LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=4)), r=4,
+                                         num_classes=768), None).to("cuda").train()
+    image, dna, _, label = synth.synth_batch(32, seed=77)
+    image, dna, label = image.cuda(), dna.cuda(), label.cuda()
+    crit = ContrastiveLoss(criterion=torch.nn.CrossEntropyLoss(), logit_scale=1 / 0.07)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    losses, mem = [], []
+    for s in range(60):
+        opt.zero_grad()
+        loss = crit(*model(image, dna, None), label)
+        loss.backward()
+        if s == 0:
+            opt.attach(model)
+        opt.step()
+        if s % 10 == 0 or s == 59:
+            losses.append(loss.item())
+            mem.append(torch.cuda.memory_allocated())
+    _log({"test": "fixed-batch training", "losses": losses})
+    assert all(l == l for l in losses) and losses[-1] < 0.5 * losses[0], losses
+    assert max(mem[1:]) - min(mem[1:]) < 64 * 2 ** 20, mem
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
 def test_requires_gpu_inputs():
     from bioscanclip.model import arch
     from bioscanclip.model.image_encoder import LoRA_ViT_timm
