@@ -283,7 +283,7 @@ __device__ __forceinline__ void gelu_lut2(const char* lut, f32x2 x, f32x2& gl, f
 //        reads of tile t+1 (phase 0) come after at least one more barrier for both groups.
 // ABL (diagnostic builds only): ablation mask for tools/gemm_ablate.py -- 1: no MFMA, 2: no LDS fragment reads, 4: no DMA,
 // 8: no barriers.  Results are garbage then; only the K-loop time is of interest.
-template <int EPI, bool HAS_BIAS, bool DIAG = false, int ABL = 0, bool DEEP = false>
+template <int EPI, bool HAS_BIAS, bool DIAG = false, int ABL = 0, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restrict__ A, int lda,
                                                           const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                           int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     };
     stamp(0);
     const int nk = K / BK;
-    if constexpr (DEEP) {
+    if constexpr (SCHED == 1) {
         // Deep-prefetch variant, kept for comparison (bsclip_gemm_set_tile(6)); NOT the default.  tools/gemm_ablate.py shows the
         // K loop bound as much by the LDS-DMA stream as by the matrix pipe (DMA + barriers alone 1.1 us per K-tile, MFMA +
         // barriers alone 1.0, both 1.45).  If the DMA side were latency x bytes in flight, refilling a set with tile t+2 as
@@ -461,6 +461,92 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             mma(0, 1);
             PP_BARRIER();
         }
+    } else if constexpr (SCHED == 2) {
+        // Four barriers per K-tile ("half-barrier ping-pong", experimental: bsclip_gemm_set_tile(7)).  One s_barrier per phase,
+        // call it b(t,p); group 0 runs   reads(p) | b(t,p) | mma(p)   and group 1 runs   b(t,p) | reads(p), mma(p),   so between
+        // two barriers group 0 does [mma(p), reads(p+1)] while group 1 does [reads(p), mma(p)]: matrix beside LDS in each half.
+        // Reads of tile t: A blocks in phases 0 and 1, B blocks in phases 0 and 2.  Group 0 issues reads(p) before b(t,p) and
+        // waits for them after it; group 1 issues and waits between b(t,p) and b(t,p+1).  Hence every read of A[set(t)] is
+        // complete before b(t,2) and every read of B[set(t)] before b(t,3).
+        // WAR: A[set(t)] may be refilled (tile t+2) after b(t,2), B[set(t)] after b(t,3).
+        // RAW: group 0 reads tile t+1 between b(t,3) and b(t+1,0), so every wave waits for its own pieces of tile t+1 BEFORE
+        //      it calls b(t,3).  Group 0's code before b(t,3) is its phase-3 slot (as in the classic schedule); group 1's is the
+        //      end of its phase 2, so group 1 issues its pieces one phase earlier than group 0:
+        //        group 0, tile t:  ph0 A-half1(t+1)  ph1 B-half0(t+1)  ph2 B-half1(t+1)  ph3 A-half0(t+2), wait vmcnt(2)
+        //        group 1, tile t:  ph0 B-half0(t+1)  ph1 B-half1(t+1)  ph2 wait vmcnt(0)  ph3 A-half0(t+2), A-half1(t+2)
+        //      (group 1's phase-3 code runs after b(t,3) > b(t,2): A[set(t)] is free; its B pieces go out after b(t,0), b(t,1),
+        //      both later than b(t-1,3)).
+        dmaA(0, 0, 0);
+        dmaA(0, 1, 0);
+        dmaB(0, 0, 0);
+        dmaB(0, 1, 0);
+        if (nk > 1) {
+            dmaA(1, 0, BK);
+            if (g == 1) {
+                dmaA(1, 1, BK);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();  // tile 0 published
+        stamp(1);
+        // one code body for both groups (two copies of the loop spilled: 308 B of scratch per lane); only the barrier position
+        // and the DMA piece of each phase depend on the group
+#define BAR_G0() do { if (g == 0) PP_BARRIER(); } while (0)
+#define BAR_G1() do { if (g == 1) PP_BARRIER(); } while (0)
+        for (int t = 0; t < nk; ++t) {
+            const int set = t & 1;
+            const char* base = smem + set * SET;
+            const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            const int k1 = (t + 1) * BK, k2 = (t + 2) * BK;
+            // ---- phase 0 ----
+            BAR_G1();
+            if (has1) {
+                if (g == 0) dmaA(set ^ 1, 1, k1);
+                else dmaB(set ^ 1, 0, k1);
+            }
+            readA(base, 0);
+            readB(base, 0);
+            BAR_G0();
+            mma(0, 0);
+            // ---- phase 1 ----
+            BAR_G1();
+            if (has1) {
+                if (g == 0) dmaB(set ^ 1, 0, k1);
+                else dmaB(set ^ 1, 1, k1);
+            }
+            readA(base, 1);
+            BAR_G0();
+            mma(1, 0);
+            // ---- phase 2 ----
+            BAR_G1();
+            if (has1 && g == 0) dmaB(set ^ 1, 1, k1);
+            readB(base, 1);
+            BAR_G0();
+            mma(1, 1);
+            // ---- phase 3 ----
+            if (g == 0) {
+                if (has2) {
+                    dmaA(set, 0, k2);
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // tile t+1 landed; A-half0(t+2) may fly
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t+1 have landed
+            }
+            PP_BARRIER();  // b(t,3): the one barrier both groups call at the same point of their code
+            if (g == 1 && has2) {
+                dmaA(set, 0, k2);
+                dmaA(set, 1, k2);
+            }
+            mma(0, 1);
+        }
+#undef BAR_G0
+#undef BAR_G1
     } else {
         // ---- prologue: tile 0 complete, plus the first piece of tile 1 (the "phase 3 of tile -1" slot) ----
         dmaA(0, 0, 0);
@@ -513,7 +599,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             PP_BARRIER();
         }
     }
-    if (g == 0) PP_BARRIER();  // balance group 1's extra barrier
+    if constexpr (SCHED != 2) {
+        if (g == 0) PP_BARRIER();  // balance group 1's extra barrier
+    }
 #undef PP_BARRIER
     stamp(2);
 
@@ -695,7 +783,7 @@ void launch_cfg(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
 
 bool g_lut_ready = false;
 
-template <int EPI, bool HB, bool DEEP = false>
+template <int EPI, bool HB, int SCHED = 0>
 void launch_pp(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
                const EpiArgs& e, hipStream_t s) {
     if (EPI == BSCLIP_EPI_GELU_BF16 && !g_lut_ready) {  // once per process, stream-ordered ahead of the first consumer
@@ -703,7 +791,7 @@ void launch_pp(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int 
         g_lut_ready = true;
     }
     const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, HB, false, 0, DEEP>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, lda, B,
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, HB, false, 0, SCHED>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, lda, B,
                        ldb, C, ldc, M, N, K, tiles_n, e);
 }
 
@@ -720,10 +808,11 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
         if (N % 256 == 0 && t256 >= 192) tile = 4;
         else tile = 1;
     }
-    if ((tile == 3 || tile == 4 || tile == 6) && N % 256 != 0) tile = 2;
+    if ((tile == 3 || tile == 4 || tile == 6 || tile == 7) && N % 256 != 0) tile = 2;
     switch (tile) {
         case 4: launch_pp<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
-        case 6: launch_pp<EPI, HB, true>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // two-tiles-ahead DMA (comparison)
+        case 6: launch_pp<EPI, HB, 1>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // two-tiles-ahead DMA (comparison)
+        case 7: launch_pp<EPI, HB, 2>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // four barriers per K-tile (experimental)
         case 3: launch_cfg<256, 256, 2, 4, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
         case 2: launch_cfg<256, 128, 4, 2, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
         default: launch_cfg<128, 128, 2, 2, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
@@ -798,7 +887,7 @@ extern "C" int bsclip_init_tables(void* stream) {
 }
 
 extern "C" int bsclip_gemm_set_tile(int tile) {
-    BSCLIP_REQUIRE(tile >= 0 && tile <= 6 && tile != 5, "bsclip_gemm_set_tile: tile %d not in {0,1,2,3,4,6}", tile);
+    BSCLIP_REQUIRE(tile >= 0 && tile <= 7 && tile != 5, "bsclip_gemm_set_tile: tile %d not in {0,1,2,3,4,6,7}", tile);
     g_tile_override = tile;
     return BSCLIP_OK;
 }

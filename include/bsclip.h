@@ -62,7 +62,8 @@ int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, in
  * its own stream; call this once (and synchronise) before launching GEMMs from several streams. */
 int bsclip_init_tables(void* stream);
 /* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x256 ping-pong, 6 = the same with
- * the LDS-DMA two K-tiles ahead instead of one (slower; kept for comparison) */
+ * the LDS-DMA two K-tiles ahead instead of one (slower), 7 = the same with four instead of eight barriers per K-tile (equal);
+ * 6 and 7 are kept for comparison only */
 int bsclip_gemm_set_tile(int tile);
 /* diagnostic build of the 256x256 kernel: per-workgroup phase stamps (start, prologue, K loop, end) in 100 MHz ticks,
  * diag[grid * 16]; tools/gemm_phases.py.  Never used by the product path. */
