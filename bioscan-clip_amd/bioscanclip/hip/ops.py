@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import lib as _l
-from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_PATCH_F32, EPI_RESID_F32, KPAD, EpiArgs,
+from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_PATCH_F32, EPI_RESID_F32, KPAD, EpiArgs,  # noqa: F401
                   check)
 
 BF16 = torch.bfloat16

@@ -5,7 +5,6 @@ Keeps ``load_pre_trained_bioscan_bert``, ``get_sequence_pipeline``, ``_LoRALayer
 Arithmetic (BERT-base trunk, MLM transform, replaced decoder, softmax over 768, mean over tokens) runs in
 the HIP engine; there is no torch fallback.
 """
-import math
 import os
 from itertools import product
 

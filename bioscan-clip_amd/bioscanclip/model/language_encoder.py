@@ -4,7 +4,6 @@
 keys (language_encoder.py:12-89).  Arithmetic (4-layer BERT trunk with additive key mask, unmasked mean over
 the 20 positions, ``proj`` Linear(512, 768)) runs in the HIP engine; there is no torch fallback.
 """
-import math
 
 import torch
 import torch.nn as nn

@@ -5,7 +5,6 @@
 The arithmetic is the fused HIP InfoNCE (``bsclip_infonce_fwd_bwd``): soft-target CE over every ordered modality
 pair, temperature fixed at construction, second ``F.normalize`` applied inside (loss_func.py:43-44).
 """
-import torch
 import torch.nn as nn
 
 from bioscanclip.hip.functional import infonce

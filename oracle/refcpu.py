@@ -19,7 +19,6 @@ itself is absent from this image -- "parity unpinned" for timm's internals, as D
 import math
 
 import torch
-import torch.nn.functional as F
 
 
 def _q(x, emulate_bf16):

@@ -131,7 +131,7 @@ def test_synthetic_loader_layout():
 def test_checkpoint_helpers_and_roundtrip(tmp_path):
     """Reference util.py:72-84 semantics + a state_dict written by one model loads strictly into another (same keys)."""
     from bioscanclip.model import arch
-    from bioscanclip.model.dna_encoder import LoRA_barcode_bert, load_pre_trained_bioscan_bert
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
     from bioscanclip.util.util import load_bert_model, remove_extra_pre_fix
     assert remove_extra_pre_fix({"module.a.b": 1, "c": 2, "module.module.d": 3}) == {"a.b": 1, "c": 2, "module.d": 3}
     torch.manual_seed(0)
