@@ -34,7 +34,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md chip table)
 GFLOP_PER_PAIR_ID = 118.3   # fwd 58.8 + LoRA-regime bwd
 GFLOP_PER_TRIPLE_IDT = 119.3
-FC1_TRAFFIC_BYTES_B256 = 901.4e6  # measured, see time_dominant_gemm
+FC1_TRAFFIC_BYTES_B256 = 892.5e6  # (11 x 1113.5 + 12 x 749.2 + 180.5) / 24 MB: the per-shape PMC figures, this build's launch mix
 
 
 class _Cfg:
