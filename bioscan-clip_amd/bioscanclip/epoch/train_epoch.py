@@ -47,8 +47,8 @@ def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimize
         loss = criterion(*model(image, dna, text), label)
         loss.backward()
         hdist.allreduce_grads(model)  # no-op without a multi-rank process group
-        if hasattr(optimizer, "attach") and not getattr(optimizer, "_flats", None):
-            optimizer.attach(model)  # FusedAdamW: adopt the engines' flat buffers once they exist
+        if hasattr(optimizer, "needs_attach") and optimizer.needs_attach():
+            optimizer.attach(model)  # FusedAdamW: adopt the engines' flat buffers once they exist (or were rebuilt)
         optimizer.step()
         if scheduler is not None:
             scheduler.step()

@@ -22,6 +22,10 @@ class FusedAdamW(torch.optim.Optimizer):
         from .dist import flat_buffers
         self._flats = flat_buffers(model)
 
+    def needs_attach(self):
+        """True until the engines' flat buffers are known, and again after an engine was rebuilt (checkpoint loaded mid-run)."""
+        return not self._flats or not all(f.valid() for f in self._flats)
+
     def zero_grad(self, set_to_none: bool = True):
         handled = set()
         for f in self._flats:
