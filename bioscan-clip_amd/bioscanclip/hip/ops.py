@@ -30,8 +30,11 @@ def _req(cond, msg):
 
 
 def _rowmajor(t, name):
-    _req(t.is_cuda, f"{name}: expected a GPU tensor")
-    _req(t.dim() == 2 and t.stride(1) == 1, f"{name}: expected a 2-D tensor with unit inner stride")
+    # messages are only formatted on failure: these checks run ~1 500 times per training step
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a GPU tensor")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D tensor with unit inner stride")
     return t.stride(0)
 
 
@@ -44,7 +47,8 @@ def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, 
     N = b.shape[0]
     _req(M <= a.shape[0] and K <= a.shape[1] and K <= b.shape[1], "gemm: M/K exceed operand shapes")
     want = F32 if epilogue in (EPI_F32, EPI_RESID_F32, EPI_PATCH_F32) else BF16
-    _req(out.dtype == want, f"gemm: out dtype {out.dtype} != {want}")
+    if out.dtype != want:
+        raise ValueError(f"gemm: out dtype {out.dtype} != {want}")
     if epilogue == EPI_PATCH_F32:
         _req(M % 196 == 0 and out.shape[0] >= M // 196 * 197 and out.shape[1] >= N, "gemm(PATCH): out too small")
     else:
