@@ -16,8 +16,13 @@ LORA_COLS = 8
 
 
 class EpiArgs(Structure):
-    _fields_ = [("bias", c_void_p), ("resid", c_void_p), ("ld_resid", c_int), ("aux", c_void_p), ("ld_aux", c_int),
-                ("dropout_p", c_float), ("dropout_seed", c_uint32)]
+    """``bsclip_epi_args`` (include/bsclip.h); ``struct_size`` is filled in, the library rejects a mismatch."""
+    _fields_ = [("struct_size", c_uint32), ("bias", c_void_p), ("resid", c_void_p), ("ld_resid", c_int),
+                ("aux", c_void_p), ("ld_aux", c_int), ("dropout_p", c_float), ("dropout_seed", c_uint32)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(EpiArgs)
 
 
 P, I, F, L, U = c_void_p, c_int, c_float, c_int64, c_uint32
@@ -29,12 +34,10 @@ SIGNATURES = {
     "bsclip_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P]),
     "bsclip_init_tables": (I, [P]),
     "bsclip_gemm_set_tile": (I, [I]),
-    "bsclip_gemm_diag_ablate": (I, [I]),
-    "bsclip_gemm_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, P]),
+    "bsclip_epi_args_size": (I, []),
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),
-    "bsclip_attn_bwd_diag": (I, [P, I, P, I, P, I, I, I, F, P, I, P, P]),
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, P]),
     "bsclip_mask_to_bias": (I, [P, I, P, P]),
@@ -60,7 +63,16 @@ SIGNATURES = {
     "bsclip_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, F, P]),
 }
 
+# only in libbsclip_hip_diag.so (`make -C bioscan-clip_amd/csrc diag`, -DBSCLIP_DIAG); used by tools/, never by the product
+DIAG_SIGNATURES = {
+    "bsclip_gemm_diag_ablate": (I, [I]),
+    "bsclip_gemm_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, P]),
+    "bsclip_attn_bwd_diag": (I, [P, I, P, I, P, I, I, I, F, P, I, P, P]),
+}
+DIAG_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libbsclip_hip_diag.so")
+
 _lib = None
+_diag_lib = None
 
 
 def load():
@@ -73,12 +85,31 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C bioscan-clip_amd/csrc`.  bioscanclip has no non-HIP compute path.")
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    _bind(lib, SIGNATURES)
+    if lib.bsclip_epi_args_size() != ctypes.sizeof(EpiArgs):
+        raise RuntimeError(f"bsclip_epi_args is {lib.bsclip_epi_args_size()} bytes in {LIB_PATH} but "
+                           f"{ctypes.sizeof(EpiArgs)} in this binding: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def _bind(lib, table):
+    for name, (res, args) in table.items():
         fn = getattr(lib, name)  # AttributeError = ABI drift between header and library
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+
+
+def load_diag():
+    """The diagnostic library (product entry points + the phase-stamped / ablated kernel builds).  tools/ only."""
+    global _diag_lib
+    if _diag_lib is None:
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise RuntimeError(f"{DIAG_LIB_PATH} is missing: build it with `make -C bioscan-clip_amd/csrc diag`")
+        _diag_lib = ctypes.CDLL(DIAG_LIB_PATH)
+        _bind(_diag_lib, SIGNATURES)
+        _bind(_diag_lib, DIAG_SIGNATURES)
+    return _diag_lib
 
 
 def last_error():

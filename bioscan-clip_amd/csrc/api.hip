@@ -14,4 +14,4 @@ void bsclip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bsclip_last_error(void) { return g_err; }
-extern "C" int bsclip_abi_version(void) { return 2; }  // 2: q_rows on the attention entry points, bsclip_topk_ip
+extern "C" int bsclip_abi_version(void) { return 3; }  // 3: bsclip_epi_args.struct_size (leading), bsclip_epi_args_size; diag builds moved out

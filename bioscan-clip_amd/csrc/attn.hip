@@ -509,6 +509,7 @@ extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, in
     return BSCLIP_OK;
 }
 
+#ifdef BSCLIP_DIAG
 // Diagnostic build of the backward kernel (S = 197 / 133 instances): per-wave wall-clock stamps
 // [start, K/V staged, phase 1 done, barrier passed, Q/dO staged, end] in diag[(B*heads) * 4 waves * 8].  Never used by the product.
 extern "C" int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
@@ -529,3 +530,4 @@ extern "C" int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dct
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }
+#endif  // BSCLIP_DIAG

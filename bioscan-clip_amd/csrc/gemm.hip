@@ -395,6 +395,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     };
     stamp(0);
     const int nk = K / BK;
+#ifdef BSCLIP_DIAG
     if constexpr (SCHED == 1) {
         // Deep-prefetch variant, kept for comparison (bsclip_gemm_set_tile(6)); NOT the default.  tools/gemm_ablate.py shows the
         // K loop bound as much by the LDS-DMA stream as by the matrix pipe (DMA + barriers alone 1.1 us per K-tile, MFMA +
@@ -547,7 +548,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         }
 #undef BAR_G0
 #undef BAR_G1
-    } else {
+    } else
+#endif
+    {
         // ---- prologue: tile 0 complete, plus the first piece of tile 1 (the "phase 3 of tile -1" slot) ----
         dmaA(0, 0, 0);
         dmaA(0, 1, 0);
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 }
 
 int g_tile_override = 0;
-int g_diag_ablate = 0;  // tools/gemm_ablate.py: which parts of the K loop the diagnostic EPI_BF16 build leaves out
+[[maybe_unused]] int g_diag_ablate = 0;  // tools/gemm_ablate.py: which parts of the K loop the diagnostic EPI_BF16 build leaves out
 
 template <int BM, int BN, int WM, int WN, int EPI, bool HB>
 void launch_cfg(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -811,8 +814,10 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
     if ((tile == 3 || tile == 4 || tile == 6 || tile == 7) && N % 256 != 0) tile = 2;
     switch (tile) {
         case 4: launch_pp<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
+#ifdef BSCLIP_DIAG
         case 6: launch_pp<EPI, HB, 1>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // two-tiles-ahead DMA (comparison)
         case 7: launch_pp<EPI, HB, 2>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // four barriers per K-tile (experimental)
+#endif
         case 3: launch_cfg<256, 256, 2, 4, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
         case 2: launch_cfg<256, 128, 4, 2, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
         default: launch_cfg<128, 128, 2, 2, EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
@@ -828,6 +833,7 @@ void launch_bias(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, in
 
 }  // namespace
 
+#ifdef BSCLIP_DIAG
 // Diagnostic: the ping-pong kernel with four phase stamps per workgroup and wave group (start, prologue done, K loop
 // done, end) written to diag[grid*16] (8 per wave group: start, prologue, K loop, end, 4 epilogue sections) (100 MHz ticks).  Used by tools/gemm_phases.py; not on any product path.
 extern "C" int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -875,6 +881,7 @@ extern "C" int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, 
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }
+#endif  // BSCLIP_DIAG
 
 // Fills the device-side GELU table.  Stream-ordered; the GEMM entry point also does this lazily on its own stream, so a
 // single-stream caller never needs it -- callers that launch GEMMs on several streams call it once up front.
@@ -887,16 +894,24 @@ extern "C" int bsclip_init_tables(void* stream) {
 }
 
 extern "C" int bsclip_gemm_set_tile(int tile) {
+#ifdef BSCLIP_DIAG
     BSCLIP_REQUIRE(tile >= 0 && tile <= 7 && tile != 5, "bsclip_gemm_set_tile: tile %d not in {0,1,2,3,4,6,7}", tile);
+#else
+    BSCLIP_REQUIRE(tile >= 0 && tile <= 4, "bsclip_gemm_set_tile: tile %d not in {0,1,2,3,4}", tile);
+#endif
     g_tile_override = tile;
     return BSCLIP_OK;
 }
 
+#ifdef BSCLIP_DIAG
 extern "C" int bsclip_gemm_diag_ablate(int mask) {
     BSCLIP_REQUIRE(mask >= 0 && mask < 16, "bsclip_gemm_diag_ablate: mask %d", mask);
     g_diag_ablate = mask;
     return BSCLIP_OK;
 }
+#endif
+
+extern "C" int bsclip_epi_args_size(void) { return (int)sizeof(bsclip_epi_args); }
 
 extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                 int epilogue, const bsclip_epi_args* args, void* stream) {
@@ -910,6 +925,9 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
     BSCLIP_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "bsclip_gemm_bf16: 16-B alignment");
     EpiArgs e{};
     if (args) {
+        BSCLIP_REQUIRE(args->struct_size == sizeof(bsclip_epi_args),
+                       "bsclip_gemm_bf16: args->struct_size=%u, this library's bsclip_epi_args is %zu bytes (binding out of date?)",
+                       args->struct_size, sizeof(bsclip_epi_args));
         e.bias = args->bias;
         e.resid = args->resid;
         e.ld_resid = args->ld_resid;

@@ -11,7 +11,8 @@ AdamW (+ optional one_cycle / exponential / step / cosine scheduler, stepped per
     all-reduced (the reference never synchronises gradients: SURVEY App. B-1);
   * parameters are broadcast as one flat buffer per encoder (reference: one broadcast per tensor, train_cl.py:29-31);
   * the HDF5 datasets are not available here: ``dataset=synthetic`` (default) feeds synthetic batches of the same layout;
-  * evaluation (faiss retrieval) is outside the accelerated path and is skipped.
+  * the per-epoch evaluation (``eval_phase``, reference train_cl.py:217-243) runs natively: feature extraction with the HIP
+    encoders and top-k retrieval with ``bsclip_topk_ip`` in place of faiss.
 """
 import datetime
 import os

@@ -48,7 +48,8 @@ enum bsclip_epilogue {
     BSCLIP_EPI_PATCH_F32 = 5   /* C f32 row (b*197+1+p) = acc + bias + pos[1+p], input row b*196+p  */
 };
 typedef struct bsclip_epi_args {
-    const float* bias;  /* [N] or NULL */
+    uint32_t struct_size; /* = sizeof(bsclip_epi_args) = bsclip_epi_args_size(); a mismatch is rejected (ABI drift guard) */
+    const float* bias;    /* [N] or NULL */
     const float* resid; /* RESID: f32 [M, ld_resid]; PATCH: pos_embed f32 [197, N] */
     int ld_resid;
     void* aux; /* GELU: bf16 out (nullable); DGELU: bf16 in */
@@ -58,20 +59,29 @@ typedef struct bsclip_epi_args {
 } bsclip_epi_args;
 int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      int epilogue, const bsclip_epi_args* args, void* stream);
+/* sizeof(bsclip_epi_args) as this library was compiled; bindings assert their own struct against it */
+int bsclip_epi_args_size(void);
 /* one-time device tables (GELU Phi/phi table of the 256x256 kernel's epilogue).  bsclip_gemm_bf16 fills them lazily on
  * its own stream; call this once (and synchronise) before launching GEMMs from several streams. */
 int bsclip_init_tables(void* stream);
-/* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x256 ping-pong, 6 = the same with
- * the LDS-DMA two K-tiles ahead instead of one (slower), 7 = the same with four instead of eight barriers per K-tile (equal);
- * 6 and 7 are kept for comparison only */
+/* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x256 ping-pong; the diagnostic
+ * library (-DBSCLIP_DIAG, `make diag`) adds 6 = ping-pong with the LDS-DMA two K-tiles ahead (slower) and 7 = four instead of
+ * eight barriers per K-tile (equal), kept for comparison only */
 int bsclip_gemm_set_tile(int tile);
-/* diagnostic build of the 256x256 kernel: per-workgroup phase stamps (start, prologue, K loop, end) in 100 MHz ticks,
- * diag[grid * 16]; tools/gemm_phases.py.  Never used by the product path. */
-/* which parts of the K loop the diagnostic EPI_BF16 build leaves out (1 MFMA, 2 LDS reads, 4 DMA, 8 barriers; sums of two
- * for the instantiated pairs): timing experiments only, results are garbage.  tools/gemm_ablate.py */
+#ifdef BSCLIP_DIAG
+/* ---- diagnostic builds: only in libbsclip_hip_diag.so (`make -C bioscan-clip_amd/csrc diag`), never in the product library.
+ * bsclip_gemm_diag: the 256x256 kernel with per-workgroup phase stamps (start, prologue, K loop, end, epilogue sections) in
+ * 100 MHz ticks, diag[grid * 16]; tools/gemm_phases.py.
+ * bsclip_gemm_diag_ablate: which parts of the K loop the diagnostic EPI_BF16 build leaves out (1 MFMA, 2 LDS reads, 4 DMA,
+ * 8 barriers; sums of two for the instantiated pairs): timing experiments only, results are garbage.  tools/gemm_ablate.py */
 int bsclip_gemm_diag_ablate(int mask);
 int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream);
+/* the attention backward kernel (S = 197 or 133, no mask, no dropout) with per-wave section stamps in 100 MHz ticks,
+ * diag[B*heads*4*8]; tools/attn_phases.py */
+int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
+                         int heads, float scale, void* dqkv, int ld_dqkv, unsigned long long* diag, void* stream);
+#endif
 
 /* ---- LayerNorm (timm norm1/norm2/norm eps 1e-6; HF BertLayerNorm eps 1e-12) ------------------------------------
  * fwd: y = LN(x) * gamma + beta for f32 rows x[M,H] (H = 768 or 512).
@@ -111,11 +121,6 @@ int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const 
 int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
                     int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
                     float dropout_p, uint32_t dropout_seed, void* stream);
-
-/* diagnostic build of the backward kernel (S = 197 or 133, no mask, no dropout): per-wave section stamps in 100 MHz ticks,
- * diag[B*heads*4*8]; tools/attn_phases.py.  Never used by the product path. */
-int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
-                         int heads, float scale, void* dqkv, int ld_dqkv, unsigned long long* diag, void* stream);
 
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column

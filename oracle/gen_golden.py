@@ -162,9 +162,11 @@ def gen_state_dict_keys():
             "n_total": sum(p.numel() for p in model.parameters())}
 
 
-def gen_trajectory(steps=10, B=8, with_text=False, seed=31):
+def gen_trajectory(steps=10, B=8, with_text=False, seed=31, n_batches=2):
     """BASELINE config 1: Image+DNA two-tower, B=8, reference modules, AdamW lr 1e-3, 10 steps
-    (loop body = train_epoch.py:22-44)."""
+    (loop body = train_epoch.py:22-44).  The loader cycles over ``n_batches`` distinct batches (a two-batch epoch repeated),
+    so the loss falls from above ln B to a few percent of it within the run: a trajectory only a correct encoder +
+    loss + backward + AdamW chain reproduces (with fresh random batches every step it would hover around ln B)."""
     torch.manual_seed(0)
     model = SimpleCLIP(build_vit(12), build_dna(12), build_txt(4) if with_text else None)
     load_synth(model, seed=seed)
@@ -174,7 +176,7 @@ def gen_trajectory(steps=10, B=8, with_text=False, seed=31):
     losses = []
     first = {}
     for s in range(steps):
-        image, dna, text, label = synth.synth_batch(B, seed=100 + s, with_text=with_text)
+        image, dna, text, label = synth.synth_batch(B, seed=100 + s % n_batches, with_text=with_text)
         opt.zero_grad()
         img_o, dna_o, txt_o = model(image, dna, text)
         loss = crit(img_o, dna_o, txt_o, label)
@@ -190,7 +192,7 @@ def gen_trajectory(steps=10, B=8, with_text=False, seed=31):
         print(f"  step {s}: loss {loss.item():.6f}", flush=True)
     params = {k: summary(k, p) for k, p in model.named_parameters() if p.requires_grad}
     return {"losses": losses, "first_step": first, "params_after": params, "B": B, "steps": steps, "lr": 0.001,
-            "weight_seed": seed, "batch_seed0": 100}
+            "weight_seed": seed, "batch_seed0": 100, "n_batches": n_batches}
 
 
 def gen_retrieval():
@@ -227,7 +229,7 @@ def main():
             "reference": "bioscan-ml/bioscan-clip @ 2024-10-24 (/root/reference)"}
     jobs = {"loss": gen_loss, "encoders": gen_encoders, "state_dict_keys": gen_state_dict_keys,
             "trajectory_id": gen_trajectory, "retrieval": gen_retrieval,
-            "trajectory_idt": lambda: gen_trajectory(steps=3, B=4, with_text=True, seed=32)}
+            "trajectory_idt": lambda: gen_trajectory(steps=6, B=4, with_text=True, seed=32)}
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

@@ -45,19 +45,26 @@ def layer_norm(x, w, b, eps):
     return (x - mu) * torch.rsqrt(var + eps) * w + b
 
 
-def sdpa(q, k, v, bias=None):
-    """softmax(q k^T / sqrt(d) + bias) v over [B, heads, S, d]."""
+def sdpa(q, k, v, bias=None, emulate_bf16=False):
+    """softmax(q k^T / sqrt(d) + bias) v over [B, heads, S, d].
+
+    ``emulate_bf16`` restates the one rounding point inside the HIP attention kernel that is not a GEMM operand of a
+    Linear: the un-normalised probabilities exp(s - max) are rounded to bf16 before the P.V product, while the row
+    sum that normalises the result is taken over the unrounded f32 values (csrc/attn.hip, attn_fwd_kernel)."""
     s = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
     if bias is not None:
         s = s + bias
-    return torch.softmax(s, dim=-1) @ v
+    if not emulate_bf16:
+        return torch.softmax(s, dim=-1) @ v
+    e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+    return (_q(e, True) @ v) / e.sum(dim=-1, keepdim=True)
 
 
 # --------------------------------------------------------------------------------------
 # ViT-B/16 + LoRA  (reference image_encoder.py:15-48, 51-109; timm 0.6.13 semantics App. A.1)
 # --------------------------------------------------------------------------------------
 def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emulate_bf16=False,
-                return_hidden=False):
+                return_hidden=False, taps=None):
     """``LoRA_ViT_timm.forward`` (image_encoder.py:108-109) -> timm ``VisionTransformer.forward``:
     patch-embed conv (k=s=16) -> cat cls -> +pos -> pre-LN blocks (eps 1e-6) with LoRA added in place to
     the Q and V slices of the fused qkv output, scale 1 (image_encoder.py:42-48) -> norm -> token 0 -> head."""
@@ -72,6 +79,8 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
     cols = image.reshape(B, 3, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, 3 * ps * ps)
     x = linear(cols, w_pe.reshape(D, -1), p("patch_embed.proj.bias"), eb)
     x = torch.cat([p("cls_token").expand(B, -1, -1), x], dim=1) + p("pos_embed")
+    tap = (lambda name, t: taps.__setitem__(name, t.detach())) if taps is not None else (lambda name, t: None)
+    tap("x0", x)
     depth = 0
     while (prefix + f"blocks.{depth}.norm1.weight") in sd:
         depth += 1
@@ -81,20 +90,28 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
         h = layer_norm(x, p(b + "norm1.weight"), p(b + "norm1.bias"), 1e-6)
         if (prefix + b + "attn.qkv.qkv.weight") in sd:  # _LoRA_qkv_timm surgery applied
             qkv = linear(h, p(b + "attn.qkv.qkv.weight"), p(b + "attn.qkv.qkv.bias"), eb)
-            new_q = linear(linear(h, p(b + "attn.qkv.linear_a_q.weight"), None, eb),
-                           p(b + "attn.qkv.linear_b_q.weight"), None, eb)
-            new_v = linear(linear(h, p(b + "attn.qkv.linear_a_v.weight"), None, eb),
-                           p(b + "attn.qkv.linear_b_v.weight"), None, eb)
+            # emulation note: the HIP LayerNorm kernel forms t = y A^T from the f32 row and the f32 master A and rounds
+            # only t (csrc/norm.hip), so the inner product is NOT taken on rounded operands
+            t_q = linear(h, p(b + "attn.qkv.linear_a_q.weight"))
+            t_v = linear(h, p(b + "attn.qkv.linear_a_v.weight"))
+            tap(f"t.{i}", torch.cat([t_q, t_v], dim=-1))
+            new_q = linear(t_q, p(b + "attn.qkv.linear_b_q.weight"), None, eb)
+            new_v = linear(t_v, p(b + "attn.qkv.linear_b_v.weight"), None, eb)
             qkv = torch.cat([qkv[..., :D] + new_q, qkv[..., D:2 * D], qkv[..., 2 * D:] + new_v], dim=-1)
         else:
             qkv = linear(h, p(b + "attn.qkv.weight"), p(b + "attn.qkv.bias"), eb)
         S = qkv.shape[1]
         qkv = qkv.reshape(B, S, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
-        ctx = sdpa(_q(qkv[0], eb), _q(qkv[1], eb), _q(qkv[2], eb)).transpose(1, 2).reshape(B, S, D)
+        tap(f"h1.{i}", h)
+        tap(f"qkv.{i}", qkv.permute(1, 3, 0, 2, 4).reshape(B, S, 3 * D))
+        ctx = sdpa(_q(qkv[0], eb), _q(qkv[1], eb), _q(qkv[2], eb), emulate_bf16=eb).transpose(1, 2).reshape(B, S, D)
+        tap(f"ctx.{i}", ctx)
         x = x + linear(ctx, p(b + "attn.proj.weight"), p(b + "attn.proj.bias"), eb)
+        tap(f"x{2 * i + 1}", x)
         h = layer_norm(x, p(b + "norm2.weight"), p(b + "norm2.bias"), 1e-6)
         h = gelu_erf(linear(h, p(b + "mlp.fc1.weight"), p(b + "mlp.fc1.bias"), eb))
         x = x + linear(h, p(b + "mlp.fc2.weight"), p(b + "mlp.fc2.bias"), eb)
+        tap(f"x{2 * i + 2}", x)
     x = layer_norm(x, p("norm.weight"), p("norm.bias"), 1e-6)
     if return_hidden:
         return x
@@ -107,8 +124,9 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
 def _lora_or_plain(sd, base, h, eb):
     """``_LoRALayer.forward``: ``w(x) + w_b(w_a(x))`` (dna_encoder.py:47-49) or the untouched Linear."""
     if (base + "w.weight") in sd:
+        # (emulation: t = h w_a^T is formed in f32 and only t is rounded, as in the ViT branch above)
         return linear(h, sd[base + "w.weight"], sd[base + "w.bias"], eb) + linear(
-            linear(h, sd[base + "w_a.weight"], None, eb), sd[base + "w_b.weight"], None, eb)
+            linear(h, sd[base + "w_a.weight"]), sd[base + "w_b.weight"], None, eb)
     return linear(h, sd[base + "weight"], sd[base + "bias"], eb)
 
 
@@ -143,7 +161,7 @@ def bert_encoder(sd, prefix, input_ids, token_type_ids=None, attention_mask=None
         k = _lora_or_plain(sd, lp + "attention.self.key.", h, eb)
         v = _lora_or_plain(sd, lp + "attention.self.value.", h, eb)
         sh = lambda t: t.reshape(B, S, num_heads, hd).transpose(1, 2)
-        ctx = sdpa(_q(sh(q), eb), _q(sh(k), eb), _q(sh(v), eb), bias).transpose(1, 2).reshape(B, S, H)
+        ctx = sdpa(_q(sh(q), eb), _q(sh(k), eb), _q(sh(v), eb), bias, emulate_bf16=eb).transpose(1, 2).reshape(B, S, H)
         a = linear(ctx, sd[lp + "attention.output.dense.weight"], sd[lp + "attention.output.dense.bias"], eb)
         h = layer_norm(h + a, sd[lp + "attention.output.LayerNorm.weight"],
                        sd[lp + "attention.output.LayerNorm.bias"], eps)

@@ -6,9 +6,12 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
+def header_functions(diag=False):
+    """Entry points declared in include/bsclip.h: the product set, or (diag=True) the -DBSCLIP_DIAG block."""
     text = open(os.path.join(ROOT, "include", "bsclip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    blocks = re.findall(r"#ifdef BSCLIP_DIAG(.*?)#endif", text, flags=re.S)
+    text = "".join(blocks) if diag else re.sub(r"#ifdef BSCLIP_DIAG.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bsclip_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -19,12 +22,42 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/bsclip.h but not exported"
-    assert handle.bsclip_abi_version() == 2
+    assert handle.bsclip_abi_version() == 3
 
 
 def test_ctypes_table_matches_header():
     from bioscanclip.hip import lib
     assert sorted(lib.SIGNATURES) == header_functions()
+    assert sorted(lib.DIAG_SIGNATURES) == header_functions(diag=True)
+
+
+def test_product_library_has_no_diagnostic_builds():
+    from bioscanclip.hip import lib
+    handle = lib.load()
+    for n in header_functions(diag=True):
+        assert not hasattr(handle, n), f"{n} is a -DBSCLIP_DIAG entry point and must not ship in libbsclip_hip.so"
+
+
+def test_epi_args_struct_matches_library_and_is_checked():
+    """The binding's struct is the library's (size exported), INTEGRATION.md documents the same fields, and a caller that
+    hands over a struct of another size (a stale binding) is refused instead of being read past its end."""
+    import ctypes
+    from bioscanclip.hip import lib
+    h = lib.load()
+    assert h.bsclip_epi_args_size() == ctypes.sizeof(lib.EpiArgs) == 56
+    fields = [f[0] for f in lib.EpiArgs._fields_]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class EpiArgs"):doc.index("_lib.bsclip_gemm_bf16.argtypes")]
+    assert re.findall(r'\("([a-z_]+)",', stub) == fields
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "bsclip.h")).read(), flags=re.S)
+    body = hdr[hdr.index("typedef struct bsclip_epi_args {"):hdr.index("} bsclip_epi_args;")]
+    assert re.findall(r"(\w+);", body) == fields
+    a = lib.EpiArgs()
+    assert a.struct_size == 56
+    one = ctypes.c_void_p(16)   # non-null, 16-byte aligned: the size check comes before any dereference or launch
+    a.struct_size = 48
+    assert h.bsclip_gemm_bf16(one, 64, one, 64, one, 128, 1, 128, 64, 0, ctypes.byref(a), None) == -1
+    assert "struct_size" in lib.last_error()
 
 
 def test_argument_validation_without_gpu():

@@ -18,7 +18,7 @@ dqkv = torch.empty(B * S, 3 * H, device="cuda", dtype=torch.bfloat16)
 lse = torch.empty(B, heads, S, device="cuda")
 ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse)
 diag = torch.zeros(B * heads * 4 * 8, dtype=torch.int64, device="cuda")
-h = lib.load()
+h = lib.load_diag()
 for _ in range(2):
     rc = h.bsclip_attn_bwd_diag(qkv.data_ptr(), qkv.stride(0), dctx.data_ptr(), dctx.stride(0), lse.data_ptr(), B, S, heads,
                                 ctypes.c_float(0.125), dqkv.data_ptr(), dqkv.stride(0), diag.data_ptr(),

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 from bioscanclip.hip import lib as L  # noqa: E402
 from bioscanclip.hip.lib import EPI_BF16, EpiArgs  # noqa: E402
 
-h = L.load()
+h = L.load_diag()
 M = 256 * 197
 NAMES = {0: "full loop", 1: "no MFMA", 2: "no LDS reads", 4: "no DMA", 8: "no barriers", 6: "no LDS reads, no DMA",
          3: "no MFMA, no LDS reads", 5: "no MFMA, no DMA", 9: "no MFMA, no barriers"}

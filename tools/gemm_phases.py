@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "bioscan-clip_amd"))
 import torch
 from bioscanclip.hip import lib as L
 from bioscanclip.hip.lib import EPI_BF16, EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32, EpiArgs
-h = L.load()
+h = L.load_diag()
 M = 256 * 197
 for name, N, K, epi in (("qkv", 2304, 832, EPI_BF16), ("dfc1", 768, 3072, EPI_BF16), ("fc1", 3072, 768, EPI_GELU_BF16),
                         ("dfc2", 3072, 768, EPI_DGELU_BF16), ("fc2", 768, 3072, EPI_RESID_F32), ("proj", 768, 768, EPI_RESID_F32)):
