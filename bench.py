@@ -249,6 +249,8 @@ def main():
 
     def step():
         opt.zero_grad()
+        if hasattr(crit, "prefetch_labels"):
+            crit.prefetch_labels(label)  # global batch: label all-gather at the top of the step (as train_epoch does)
         io, do, to = model(image, dna, text)
         loss = crit(io, do, to, label)
         loss.backward()

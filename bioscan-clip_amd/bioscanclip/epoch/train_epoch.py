@@ -44,6 +44,8 @@ def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimize
     for step, batch in steps:
         image, dna, text, label = _to_device(batch, device)
         optimizer.zero_grad()
+        if hasattr(criterion, "prefetch_labels"):
+            criterion.prefetch_labels(label)  # global-batch loss: the label all-gather starts before the encoders
         loss = criterion(*model(image, dna, text), label)
         loss.backward()
         hdist.allreduce_grads(model)  # no-op without a multi-rank process group

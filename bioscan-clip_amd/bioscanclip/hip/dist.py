@@ -4,12 +4,20 @@
   * ``gather_features_and_labels``: all-gather of each modality's [B,768] embeddings and of the labels.  Gathered
     remote rows are constants; the local slice is re-inserted so only it carries gradient -- the reference's
     ``gather_features(gather_with_grad=False, local_loss=False)`` variant (loss_func.py:84-89).  Payloads are tiny
-    (0.79 MB f32 per modality at B=256), i.e. latency-bound: one collective per modality, issued on a side stream
-    as soon as that modality's embedding exists, so it overlaps the next encoder's head GEMMs.
+    (0.79 MB f32 per modality at B=256), i.e. latency-bound: one collective per modality.
+  * Overlap (``enable_overlap``, switched on by ``GlobalBatchContrastiveLoss``): ``SimpleCLIP.forward`` calls
+    ``start_gather`` on each TOWER's stream right after that tower's ``l2_normalize`` is enqueued, so a modality's
+    all-gather runs on RCCL's stream beside the other towers' encoders; the loss only waits for the handles.  Labels
+    are gathered at the start of the step (``start_label_gather``).  In backward each encoder's flat gradient buffer
+    is all-reduced from ``_EncoderFn.backward`` the moment that tower's kernels are enqueued (``start_allreduce``),
+    beside the other tower's backward; ``allreduce_grads`` then only waits.  Collectives are issued from the host
+    thread (forward) and from autograd's per-device thread (backward) in an order fixed by the model, identical on
+    every rank.  One ``backward()`` per optimizer step is assumed (as in the reference loop, train_epoch.py:28-42).
   * ``allreduce_grads``: one all-reduce(SUM) per flat trainable-gradient buffer (5.9-7.6 MB).  SUM, not mean: the
     loss is already the global mean and each rank back-propagates only its own rows' dLoss/dz.
-  * ``broadcast_trainable``: the reference broadcasts every parameter tensor one by one (train_cl.py:29-31); here one
-    flat buffer per encoder (frozen weights are identical on every rank by construction).
+  * ``broadcast_parameters``: every parameter and buffer from rank 0, as the reference does (train_cl.py:29-31,149) --
+    ranks that build a random-init or differently-seeded trunk would otherwise train different models;
+    ``broadcast_trainable`` (one broadcast per flat buffer) is the cheap re-sync once the engines exist.
 The functions are compute-agnostic (they move tensors, nothing else), so the world_size-2 gloo tests drive them on
 CPU tensors.
 """
@@ -52,30 +60,75 @@ def _comm_stream(device):
     return s
 
 
+_OVERLAP = {"on": False, "group": None}
+_PENDING_AR = []      # [(flat gradient buffer, work handle)] issued from _EncoderFn.backward, waited in allreduce_grads
+_PENDING_LABELS = {}  # id(label tensor) -> (label tensor, gathered labels, work handle)
+
+
+def enable_overlap(group=None, on=True):
+    """Issue the per-modality all-gathers from the tower streams and the per-encoder gradient all-reduces from the
+    encoder autograd nodes (see the module docstring).  Set by GlobalBatchContrastiveLoss; harmless without a process
+    group (every hook checks ``overlap_active``)."""
+    _OVERLAP["on"], _OVERLAP["group"] = bool(on), group
+    _PENDING_AR.clear()
+    _PENDING_LABELS.clear()
+
+
+def overlap_active():
+    return _OVERLAP["on"] and not _inactive(_OVERLAP["group"])
+
+
+def _all_gather_async(t, group):
+    W = dist.get_world_size(group)
+    full = torch.empty((W * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    return full, dist.all_gather_into_tensor(full, t.detach().contiguous(), group=group, async_op=True)
+
+
+def start_gather(y):
+    """Called on the stream that produced ``y`` ([B, D] embedding of one modality), right after its l2_normalize: the
+    collective is ordered behind that stream only, the handle rides on the tensor until the loss picks it up."""
+    if overlap_active():
+        y._bsclip_gather = _all_gather_async(y, _OVERLAP["group"])
+    return y
+
+
+def start_label_gather(label):
+    """Start of the step: labels are known before any encoder runs."""
+    if overlap_active():
+        _PENDING_LABELS.clear()
+        _PENDING_LABELS[id(label)] = (label,) + _all_gather_async(label, _OVERLAP["group"])
+
+
+def start_allreduce(flat):
+    """Called from an encoder's autograd node on that tower's stream once its whole backward is enqueued."""
+    if overlap_active():
+        _PENDING_AR.append((flat.grad, dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=_OVERLAP["group"],
+                                                       async_op=True)))
+
+
+def _finish(full, work):
+    work.wait()  # CUDA: the current stream waits for RCCL's stream; CPU (gloo): blocks
+    if full.is_cuda:
+        full.record_stream(torch.cuda.current_stream(full.device))
+    return full
+
+
 def gather_features_and_labels(feats, label, group=None):
-    """feats: list of [B, D] f32 (autograd); label: [B] int64.  Returns ([W*B, D] per modality, [W*B] labels, row0)."""
+    """feats: list of [B, D] f32 (autograd); label: [B] int64.  Returns ([W*B, D] per modality, [W*B] labels, row0).
+    Gathers already started by ``start_gather`` / ``start_label_gather`` are only waited for here."""
     if _inactive(group):
         return feats, label, 0
-    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    rank = dist.get_rank(group)
     B = feats[0].shape[0]
     row0 = rank * B
-    dev = feats[0].device
-    side = _comm_stream(dev)
-    outs, works = [], []
-    if side is not None:
-        side.wait_stream(torch.cuda.current_stream(dev))
-    ctxm = torch.cuda.stream(side) if side is not None else _null()
-    with ctxm:
-        for f in feats:
-            full = torch.empty(W * B, f.shape[1], dtype=f.dtype, device=dev)
-            works.append(dist.all_gather_into_tensor(full, f.detach().contiguous(), group=group, async_op=True))
-            outs.append(full)
-        labels = torch.empty(W * B, dtype=label.dtype, device=dev)
-        works.append(dist.all_gather_into_tensor(labels, label.contiguous(), group=group, async_op=True))
-    for w in works:
-        w.wait()
-    if side is not None:
-        torch.cuda.current_stream(dev).wait_stream(side)
+    handles = []
+    for f in feats:
+        h = getattr(f, "_bsclip_gather", None)
+        handles.append(h if h is not None else _all_gather_async(f, group))
+    pend = _PENDING_LABELS.pop(id(label), None)
+    lab = pend[1:] if pend is not None and pend[0] is label else _all_gather_async(label, group)
+    outs = [_finish(*h) for h in handles]
+    labels = _finish(*lab)
     gathered = [_InsertLocal.apply(f, full, row0) for f, full in zip(feats, outs)]
     return gathered, labels, row0
 
@@ -99,12 +152,49 @@ def flat_buffers(model):
 
 
 def allreduce_grads(model_or_buffers, group=None):
+    """SUM the flat trainable-gradient buffers over the ranks.  Buffers whose all-reduce was already started by
+    ``start_allreduce`` (overlap mode) are only waited for."""
     if _inactive(group):
         return
     bufs = model_or_buffers if isinstance(model_or_buffers, (list, tuple)) else [f.grad for f in flat_buffers(model_or_buffers)]
-    works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in bufs]
-    for w in works:
+    started = {b.data_ptr(): w for b, w in _PENDING_AR}
+    _PENDING_AR.clear()
+    works = [started.pop(b.data_ptr(), None) or dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True)
+             for b in bufs]
+    for w in list(started.values()) + works:
         w.wait()
+
+
+def broadcast_parameters(model, src=0, group=None):
+    """Reference ``broadcast_model`` (train_cl.py:29-31): every parameter (and buffer) of the model from rank ``src``.
+    In-place copies bump the tensors' version counters, so engines that already packed the frozen weights repack."""
+    if _inactive(group):
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def frozen_checksum(model):
+    """float64 sum over every non-trainable floating-point tensor (on the tensors' device): a cheap cross-rank
+    equality check of the frozen trunk."""
+    tensors = [t for t in list(model.parameters()) + list(model.buffers())
+               if not getattr(t, "requires_grad", False) and t.is_floating_point()]
+    total = torch.zeros(1, dtype=torch.float64, device=tensors[0].device if tensors else "cpu")
+    for t in tensors:
+        total += t.detach().double().sum()
+    return total
+
+
+def assert_frozen_in_sync(model, group=None):
+    """Raise if the ranks hold different frozen weights (they would silently train different models)."""
+    if _inactive(group):
+        return
+    mine = frozen_checksum(model)
+    allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(allv, mine, group=group)
+    vals = [v.item() for v in allv]
+    if any(v != vals[0] for v in vals):
+        raise RuntimeError(f"frozen weights differ across ranks: checksums {vals}")
 
 
 def broadcast_trainable(model_or_buffers, src=0, group=None):

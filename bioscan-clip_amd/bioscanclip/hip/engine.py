@@ -32,6 +32,11 @@ def _pad64(n):
     return (n + 63) // 64 * 64
 
 
+def _rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 class FlatParams:
     """Contiguous f32 home for a list of trainable parameters and their gradients."""
 
@@ -449,7 +454,9 @@ class BertEngine(EncoderEngineBase):
         # masks are functions of (seed, element index), regenerated in backward from the seeds kept here
         self._fwd_calls = getattr(self, "_fwd_calls", 0) + 1
         ws["train"] = bool(getattr(self, "training", False))
-        ws["drop_base"] = (torch.initial_seed() * 0x2545F491 + self._fwd_calls * 0x9E3779B9) & 0xFFFFFFFF
+        # the rank is mixed in: ranks seeded alike (bench.py, train_cl.py) must not draw the same masks for their shards
+        ws["drop_base"] = (torch.initial_seed() * 0x2545F491 + self._fwd_calls * 0x9E3779B9
+                           + _rank() * 0x632BE5AB) & 0xFFFFFFFF
         self.refresh_lora_weights()
         ops.cast_f32_bf16(self.extra(0), self.w_head_bf)
         key_bias = None
@@ -574,6 +581,8 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         ctx.engine.backward(dout.contiguous())
+        from .dist import start_allreduce
+        start_allreduce(ctx.engine.flat)  # global-batch step: this tower's gradients are complete on this stream
         here = torch.cuda.current_stream()
         for parent in {ctx.parent, torch.cuda.default_stream(here.device)}:
             if parent is not None and parent != here:

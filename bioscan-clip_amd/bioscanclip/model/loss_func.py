@@ -38,13 +38,22 @@ class ContrastiveLoss(nn.Module):
 
 class GlobalBatchContrastiveLoss(ContrastiveLoss):
     """Global-batch loss over an all-gathered batch: every rank gathers all ranks' embeddings and
-    labels (RCCL all_gather over xGMI, issued per modality on a side stream), evaluates the full N x N loss
+    labels (RCCL all_gather over xGMI, issued per modality from its tower's stream in SimpleCLIP.forward and only
+    waited for here), evaluates the full N x N loss
     redundantly and keeps dLoss/dz for its own rows only; the caller all-reduces (SUM) the flat trainable
     gradients.  Equivalent to the single-process loss on the concatenated batch."""
 
-    def __init__(self, criterion=None, logit_scale=1 / 0.07, group=None):
+    def __init__(self, criterion=None, logit_scale=1 / 0.07, group=None, overlap=True):
         super().__init__(criterion, logit_scale)
         self.group = group
+        if overlap:  # all-gathers from the tower streams, gradient all-reduces from the encoder nodes (hip/dist.py)
+            from bioscanclip.hip.dist import enable_overlap
+            enable_overlap(group)
+
+    def prefetch_labels(self, label):
+        """Start the label all-gather at the top of the step (train_epoch calls this before the encoders run)."""
+        from bioscanclip.hip.dist import start_label_gather
+        start_label_gather(label)
 
     def forward(self, image_features, dna_features, text_features, label, logit_scale=1 / 0.07):
         from bioscanclip.hip.dist import gather_features_and_labels

@@ -8,6 +8,7 @@ and raises.
 import torch
 import torch.nn as nn
 
+from bioscanclip.hip.dist import start_gather
 from bioscanclip.hip.engine import forked_from
 from bioscanclip.hip.functional import l2_normalize
 from bioscanclip.model.arch import vit_base_patch16_224
@@ -62,11 +63,12 @@ class SimpleCLIP(nn.Module):
                 side = _tower_stream(k, cur.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side), forked_from(cur):
-                    y = l2_normalize(enc(x))
+                    # global-batch loss: this modality's all-gather starts here, ordered behind this tower's stream only
+                    y = start_gather(l2_normalize(enc(x)))
                 y.record_stream(cur)
                 outs[k] = (y, side)
             else:
-                outs[k] = (l2_normalize(enc(x)), None)
+                outs[k] = (start_gather(l2_normalize(enc(x))), None)
         for k in range(3):
             if outs[k] is not None:
                 y, side = outs[k]

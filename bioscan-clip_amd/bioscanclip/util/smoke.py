@@ -37,6 +37,13 @@ def run_smoke():
     named = dict(model.named_parameters())
     e_par = max(((named[k].detach().cpu() - state.sd[k].detach()).norm() / state.sd[k].detach().norm()).item()
                 for k in state.train_keys)
-    print(f"smoke: loss {loss.item():.6f} (oracle {ref_loss.item():.6f}), rel err img {e_img:.2e} dna {e_dna:.2e} "
-          f"loss {e_loss:.2e} params-after-step {e_par:.2e}")
-    assert e_img < 2e-2 and e_dna < 2e-2 and e_loss < 2e-3 and e_par < 2e-2, "HIP step disagrees with the CPU oracle"
+    with torch.no_grad():  # the same forward with bf16 rounding restated where the kernels round
+        qi, qd, _ = refcpu.simple_clip_forward(sd, image, ids, None, emulate_bf16=True)
+    q_img = ((io.detach().cpu() - qi).norm() / qi.norm()).item()
+    q_dna = ((do.detach().cpu() - qd).norm() / qd.norm()).item()
+    print(f"smoke: loss {loss.item():.6f} (oracle {ref_loss.item():.6f}), rel err vs f32 oracle: img {e_img:.2e} dna {e_dna:.2e} "
+          f"loss {e_loss:.2e} params-after-step {e_par:.2e}; vs bf16-rounding-aware oracle: img {q_img:.2e} dna {q_dna:.2e}")
+    # 2x the values measured on MI355X (1.6e-2, 4.4e-3, 5.7e-4, 1.1e-2): bf16 operands against an all-f32 oracle on peaked
+    # attention; against the oracle that rounds at the same points the embeddings agree to a few 1e-3
+    assert e_img < 3.2e-2 and e_dna < 9e-3 and e_loss < 1.2e-3 and e_par < 2.2e-2, "HIP step disagrees with the CPU oracle"
+    assert q_img < 1e-2 and q_dna < 1e-2, "HIP step disagrees with the bf16-rounding-aware oracle"

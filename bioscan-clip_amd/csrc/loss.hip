@@ -283,6 +283,7 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
                                    W);
                 float* dar = da + (size_t)l0 * D;
                 bsclip_epi_args ea{};
+                ea.struct_size = sizeof(ea);
                 ea.resid = dar;
                 ea.ld_resid = D;
                 rc = bsclip_gemm_bf16(W, 3 * Np, PBt + b * opT, 3 * Np, dar, D, nr, D, 3 * Np,

@@ -43,9 +43,10 @@ def print_when_rank_zero(message, rank=0):
 
 
 def broadcast_model(model, rank):
-    """Reference train_cl.py:29-31, restricted to the trainable tensors (frozen weights are identical by construction:
-    same checkpoint / same seed on every rank): per tensor before the first forward, one broadcast per flat buffer after."""
-    hdist.broadcast_trainable(model, src=0)
+    """Reference train_cl.py:29-31: every parameter from rank 0 (plus buffers).  Random-init / unseeded trunks differ per
+    rank otherwise, and the summed LoRA gradients would come from different models."""
+    hdist.broadcast_parameters(model, src=0)
+    hdist.assert_frozen_in_sync(model)
 
 
 def eval_phase(model, device, all_keys_dataloader, seen_val_dataloader, unseen_val_dataloader, k_list, args,

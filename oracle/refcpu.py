@@ -26,7 +26,7 @@ def _q(x, emulate_bf16):
     *where* the HIP path rounds (A/B operands of every MFMA GEMM) while keeping fp32 math."""
     if not emulate_bf16:
         return x
-    return x + (x.detach().to(torch.bfloat16).to(torch.float32) - x.detach())
+    return x + (x.detach().to(torch.bfloat16).to(x.dtype) - x.detach())
 
 
 def linear(x, w, b=None, emulate_bf16=False):

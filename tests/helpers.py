@@ -39,6 +39,18 @@ def check_summary(key, t, gold, rtol, what="", first_slack=1.0):
     return s
 
 
+def summary_distance(key, t, gold):
+    """Measured distances to a golden fingerprint, in the units ``check_summary`` asserts on (all relative to the golden
+    norm): norm difference, projection difference / 4, worst of the first-8 differences / (6 / sqrt(numel))."""
+    s = summary(key, t)
+    n = max(gold["norm"], 1e-30)
+    numel = 1
+    for d in gold["shape"]:
+        numel *= d
+    return {"norm": abs(s["norm"] - gold["norm"]) / n, "probe": abs(s["probe"] - gold["probe"]) / (4 * n),
+            "first": max(abs(a - b) for a, b in zip(s["first"], gold["first"])) * numel ** 0.5 / (6 * n)}
+
+
 def rel_err(a, b):
     a = a.detach().to("cpu", torch.float64)
     b = b.detach().to("cpu", torch.float64)

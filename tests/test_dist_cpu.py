@@ -50,12 +50,32 @@ def _worker(rank, world, port, B, tmp):
     _, dna, text, label = synth.synth_batch(world * B, seed=9, with_text=True, dup_labels=True)
     sl = slice(rank * B, (rank + 1) * B)
     zd, zt = _forward(state.sd, dna[sl], {k: v[sl] for k, v in text.items()})
-    gathered, labels, row0 = hdist.gather_features_and_labels([zd, zt], label[sl].contiguous())
+    # overlap mode, as the product runs it: the label gather starts at the top of the step, each modality's gather as soon
+    # as its embedding exists (SimpleCLIP.forward -> start_gather), the loss only waits for the handles
+    hdist.enable_overlap()
+    local_label = label[sl].contiguous()
+    hdist.start_label_gather(local_label)
+    zd, zt = hdist.start_gather(zd), hdist.start_gather(zt)
+    assert hasattr(zd, "_bsclip_gather") and hdist._PENDING_LABELS
+    gathered, labels, row0 = hdist.gather_features_and_labels([zd, zt], local_label)
+    assert not hdist._PENDING_LABELS
     assert row0 == rank * B and labels.tolist() == label.tolist()
     loss = refcpu.contrastive_loss(None, gathered[0], gathered[1], labels)
     loss.backward()
     flat = torch.cat([state.sd[k].grad.reshape(-1) for k in state.train_keys])
-    hdist.allreduce_grads([flat])
+    # the encoder node starts its flat buffer's all-reduce itself (start_allreduce); allreduce_grads then only waits for it
+    # and reduces whatever was not started (second buffer)
+    class _Flat:
+        grad = flat
+    other = torch.full((5,), float(rank + 1))
+    hdist.start_allreduce(_Flat)
+    assert len(hdist._PENDING_AR) == 1
+    hdist.allreduce_grads([flat, other])
+    assert not hdist._PENDING_AR and (other == 3).all()
+    hdist.enable_overlap(on=False)
+    # the same collectives without overlap mode give the same gathered batch
+    g2, l2, _ = hdist.gather_features_and_labels([zd.detach().clone(), zt.detach().clone()], local_label.clone())
+    assert torch.equal(g2[0], gathered[0].detach()) and torch.equal(l2, labels)
     # broadcast of the flat trainable buffer (train_cl.py:29-31 semantics)
     buf = torch.full((7,), float(rank))
     hdist.broadcast_trainable([buf], src=0)
@@ -71,6 +91,13 @@ def _worker(rank, world, port, B, tmp):
     torch.save({k: v.detach().clone() for k, v in txt.named_parameters() if v.requires_grad},
                os.path.join(tmp, f"trainable{rank}.pt"))
     assert all(torch.equal(v, frozen_before[k]) for k, v in txt.named_parameters() if not v.requires_grad)
+    # train_cl.broadcast_model (reference train_cl.py:29-31,149): the ranks built DIFFERENT random trunks (seed 100 + rank);
+    # the checksum guard sees it, broadcasting every parameter and buffer from rank 0 repairs it
+    with pytest.raises(RuntimeError, match="frozen weights differ"):
+        hdist.assert_frozen_in_sync(txt)
+    hdist.broadcast_parameters(txt, src=0)
+    hdist.assert_frozen_in_sync(txt)
+    torch.save({k: v.detach().clone() for k, v in txt.state_dict().items()}, os.path.join(tmp, f"all{rank}.pt"))
     torch.save({"loss": loss.detach(), "flat": flat}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -95,6 +122,8 @@ def test_two_rank_global_batch_step_equals_single_process(tmp_path):
     assert torch.equal(r0["flat"], r1["flat"])
     t0, t1 = (torch.load(os.path.join(str(tmp_path), f"trainable{r}.pt")) for r in (0, 1))
     assert len(t0) >= 6 and all(torch.equal(t0[k], t1[k]) for k in t0)
+    a0, a1 = (torch.load(os.path.join(str(tmp_path), f"all{r}.pt")) for r in (0, 1))
+    assert len(a0) > 20 and all(torch.equal(a0[k], a1[k]) for k in a0)   # frozen trunk identical after broadcast_model
     err = ((r0["flat"] - flat).norm() / flat.norm()).item()
     assert err < 1e-5, err
 

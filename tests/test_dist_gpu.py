@@ -17,15 +17,18 @@ from oracle import synth  # noqa: E402
 NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
 
 
-def _build():
+def _build(with_text=False):
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
     from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from bioscanclip.model.language_encoder import LoRA_bert
     from bioscanclip.model.simple_clip import SimpleCLIP
     img = LoRA_ViT_timm(arch.VisionTransformerParams(depth=2), r=4, num_classes=768)
     dna = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2, **NODROP)), r=4,
                             num_classes=768)
-    model = SimpleCLIP(img, dna, None)
+    txt = LoRA_bert(arch.BertModelParams(arch.bert_small_config(num_hidden_layers=2, **NODROP)), r=4,
+                    num_classes=768) if with_text else None
+    model = SimpleCLIP(img, dna, txt)
     model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=51))
     return model.cuda().train()
 
@@ -34,20 +37,29 @@ def _flat_grads(model):
     return torch.cat([p.grad.reshape(-1) for _, p in sorted(model.named_parameters()) if p.requires_grad]).cpu()
 
 
-def _worker(rank, world, port, B, tmp):
+def _cuda(text):
+    return None if text is None else {k: v.cuda() for k, v in text.items()}
+
+
+def _worker(rank, world, port, B, tmp, with_text):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bioscanclip.hip import dist as hdist
     from bioscanclip.model.loss_func import GlobalBatchContrastiveLoss
-    model = _build()
-    image, dna, _, label = synth.synth_batch(world * B, seed=9, dup_labels=True)
+    model = _build(with_text)
+    image, dna, text, label = synth.synth_batch(world * B, seed=9, dup_labels=True, with_text=with_text)
     sl = slice(rank * B, (rank + 1) * B)
-    crit = GlobalBatchContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)
-    io, do, _ = model(image[sl].cuda(), dna[sl].cuda(), None)
-    loss = crit(io, do, None, label[sl].cuda())
+    crit = GlobalBatchContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)   # switches overlap mode on
+    assert hdist.overlap_active()
+    local_label = label[sl].cuda()
+    crit.prefetch_labels(local_label)
+    io, do, to = model(image[sl].cuda(), dna[sl].cuda(), _cuda(None if text is None else {k: v[sl] for k, v in text.items()}))
+    assert hasattr(io, "_bsclip_gather") and hasattr(do, "_bsclip_gather")   # gathers started from the tower streams
+    loss = crit(io, do, to, local_label)
     loss.backward()
+    assert len(hdist._PENDING_AR) == (3 if with_text else 2)                  # one all-reduce per encoder, from its node
     hdist.allreduce_grads(model)
     torch.cuda.synchronize()
     torch.save({"loss": loss.detach().cpu(), "flat": _flat_grads(model)}, os.path.join(tmp, f"rank{rank}.pt"))
@@ -56,7 +68,8 @@ def _worker(rank, world, port, B, tmp):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+@pytest.mark.parametrize("with_text", [False, True])
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path, with_text):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     world, B = 2, 4
@@ -64,12 +77,12 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, B, str(tmp_path), with_text), nprocs=world, join=True)
     from bioscanclip.model.loss_func import ContrastiveLoss
-    model = _build()
-    image, dna, _, label = synth.synth_batch(world * B, seed=9, dup_labels=True)
-    io, do, _ = model(image.cuda(), dna.cuda(), None)
-    loss = ContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)(io, do, None, label.cuda())
+    model = _build(with_text)
+    image, dna, text, label = synth.synth_batch(world * B, seed=9, dup_labels=True, with_text=with_text)
+    io, do, to = model(image.cuda(), dna.cuda(), _cuda(text))
+    loss = ContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)(io, do, to, label.cuda())
     loss.backward()
     flat = _flat_grads(model)
     r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
@@ -78,3 +91,28 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     assert abs(r1["loss"].item() - loss.item()) < 1e-5 * abs(loss.item())
     assert torch.equal(r0["flat"], r1["flat"])
     assert rel_err(r0["flat"], flat) < 2e-3
+
+
+@pytest.mark.timeout(900)
+def test_rccl_collectives_at_world_size_one():
+    """The one-GPU box cannot host two RCCL ranks, but it can run the REAL collectives: BSCLIP_FORCE_DIST=1 sends a
+    world_size-1 bench job through init_process_group("nccl"), the tower-stream all-gathers, the per-encoder all-reduces
+    started from the autograd nodes, the flat broadcast and the barrier -- the code path the 8-GPU driver run takes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BSCLIP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for name, e in (("dist", env), ("plain", {k: v for k, v in env.items() if k != "BSCLIP_FORCE_DIST"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--text", "--batch", "16", "--steps", "3", "--warmup", "1",
+                            "--no-cpu-baseline"], env=e, capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    # same seeds, same batch, dropout masks keyed on (seed, call count, rank 0): the collectives must not change the numbers
+    assert outs["dist"]["config"]["final_loss"] == outs["plain"]["config"]["final_loss"], outs
