@@ -100,7 +100,7 @@ def time_dominant_gemm(B, device, reps=4):
     for M, N, K, _ in shapes:
         bufs.append((torch.randn(M, K, device=device).bfloat16(), (torch.randn(N, K, device=device) * 0.03).bfloat16(),
                      torch.randn(N, device=device), torch.empty(M, N, device=device, dtype=torch.bfloat16),
-                     torch.empty(M, N, device=device, dtype=torch.bfloat16)))
+                     torch.empty(M, N, device=device, dtype=torch.uint8)))
 
     def mix():
         for (M, N, K, cnt), (a, w, bias, out, z) in zip(shapes, bufs):
@@ -124,8 +124,8 @@ def time_dominant_gemm(B, device, reps=4):
             # same launch mix; collected offline with rocprofv3 --pmc (profiles/r01_c_fc1_traffic.txt), valid for B=256
             "traffic": FC1_TRAFFIC_BYTES_B256 if B == 256 else None,
             "traffic_note": "rocprofv3 PMC, profiles/r01_c_fc1_traffic.txt; algorithmic bytes per launch: "
-                            "%.1f MB (A + W + 2 outputs)" % (sum((M * K + N * K + 2 * M * N) * 2.0 * c for M, N, K, c in shapes)
-                                                             / launches / 1e6),
+                            "%.1f MB (A + W bf16, gelu bf16, gelu' 8-bit)" % (sum(((M * K + N * K) * 2.0 + 3.0 * M * N) * c for M, N, K, c in shapes)
+                                                                             / launches / 1e6),
             "kernel": "gemm_nt_pp_kernel<2 = EPI_GELU_BF16, true> (fc1 + bias + GELU; 24 launches per step)",
             "launch_mix_MNK_count": [list(x) for x in shapes],
             "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "avg_launch_ms": round(mean_ms, 4)}

@@ -196,7 +196,7 @@ class ViTEngine(EncoderEngineBase):
         ws["qkv"] = [z(M, 3 * H) for _ in range(L)]
         ws["ctx"] = [z(M, H) for _ in range(L)]
         ws["lse"] = [z(B, self.heads, S, dt=F32) for _ in range(L)]
-        ws["z"] = [z(M, FF) for _ in range(L)]                        # fc1 pre-activation
+        ws["z"] = [z(M, FF, dt=torch.uint8) for _ in range(L)]        # gelu'(fc1 pre-activation), 8-bit codes
         ws["h2"] = z(M, H)
         ws["act"] = z(M, FF)
         ws["clsn"] = z(B, H)
@@ -215,7 +215,7 @@ class ViTEngine(EncoderEngineBase):
         ws["clsn_t"] = torch.zeros(H, Bp, dtype=BF16, device=dev)
         ws["dclsn"] = z(B, H)
         ws["dz_c"], ws["dh_c"], ws["st_c"] = z(B, FF), z(B, H), z(B, 2, dt=F32)   # last-block token-0 path
-        ws["h2_c"], ws["act_c"], ws["z_c"] = z(B, H), z(B, FF), z(B, FF)
+        ws["h2_c"], ws["act_c"], ws["z_c"] = z(B, H), z(B, FF), z(B, FF, dt=torch.uint8)
         self.ws = ws
         return ws
 
@@ -402,7 +402,7 @@ class BertEngine(EncoderEngineBase):
         ws["s2"] = [z(M, H, dt=F32) for _ in range(L)]
         ws["sta"] = [z(M, 2, dt=F32) for _ in range(L)]
         ws["stb"] = [z(M, 2, dt=F32) for _ in range(L)]
-        ws["z"] = [z(M, FF) for _ in range(L)]
+        ws["z"] = [z(M, FF, dt=torch.uint8) for _ in range(L)]       # gelu'(intermediate pre-activation), 8-bit codes
         ws["act"] = z(M, FF)
         ws["key_bias"] = None
         ws["kb_buf"] = z(B, S, dt=F32)
@@ -417,7 +417,7 @@ class BertEngine(EncoderEngineBase):
         ws["dt"] = z(M, 8, dt=F32)
         if self.head == "mlm_softmax_mean":
             Mp = _pad64(M)
-            ws["tz"] = z(M, H)            # transform pre-activation
+            ws["tz"] = z(M, H, dt=torch.uint8)   # gelu'(transform pre-activation), 8-bit codes
             ws["tg"] = z(M, H)            # gelu(transform)
             ws["tn"] = z(M, H)            # LN(gelu(.)) = decoder input
             ws["st_t"] = z(M, 2, dt=F32)

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libbsclip_hip.so")
 
-EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, EPI_DGELU_BF16, EPI_PATCH_F32 = range(6)
+EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, EPI_DGELU_BF16, EPI_PATCH_F32, EPI_GELU_FP8 = range(7)
 KPAD = 64
 LORA_COLS = 8
 
@@ -25,6 +25,16 @@ class EpiArgs(Structure):
         self.struct_size = ctypes.sizeof(EpiArgs)
 
 
+class Fp8Args(Structure):
+    """``bsclip_fp8_args`` (include/bsclip.h)."""
+    _fields_ = [("struct_size", c_uint32), ("form", c_int), ("alpha", c_void_p), ("a_aug", c_void_p), ("ld_a_aug", c_int),
+                ("b_aug", c_void_p), ("ld_b_aug", c_int)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(Fp8Args)
+
+
 P, I, F, L, U = c_void_p, c_int, c_float, c_int64, c_uint32
 
 # name -> (restype, argtypes); mirrors include/bsclip.h one to one (tests/test_abi.py checks both directions)
@@ -35,6 +45,9 @@ SIGNATURES = {
     "bsclip_init_tables": (I, [P]),
     "bsclip_gemm_set_tile": (I, [I]),
     "bsclip_epi_args_size": (I, []),
+    "bsclip_gemm_fp8": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), POINTER(Fp8Args), P]),
+    "bsclip_quantize_rows_fp8": (I, [P, I, I, P, I, P, P]),
+    "bsclip_lora_baug_set": (I, [P, I, I, P, P, P, P]),
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),

@@ -9,8 +9,8 @@ import ctypes
 import torch
 
 from . import lib as _l
-from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_PATCH_F32, EPI_RESID_F32, KPAD, EpiArgs,  # noqa: F401
-                  check)
+from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_GELU_FP8, EPI_PATCH_F32, EPI_RESID_F32, KPAD,  # noqa: F401
+                  EpiArgs, Fp8Args, check)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -63,8 +63,8 @@ def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, 
         _req(resid.shape[0] >= need and resid.shape[1] >= N, "gemm: resid too small")
         args.resid = resid.data_ptr()
         args.ld_resid = _rowmajor(resid, "resid")
-    if aux is not None:
-        _req(aux.dtype == BF16 and aux.shape[0] >= M and aux.shape[1] >= N, "gemm: aux must be bf16 [M, N]")
+    if aux is not None:  # gelu' side band: 8-bit codes (include/bsclip.h)
+        _req(aux.dtype == torch.uint8 and aux.shape[0] >= M and aux.shape[1] >= N, "gemm: aux must be uint8 [M, N]")
         args.aux = aux.data_ptr()
         args.ld_aux = _rowmajor(aux, "aux")
     if dropout is not None:  # (p, seed): C = dropout(acc + bias) + resid
@@ -73,6 +73,66 @@ def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, 
     check(_l.load().bsclip_gemm_bf16(_p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, epilogue, ctypes.byref(args),
                                      _stream()))
     return out
+
+
+FP8 = torch.float8_e4m3fn   # OCP e4m3 (gfx950); one byte per element
+FP8_FORM = int(__import__("os").environ.get("BSCLIP_FP8_FORM", "2"))   # 1: 16x16x32 fp8 MFMA, 2: block-scaled 16x16x128 (2x rate)
+
+
+def gemm_fp8(a8, b8, out, alpha, bias, epilogue=EPI_BF16, resid=None, aux=None, a_aug=None, b_aug=None, M=None, K=None,
+             dropout=None, form=None):
+    """out = epilogue(alpha[n] * (a8[:M, :K] @ b8[:, :K].T + a_aug @ b_aug.T) + bias).  a8 [M, >=K], b8 [N, >=K] fp8 e4m3;
+    a_aug [M, >=64] / b_aug [N, >=64] bf16 (the LoRA K-augmentation block) or both None."""
+    lda, ldb, ldc = _rowmajor(a8, "a8"), _rowmajor(b8, "b8"), _rowmajor(out, "out")
+    _req(a8.dtype == FP8 and b8.dtype == FP8, "gemm_fp8 operands must be float8_e4m3fn")
+    M = a8.shape[0] if M is None else M
+    K = min(a8.shape[1], b8.shape[1]) if K is None else K
+    N = b8.shape[0]
+    _req(M <= a8.shape[0] and K <= a8.shape[1] and K <= b8.shape[1], "gemm_fp8: M/K exceed operand shapes")
+    want = {EPI_BF16: BF16, EPI_F32: F32, EPI_RESID_F32: F32, EPI_GELU_FP8: FP8}.get(epilogue)
+    _req(want is not None and out.dtype == want, f"gemm_fp8: epilogue {epilogue} needs out dtype {want}")
+    _req(out.shape[0] >= M and out.shape[1] >= N, "gemm_fp8: out too small")
+    _req(alpha.dtype == F32 and alpha.numel() >= N and alpha.is_contiguous(), "gemm_fp8: alpha must be f32 [N]")
+    _req(bias.dtype == F32 and bias.numel() >= N and bias.is_contiguous(), "gemm_fp8: bias must be f32 [N]")
+    args = EpiArgs()
+    args.bias = bias.data_ptr()
+    if resid is not None:
+        _req(resid.dtype == F32 and resid.shape[0] >= M and resid.shape[1] >= N, "gemm_fp8: resid must be f32 [M, N]")
+        args.resid, args.ld_resid = resid.data_ptr(), _rowmajor(resid, "resid")
+    if aux is not None:
+        _req(aux.dtype == torch.uint8 and aux.shape[0] >= M and aux.shape[1] >= N, "gemm_fp8: aux must be uint8 [M, N]")
+        args.aux, args.ld_aux = aux.data_ptr(), _rowmajor(aux, "aux")
+    if dropout is not None:
+        _req(epilogue == EPI_RESID_F32, "gemm_fp8: dropout is only defined for EPI_RESID_F32")
+        args.dropout_p, args.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF
+    f8 = Fp8Args()
+    f8.form = FP8_FORM if form is None else form
+    f8.alpha = alpha.data_ptr()
+    _req((a_aug is None) == (b_aug is None), "gemm_fp8: a_aug and b_aug go together")
+    if a_aug is not None:
+        _req(a_aug.dtype == BF16 and b_aug.dtype == BF16 and a_aug.shape[0] >= M and b_aug.shape[0] >= N
+             and a_aug.shape[1] >= 64 and b_aug.shape[1] >= 64, "gemm_fp8: aug blocks must be bf16 [M,>=64] / [N,>=64]")
+        f8.a_aug, f8.ld_a_aug = a_aug.data_ptr(), _rowmajor(a_aug, "a_aug")
+        f8.b_aug, f8.ld_b_aug = b_aug.data_ptr(), _rowmajor(b_aug, "b_aug")
+    check(_l.load().bsclip_gemm_fp8(_p(a8), lda, _p(b8), ldb, _p(out), ldc, M, N, K, epilogue, ctypes.byref(args),
+                                    ctypes.byref(f8), _stream()))
+    return out
+
+
+def quantize_rows_fp8(w):
+    """f32 [R, C] -> (fp8 e4m3 [R, C], f32 scale [R]) with w ~= q * scale[:, None] (row amax mapped to 448)."""
+    _req(w.dtype == F32 and w.is_contiguous() and w.dim() == 2 and w.is_cuda and w.shape[1] % 4 == 0, "quantize_rows_fp8: f32 [R, C]")
+    q = torch.empty(w.shape, dtype=FP8, device=w.device)
+    sc = torch.empty(w.shape[0], dtype=F32, device=w.device)
+    check(_l.load().bsclip_quantize_rows_fp8(_p(w), w.shape[0], w.shape[1], _p(q), w.shape[1], _p(sc), _stream()))
+    return q, sc
+
+
+def lora_baug_set(b_aug, H, bq, bv, alpha):
+    _req(b_aug.dtype == BF16 and b_aug.shape[0] >= 3 * H and b_aug.shape[1] >= 64, "b_aug bf16 [3H, >=64]")
+    _req(all(t.dtype == F32 and t.is_contiguous() and tuple(t.shape) == (H, 4) for t in (bq, bv)), "bq/bv f32 [H,4]")
+    _req(alpha.dtype == F32 and alpha.is_contiguous() and alpha.numel() >= 3 * H, "alpha f32 [3H]")
+    check(_l.load().bsclip_lora_baug_set(_p(b_aug), _rowmajor(b_aug, "b_aug"), H, _p(bq), _p(bv), _p(alpha), _stream()))
 
 
 _tables_ready = False
@@ -234,7 +294,8 @@ def meanpool_tokens_bwd(d_pooled, B, S, dx):
 
 
 def dgelu_mul(g, z, M, N, out):
-    _req(all(t.dtype == BF16 and t.shape[0] >= M and t.shape[1] >= N for t in (g, z, out)), "dgelu_mul: bf16 [M,>=N]")
+    _req(all(t.dtype == BF16 and t.shape[0] >= M and t.shape[1] >= N for t in (g, out)), "dgelu_mul: g/out bf16 [M,>=N]")
+    _req(z.dtype == torch.uint8 and z.shape[0] >= M and z.shape[1] >= N, "dgelu_mul: z uint8 codes [M,>=N]")
     check(_l.load().bsclip_dgelu_mul(_p(g), _rowmajor(g, "g"), _p(z), _rowmajor(z, "z"), M, N, _p(out),
                                      _rowmajor(out, "out"), _stream()))
 

@@ -134,6 +134,44 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return fmaf(x * 0.39894228040143268f, e, cdf);
 }
 
+// ---- OCP fp8 e4m3 (gfx950: e4m3fn, max 448, no infinities) ---------------------------------------------
+// v_cvt_pk_fp8_f32 rounds to nearest even; inputs are clamped to +-448 first so an overflow saturates instead of becoming
+// NaN (0x7f).  Four values -> one dword, element i in byte i.
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f);
+    b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f);
+    d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+__device__ __forceinline__ float fp8_to_f32(unsigned w, int byte) {  // byte is a compile-time constant at every call site
+    switch (byte) {
+        case 0: return __builtin_amdgcn_cvt_f32_fp8((int)w, 0);
+        case 1: return __builtin_amdgcn_cvt_f32_fp8((int)w, 1);
+        case 2: return __builtin_amdgcn_cvt_f32_fp8((int)w, 2);
+        default: return __builtin_amdgcn_cvt_f32_fp8((int)w, 3);
+    }
+}
+
+// ---- 8-bit side band for gelu'(pre-activation) -------------------------------------------------------
+// The forward fc1 epilogue saves gelu'(z) for the backward pass (so dfc2's epilogue is one multiply).  gelu' lives in
+// [-0.1290, 1.1290]; a uniform 8-bit code over [-0.13, 1.13] has step 4.9e-3, i.e. rounding noise 1.4e-3 rms -- the
+// size of the bf16 rounding of a value near 1 (2^-9 .. 2^-8) -- at half the bytes of the bf16 band it replaces
+// (fc1 wrote 12 KB per row, now 9 KB; dfc2 read 6 KB of side band per row, now 3 KB).
+constexpr float DG8_OFF = 0.13f, DG8_SCALE = 255.0f / 1.26f, DG8_STEP = 1.26f / 255.0f;
+__device__ __forceinline__ unsigned dg8_code(float g) {
+    return (unsigned)(int)__builtin_amdgcn_fmed3f(fmaf(g, DG8_SCALE, DG8_OFF * DG8_SCALE + 0.5f), 0.0f, 255.0f);
+}
+__device__ __forceinline__ unsigned dg8_pack4(float a, float b, float c, float d) {
+    return dg8_code(a) | (dg8_code(b) << 8) | (dg8_code(c) << 16) | (dg8_code(d) << 24);
+}
+__device__ __forceinline__ f32x4 dg8_unpack4(unsigned w) {
+    return f32x4{fmaf((float)(w & 0xff), DG8_STEP, -DG8_OFF), fmaf((float)((w >> 8) & 0xff), DG8_STEP, -DG8_OFF),
+                 fmaf((float)((w >> 16) & 0xff), DG8_STEP, -DG8_OFF), fmaf((float)(w >> 24), DG8_STEP, -DG8_OFF)};
+}
+
 // ---- async global -> LDS, 16 B per lane (LDS dest = wave-uniform base + lane*16) ---------------------
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

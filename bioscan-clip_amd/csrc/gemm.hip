@@ -42,12 +42,65 @@ struct EpiArgs {
     const float* bias;
     const float* resid;
     int ld_resid;
-    bf16_t* aux;
+    unsigned char* aux;  // gelu' side band, 8-bit codes (common.h dg8_*)
     int ld_aux;
     DropCfg drop;  // RESID only: C = dropout(acc + bias) + resid  (HF BertSelfOutput / BertOutput)
     int n_total;   // logical row width for the dropout element index
     unsigned long long* diag;  // diagnostic build only: per-workgroup phase stamps (100 MHz wall clock)
+    // fp8 main operands (OP != 0): C = epilogue(alpha[n] * (A8 . B8^T + A_aug . B_aug^T) + bias)
+    const float* alpha;                   // [N] dequantisation scale of output column n (activation scale x weight-row scale)
+    const bf16_t* a_aug;                  // bf16 [M, 64] K-augmentation block (LoRA t columns), nullable
+    const bf16_t* b_aug;                  // bf16 [N, 64] matching weight columns (LoRA B / alpha[n])
+    int ld_a_aug, ld_b_aug;
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// GELU table for the 256x256 kernel's epilogue
+// ---------------------------------------------------------------------------------------------------------------
+// The two-output GELU epilogue (gelu and gelu' of 128 values per lane) computed with exp + rcp was VALU-bound (~24
+// instructions per value, 12 us per tile with no MFMA to hide behind), and a 16-B-per-entry interpolation table was bound by
+// the LDS array instead: 64 lanes gathering random 16-B entries conflict ~3x per 16-lane group (phase stamps: 4.4 us per
+// 64-row slab).  Entries are therefore 8 B -- {Phi(x_i), phi(x_i)} on a 1/64 grid over [-8, 8], nearest grid point, one
+// ds_read_b64 per value -- and the neighbourhood comes from the derivatives, which are free: Phi' = phi, phi' = -x phi, so
+//   Phi(x_i + d) = Phi_i + d phi_i (1 - x_i d / 2) + O(d^3 |phi''| / 6)   <= 2e-8   for |d| <= 1/128,
+//   phi(x_i + d) = phi_i (1 - x_i d)               + O(d^2 |phi''| / 2)   <= 1.3e-5,
+// both far inside the bf16 rounding of the outputs.  Computed once on the device in f64 with erf().
+constexpr int GELU_LUT_N = 1024;                      // intervals
+constexpr int GELU_LUT_BYTES = (GELU_LUT_N + 1) * 8;  // 8200
+__device__ float2 g_gelu_lut[GELU_LUT_N + 1];
+
+__global__ void gelu_lut_init_kernel() {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > GELU_LUT_N) return;
+    const double x = -8.0 + i / 64.0;
+    g_gelu_lut[i] = float2{(float)(0.5 * (1.0 + erf(x * 0.70710678118654752440))),
+                           (float)(0.39894228040143267794 * exp(-0.5 * x * x))};
+}
+
+// Two values per call so that the arithmetic runs on the packed-f32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32);
+// the clamp, the float<->int conversions and the table address stay per value.  Phi is taken to first order as well
+// (error d^2 |phi'| / 2 <= 7.4e-6 for |d| <= 1/128).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_lut2(const char* lut, f32x2 x, f32x2& gl, f32x2& dg) {
+    f32x2 xc, fi, Phi, phi;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) xc[k] = __builtin_amdgcn_fmed3f(x[k], -8.0f, 8.0f);
+    const f32x2 t = xc * 64.0f + 512.5f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = (int)t[k];  // t in [0.5, 1024.5]: truncation = nearest grid point
+        const float2 e = *reinterpret_cast<const float2*>(lut + i * 8);
+        fi[k] = (float)i;
+        Phi[k] = e.x;
+        phi[k] = e.y;
+    }
+    const f32x2 xi = fi * 0.015625f - 8.0f;
+    const f32x2 d = xc - xi;
+    const f32x2 cdf = d * phi + Phi;
+    const f32x2 pdf = phi - (xi * d) * phi;
+    gl = x * cdf;
+    dg = x * pdf + cdf;
+}
 
 // v already holds acc (+ bias).  No data-dependent branch guards a load.
 template <int EPI>
@@ -60,15 +113,14 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, i
     } else if constexpr (EPI == BSCLIP_EPI_F32) {
         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
     } else if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
-        float gl[4], dg[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) gelu_both(v[i], gl[i], dg[i]);
-        if (e.aux) {  // store only: gelu'(pre-activation), all the backward pass needs
-            uint2 z;
-            z.x = pack_bf2(dg[0], dg[1]);
-            z.y = pack_bf2(dg[2], dg[3]);
-            *reinterpret_cast<uint2*>(e.aux + (size_t)m * e.ld_aux + n) = z;
-        }
+        // the same table-driven GELU as the 256x256 kernel (table read from global memory here: 8 KB, cache-resident), so a
+        // row's result does not depend on which tile shape its batch size selects (tests/test_configs_gpu.py)
+        f32x2 g0, d0, g1, d1;
+        gelu_lut2(reinterpret_cast<const char*>(g_gelu_lut), f32x2{v[0], v[1]}, g0, d0);
+        gelu_lut2(reinterpret_cast<const char*>(g_gelu_lut), f32x2{v[2], v[3]}, g1, d1);
+        const float gl[4] = {g0[0], g0[1], g1[0], g1[1]}, dg[4] = {d0[0], d0[1], d1[0], d1[1]};
+        if (e.aux)  // store only: gelu'(pre-activation) as 8-bit codes, all the backward pass needs
+            *reinterpret_cast<unsigned*>(e.aux + (size_t)m * e.ld_aux + n) = dg8_pack4(dg[0], dg[1], dg[2], dg[3]);
         uint2 o;
         o.x = pack_bf2(gl[0], gl[1]);
         o.y = pack_bf2(gl[2], gl[3]);
@@ -79,10 +131,10 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, i
         v += r;
         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
     } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
-        const uint2 z = *reinterpret_cast<const uint2*>(e.aux + (size_t)m * e.ld_aux + n);
+        const f32x4 z = dg8_unpack4(*reinterpret_cast<const unsigned*>(e.aux + (size_t)m * e.ld_aux + n));
         uint2 o;
-        o.x = pack_bf2(v[0] * bf2f(z.x & 0xffff), v[1] * bf2f(z.x >> 16));
-        o.y = pack_bf2(v[2] * bf2f(z.y & 0xffff), v[3] * bf2f(z.y >> 16));
+        o.x = pack_bf2(v[0] * z[0], v[1] * z[1]);
+        o.y = pack_bf2(v[2] * z[2], v[3] * z[3]);
         *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = o;
     } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
         const int b = m / 196, p = m - b * 196;
@@ -218,54 +270,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const bf
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// GELU table for the 256x256 kernel's epilogue
-// ---------------------------------------------------------------------------------------------------------------
-// The two-output GELU epilogue (gelu and gelu' of 128 values per lane) computed with exp + rcp was VALU-bound (~24
-// instructions per value, 12 us per tile with no MFMA to hide behind), and a 16-B-per-entry interpolation table was bound by
-// the LDS array instead: 64 lanes gathering random 16-B entries conflict ~3x per 16-lane group (phase stamps: 4.4 us per
-// 64-row slab).  Entries are therefore 8 B -- {Phi(x_i), phi(x_i)} on a 1/64 grid over [-8, 8], nearest grid point, one
-// ds_read_b64 per value -- and the neighbourhood comes from the derivatives, which are free: Phi' = phi, phi' = -x phi, so
-//   Phi(x_i + d) = Phi_i + d phi_i (1 - x_i d / 2) + O(d^3 |phi''| / 6)   <= 2e-8   for |d| <= 1/128,
-//   phi(x_i + d) = phi_i (1 - x_i d)               + O(d^2 |phi''| / 2)   <= 1.3e-5,
-// both far inside the bf16 rounding of the outputs.  Computed once on the device in f64 with erf().
-constexpr int GELU_LUT_N = 1024;                      // intervals
-constexpr int GELU_LUT_BYTES = (GELU_LUT_N + 1) * 8;  // 8200
-__device__ float2 g_gelu_lut[GELU_LUT_N + 1];
-
-__global__ void gelu_lut_init_kernel() {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > GELU_LUT_N) return;
-    const double x = -8.0 + i / 64.0;
-    g_gelu_lut[i] = float2{(float)(0.5 * (1.0 + erf(x * 0.70710678118654752440))),
-                           (float)(0.39894228040143267794 * exp(-0.5 * x * x))};
-}
-
-// Two values per call so that the arithmetic runs on the packed-f32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32);
-// the clamp, the float<->int conversions and the table address stay per value.  Phi is taken to first order as well
-// (error d^2 |phi'| / 2 <= 7.4e-6 for |d| <= 1/128).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gelu_lut2(const char* lut, f32x2 x, f32x2& gl, f32x2& dg) {
-    f32x2 xc, fi, Phi, phi;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) xc[k] = __builtin_amdgcn_fmed3f(x[k], -8.0f, 8.0f);
-    const f32x2 t = xc * 64.0f + 512.5f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = (int)t[k];  // t in [0.5, 1024.5]: truncation = nearest grid point
-        const float2 e = *reinterpret_cast<const float2*>(lut + i * 8);
-        fi[k] = (float)i;
-        Phi[k] = e.x;
-        phi[k] = e.y;
-    }
-    const f32x2 xi = fi * 0.015625f - 8.0f;
-    const f32x2 d = xc - xi;
-    const f32x2 cdf = d * phi + Phi;
-    const f32x2 pdf = phi - (xi * d) * phi;
-    gl = x * cdf;
-    dg = x * pdf + cdf;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // 256x256 ping-pong kernel
 // ---------------------------------------------------------------------------------------------------------------
 // LDS: 2 buffer sets x {A[256][64], B[256][64]} bf16 = 128 KiB; a "half" is 128 rows (16 KiB) = 16 wave-instructions of
@@ -283,13 +287,25 @@ __device__ __forceinline__ void gelu_lut2(const char* lut, f32x2 x, f32x2& gl, f
 //        reads of tile t+1 (phase 0) come after at least one more barrier for both groups.
 // ABL (diagnostic builds only): ablation mask for tools/gemm_ablate.py -- 1: no MFMA, 2: no LDS fragment reads, 4: no DMA,
 // 8: no barriers.  Results are garbage then; only the K-loop time is of interest.
-template <int EPI, bool HAS_BIAS, bool DIAG = false, int ABL = 0, int SCHED = 0>
+// OP: operand type of the main K loop.  0 = bf16 (v_mfma_f32_16x16x32_bf16).  1 / 2 = OCP fp8 e4m3 (BASELINE configs[4]): the
+// SAME LDS image, DMA schedule and ds_read_b128 fragment reads -- a 128-byte LDS row now holds 128 k-elements instead of 64, so
+// LDS-DMA and LDS-read bytes per FLOP halve (tools/gemm_ablate.py: the bf16 loop is limited as much by the DMA stream as by the
+// matrix pipe).  A lane's 16-byte fragment is 16 consecutive k of one row; any assignment of those bytes to MFMA k-slots is
+// valid as long as A and B use the same one, so
+//   OP 1: the two 8-byte halves feed two v_mfma_f32_16x16x32_fp8_fp8 (bf16 rate: gains the bytes only);
+//   OP 2: the fragments of both half-tiles (32 bytes) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales
+//         (E8M0 127): 2x the bf16 MFMA rate.
+// An optional LAST K-tile is bf16 (e.a_aug / e.b_aug, 64 columns): the LoRA branch t . B^T stays in bf16 and is added in the
+// accumulator's units (B_aug rows pre-divided by alpha[n]), then alpha[n] dequantises the sum in the epilogue.
+template <int EPI, bool HAS_BIAS, bool DIAG = false, int ABL = 0, int SCHED = 0, int OP = 0>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restrict__ A, int lda,
                                                           const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                           int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
+    static_assert(OP == 0 || (SCHED == 0 && ABL == 0), "fp8 operands: production schedule only");
+    constexpr int ESZ = OP == 0 ? 2 : 1;   // bytes per element of the main operands
     constexpr int SET = 65536, HALF = 16384, B_OFF = 32768;
     // main loop 128 KiB; epilogue slabs 2x64x1040 (f32) or 4x64x528 (bf16 x2) = 132 KiB, + 16 KiB GELU table
-    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 528 + (EPI == BSCLIP_EPI_GELU_BF16 ? GELU_LUT_BYTES : 0)];
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 528 + (EPI == BSCLIP_EPI_GELU_BF16 || EPI == BSCLIP_EPI_GELU_FP8 ? GELU_LUT_BYTES : 0)];
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
@@ -299,29 +315,49 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     const int g = wave >> 2, wc = wave & 3;
 
     // ---- LDS-DMA sources: for half h, this wave moves chunks (wave) and (wave+8): rows 128h + 8*chunk + (lane>>3) ----
-    const bf16_t* srcA[2][2];
-    const bf16_t* srcB[2][2];
+    // sources are byte pointers; K-tile t of the main operands starts t * 128 bytes into the row (64 bf16 / 128 fp8 elements)
+    const char* srcA[2][2];
+    const char* srcB[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = 128 * h + 8 * (wave + 8 * i) + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            srcA[h][i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
-            srcB[h][i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
+            srcA[h][i] = reinterpret_cast<const char*>(A) + (size_t)min(m0 + row, M - 1) * lda * ESZ + c * 16;
+            srcB[h][i] = reinterpret_cast<const char*>(B) + (size_t)min(n0 + row, N - 1) * ldb * ESZ + c * 16;
         }
+    const int nk_main = K / (BK * 2 / ESZ);
+    const bool aug = OP != 0 && e.a_aug != nullptr;   // wave-uniform
     const int dma_off = wave * 1024;  // + i*8192 + half*HALF (+ B_OFF) + set*SET
-    auto dmaA = [&](int set, int h, int k0) {
+    // the bf16 K-augmentation tile: its per-lane sources are recomputed when it is staged (once per workgroup) instead of
+    // living in 16 more VGPRs through the whole loop
+    auto aug_src = [&](const bf16_t* base, int ld, int r0, int rmax, int h, int i) {
+        const int row = 128 * h + 8 * (wave + 8 * i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        return reinterpret_cast<const char*>(base) + (size_t)min(r0 + row, rmax) * ld * 2 + c * 16;
+    };
+    auto dmaA = [&](int set, int h, int k0) {   // k0 = K-tile index * 128 (byte offset into the row)
         if constexpr (ABL & 4) return;
         char* d = smem + set * SET + h * HALF + dma_off;
-        glds16(srcA[h][0] + k0, d);
-        glds16(srcA[h][1] + k0, d + 8192);
+        if (OP != 0 && aug && k0 == nk_main * 128) {
+            glds16(aug_src(e.a_aug, e.ld_a_aug, m0, M - 1, h, 0), d);
+            glds16(aug_src(e.a_aug, e.ld_a_aug, m0, M - 1, h, 1), d + 8192);
+        } else {
+            glds16(srcA[h][0] + k0, d);
+            glds16(srcA[h][1] + k0, d + 8192);
+        }
     };
     auto dmaB = [&](int set, int h, int k0) {
         if constexpr (ABL & 4) return;
         char* d = smem + set * SET + B_OFF + h * HALF + dma_off;
-        glds16(srcB[h][0] + k0, d);
-        glds16(srcB[h][1] + k0, d + 8192);
+        if (OP != 0 && aug && k0 == nk_main * 128) {
+            glds16(aug_src(e.b_aug, e.ld_b_aug, n0, N - 1, h, 0), d);
+            glds16(aug_src(e.b_aug, e.ld_b_aug, n0, N - 1, h, 1), d + 8192);
+        } else {
+            glds16(srcB[h][0] + k0, d);
+            glds16(srcB[h][1] + k0, d + 8192);
+        }
     };
 
     // ---- fragment read offsets ----
@@ -369,16 +405,46 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             for (int j = 0; j < 2; ++j)
                 fb[ni][ks][j] = *reinterpret_cast<const bf16x8*>(base + ((b_off ^ (ks << 6)) + (32 * ni + 16 * j) * ROW_BYTES));
     };
+    bool bf16_tile = OP == 0;   // fp8 builds: true only while the K-augmentation tile is being multiplied (wave-uniform)
     auto mma = [&](int mi, int ni) {
         if constexpr (ABL & 1) return;
         __builtin_amdgcn_s_setprio(1);
+        if (OP == 0 || bf16_tile) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[mi][ni][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni][ks][j], fa[mi][ks][i], acc[mi][ni][i][j], 0, 0, 0);
+        } else if constexpr (OP == 1) {
+            typedef long i64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const i64x2 a2 = __builtin_bit_cast(i64x2, fa[mi][ks][i]), b2 = __builtin_bit_cast(i64x2, fb[ni][ks][j]);
+                        acc[mi][ni][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[0], a2[0], acc[mi][ni][i][j], 0, 0, 0);
+                        acc[mi][ni][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[1], a2[1], acc[mi][ni][i][j], 0, 0, 0);
+                    }
+        } else if constexpr (OP == 2) {
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            typedef int i32x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[mi][ni][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni][ks][j], fa[mi][ks][i], acc[mi][ni][i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    const i32x4 a0 = __builtin_bit_cast(i32x4, fa[mi][0][i]), a1 = __builtin_bit_cast(i32x4, fa[mi][1][i]);
+                    const i32x4 b0 = __builtin_bit_cast(i32x4, fb[ni][0][j]), b1 = __builtin_bit_cast(i32x4, fb[ni][1][j]);
+                    const i32x8 a8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const i32x8 b8 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    // cbsz = blgp = 0: both operands OCP e4m3; block scales 2^(127-127) = 1 for every 32-element block
+                    acc[mi][ni][i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8, a8, acc[mi][ni][i][j], 0, 0, 0,
+                                                                                         0x7f7f7f7f, 0, 0x7f7f7f7f);
+                }
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 #define PP_BARRIER()                                           \
@@ -394,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         }
     };
     stamp(0);
-    const int nk = K / BK;
+    const int nk = nk_main + (aug ? 1 : 0);
 #ifdef BSCLIP_DIAG
     if constexpr (SCHED == 1) {
         // Deep-prefetch variant, kept for comparison (bsclip_gemm_set_tile(6)); NOT the default.  tools/gemm_ablate.py shows the
@@ -415,10 +481,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         dmaB(0, 0, 0);
         dmaB(0, 1, 0);
         if (nk > 1) {
-            dmaA(1, 0, BK);
-            dmaA(1, 1, BK);
-            dmaB(1, 0, BK);
-            dmaB(1, 1, BK);
+            dmaA(1, 0, 2 * BK);
+            dmaA(1, 1, 2 * BK);
+            dmaB(1, 0, 2 * BK);
+            dmaB(1, 1, 2 * BK);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -430,7 +496,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             const int set = t & 1;
             const char* base = smem + set * SET;
             const bool has2 = t + 2 < nk;
-            const int k2 = (t + 2) * BK;
+            const int k2 = (t + 2) * 2 * BK;
             // ---- phase 0 ----
             readA(base, 0);
             readB(base, 0);
@@ -482,9 +548,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         dmaB(0, 0, 0);
         dmaB(0, 1, 0);
         if (nk > 1) {
-            dmaA(1, 0, BK);
+            dmaA(1, 0, 2 * BK);
             if (g == 1) {
-                dmaA(1, 1, BK);
+                dmaA(1, 1, 2 * BK);
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -502,7 +568,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             const int set = t & 1;
             const char* base = smem + set * SET;
             const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
-            const int k1 = (t + 1) * BK, k2 = (t + 2) * BK;
+            const int k1 = (t + 1) * 2 * BK, k2 = (t + 2) * 2 * BK;
             // ---- phase 0 ----
             BAR_G1();
             if (has1) {
@@ -557,7 +623,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         dmaB(0, 0, 0);
         dmaB(0, 1, 0);
         if (nk > 1) {
-            dmaA(1, 0, BK);
+            dmaA(1, 0, 2 * BK);
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -570,7 +636,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             const int set = t & 1;
             const char* base = smem + set * SET;
             const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
-            const int k1 = (t + 1) * BK, k2 = (t + 2) * BK;
+            const int k1 = (t + 1) * 2 * BK, k2 = (t + 2) * 2 * BK;   // byte offsets of K-tiles t+1, t+2
+            if constexpr (OP != 0) bf16_tile = aug && t == nk - 1;
             // ---- phase 0 ----
             if (has1) dmaA(set ^ 1, 1, k1);
             readA(base, 0);
@@ -618,6 +685,22 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             if constexpr (HAS_BIAS)
                 bias[ni][j] = *reinterpret_cast<const f32x4*>(e.bias + n0 + 64 * wc + 32 * ni + 16 * j + fq * 4);
         }
+    if constexpr (OP != 0) {  // dequantise: alpha[n] = activation scale x weight-row scale
+        f32x4 al[2][2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                al[ni][j] = *reinterpret_cast<const f32x4*>(e.alpha + n0 + 64 * wc + 32 * ni + 16 * j + fq * 4);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[mi][ni][i][j] *= al[ni][j];
+    }
     if constexpr (HAS_BIAS) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -640,12 +723,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     const int wq = wave & 3;
     __syncthreads();  // every wave is past its last fragment read
     const char* lut = smem + 4 * 64 * SB;
-    if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {  // 16 KiB table, L2-resident, behind the slabs
+    constexpr bool GELU = EPI == BSCLIP_EPI_GELU_BF16 || EPI == BSCLIP_EPI_GELU_FP8;
+    if constexpr (GELU) {  // 16 KiB table, L2-resident, behind the slabs
         for (int i = tid; i <= GELU_LUT_N; i += 512)
             *reinterpret_cast<float2*>(smem + 4 * 64 * SB + i * 8) = g_gelu_lut[i];
         __syncthreads();
     }
-    char* slab2 = smem + 2 * 64 * SB + g * (64 * SB);  // second bf16 slab (GELU: gelu' side band)
+    constexpr int S8 = 272;   // 8-bit slab row stride (256 + 16)
+    char* slab2 = smem + 2 * 64 * SB + g * (64 * S8);  // second slab (GELU: gelu' side band, 8-bit codes)
     auto stage_bf16 = [&](int mi) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -656,16 +741,20 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                     const f32x4 v = acc[mi][ni][i][j];
                     const int off = (16 * i + fr) * SB + (64 * wc + 32 * ni + 16 * j + 4 * fq) * 2;
                     uint2 o;
-                    if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
+                    if constexpr (GELU) {
                         f32x2 gl0, dg0, gl1, dg1;
                         gelu_lut2(lut, f32x2{v[0], v[1]}, gl0, dg0);
                         gelu_lut2(lut, f32x2{v[2], v[3]}, gl1, dg1);
+                        *reinterpret_cast<unsigned*>(slab2 + (16 * i + fr) * S8 + (64 * wc + 32 * ni + 16 * j + 4 * fq)) =
+                            dg8_pack4(dg0[0], dg0[1], dg1[0], dg1[1]);
+                        if constexpr (EPI == BSCLIP_EPI_GELU_FP8) {  // the next GEMM's fp8 operand: e4m3, scale 1, saturated
+                            *reinterpret_cast<unsigned*>((g ? smem + 64 * SB : smem) + (16 * i + fr) * S8 +
+                                                         (64 * wc + 32 * ni + 16 * j + 4 * fq)) =
+                                pack_fp8x4(gl0[0], gl0[1], gl1[0], gl1[1]);
+                            continue;
+                        }
                         o.x = pack_bf2(gl0[0], gl0[1]);
                         o.y = pack_bf2(gl1[0], gl1[1]);
-                        uint2 d;
-                        d.x = pack_bf2(dg0[0], dg0[1]);
-                        d.y = pack_bf2(dg1[0], dg1[1]);
-                        *reinterpret_cast<uint2*>(slab2 + off) = d;
                     } else {
                         o.x = pack_bf2(v[0], v[1]);
                         o.y = pack_bf2(v[2], v[3]);
@@ -682,6 +771,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             if (m < M) *reinterpret_cast<uint4*>(dst + (size_t)m * ld + n0 + (lane & 31) * 8) = v;
         }
     };
+    // 64 x 256 B slab of 8-bit codes: 16 lanes x 16 B per row, 16 rows per pass of the group's 256 threads
+    auto rows_u8 = [&](int mi, const char* src, unsigned char* dst, int ld) {
+        const int t = tid & 255;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 16 + (t >> 4);
+            const int m = m0 + 128 * g + 64 * mi + r;
+            const uint4 v = *reinterpret_cast<const uint4*>(src + r * S8 + (t & 15) * 16);
+            if (m < M) *reinterpret_cast<uint4*>(dst + (size_t)m * ld + n0 + (t & 15) * 16) = v;
+        }
+    };
     auto stage_f32 = [&](int mi) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -694,19 +794,20 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     };
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        if constexpr (EPI == BSCLIP_EPI_BF16 || EPI == BSCLIP_EPI_GELU_BF16) {
+        if constexpr (EPI == BSCLIP_EPI_BF16 || GELU) {
             stage_bf16(mi);
             __syncthreads();
             stamp(4 + 2 * mi);
-            rows_bf16(mi, smem + g * (64 * SB), static_cast<bf16_t*>(C), ldc);
-            if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
-                if (e.aux) rows_bf16(mi, slab2, e.aux, e.ld_aux);  // gelu'(pre-activation) for the backward pass
+            if constexpr (EPI == BSCLIP_EPI_GELU_FP8) rows_u8(mi, smem + g * (64 * SB), static_cast<unsigned char*>(C), ldc);
+            else rows_bf16(mi, smem + g * (64 * SB), static_cast<bf16_t*>(C), ldc);
+            if constexpr (GELU) {
+                if (e.aux) rows_u8(mi, slab2, e.aux, e.ld_aux);  // gelu'(pre-activation) for the backward pass
             }
             __syncthreads();
             stamp(5 + 2 * mi);
         }
     }
-    if constexpr (!(EPI == BSCLIP_EPI_BF16 || EPI == BSCLIP_EPI_GELU_BF16)) {
+    if constexpr (!(EPI == BSCLIP_EPI_BF16 || GELU)) {
         // f32-staged epilogues read a second operand (residual stream / saved gelu') row-wise.  Those loads do not
         // depend on the accumulators, so they are issued one slab ahead -- before the staging barrier -- and have the
         // whole LDS round trip to land (issued just-in-time they were 16 serial HBM round trips per wave: 26 us/tile).
@@ -719,8 +820,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
                     R[it] = *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
                 } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
-                    const uint2 z = *reinterpret_cast<const uint2*>(e.aux + (size_t)m * e.ld_aux + n);
-                    R[it] = f32x4{bf2f(z.x & 0xffff), bf2f(z.x >> 16), bf2f(z.y & 0xffff), bf2f(z.y >> 16)};
+                    R[it] = dg8_unpack4(*reinterpret_cast<const unsigned*>(e.aux + (size_t)m * e.ld_aux + n));
                 } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
                     R[it] = *reinterpret_cast<const f32x4*>(e.resid + (size_t)(1 + m % 196) * e.ld_resid + n);
                 } else {
@@ -789,10 +889,6 @@ bool g_lut_ready = false;
 template <int EPI, bool HB, int SCHED = 0>
 void launch_pp(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
                const EpiArgs& e, hipStream_t s) {
-    if (EPI == BSCLIP_EPI_GELU_BF16 && !g_lut_ready) {  // once per process, stream-ordered ahead of the first consumer
-        hipLaunchKernelGGL(gelu_lut_init_kernel, dim3(ceil_div(GELU_LUT_N + 1, 256)), dim3(256), 0, s);
-        g_lut_ready = true;
-    }
     const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
     hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, HB, false, 0, SCHED>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, lda, B,
                        ldb, C, ldc, M, N, K, tiles_n, e);
@@ -801,6 +897,10 @@ void launch_pp(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int 
 template <int EPI, bool HB>
 void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
                 const EpiArgs& e, hipStream_t s) {
+    if (EPI == BSCLIP_EPI_GELU_BF16 && !g_lut_ready) {  // once per process, stream-ordered ahead of the first consumer
+        hipLaunchKernelGGL(gelu_lut_init_kernel, dim3(ceil_div(GELU_LUT_N + 1, 256)), dim3(256), 0, s);
+        g_lut_ready = true;
+    }
     int tile = g_tile_override;
     if (tile == 0) {
         // 256x256 (8 waves, 1 block/CU) halves L2->LDS traffic per FLOP; fall back when N is not a multiple of
@@ -824,6 +924,18 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
     }
 }
 
+template <int EPI, int OP>
+void launch_f8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
+               hipStream_t s) {
+    if (EPI == BSCLIP_EPI_GELU_FP8 && !g_lut_ready) {
+        hipLaunchKernelGGL(gelu_lut_init_kernel, dim3(ceil_div(GELU_LUT_N + 1, 256)), dim3(256), 0, s);
+        g_lut_ready = true;
+    }
+    const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, false, 0, 0, OP>), dim3(tiles_m * tiles_n), dim3(512), 0, s,
+                       static_cast<const bf16_t*>(A), lda, static_cast<const bf16_t*>(B), ldb, C, ldc, M, N, K, tiles_n, e);
+}
+
 template <int EPI>
 void launch_bias(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K,
                  const EpiArgs& e, hipStream_t s) {
@@ -844,7 +956,7 @@ extern "C" int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, 
     e.bias = args->bias;
     e.resid = args->resid;
     e.ld_resid = args->ld_resid;
-    e.aux = static_cast<bf16_t*>(args->aux);
+    e.aux = static_cast<unsigned char*>(args->aux);
     e.ld_aux = args->ld_aux;
     e.drop = make_drop(0.f, 0);
     e.n_total = N;
@@ -931,8 +1043,11 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
         e.bias = args->bias;
         e.resid = args->resid;
         e.ld_resid = args->ld_resid;
-        e.aux = static_cast<bf16_t*>(args->aux);
+        e.aux = static_cast<unsigned char*>(args->aux);
         e.ld_aux = args->ld_aux;
+        BSCLIP_REQUIRE(!e.aux || (e.ld_aux >= N && e.ld_aux % 16 == 0 && (((uintptr_t)e.aux) & 15) == 0),
+                       "bsclip_gemm_bf16: aux (8-bit gelu' band) needs ld_aux >= N, ld_aux %% 16 == 0, 16-B alignment (ld_aux=%d)",
+                       args->ld_aux);
         BSCLIP_REQUIRE(args->dropout_p >= 0.f && args->dropout_p < 1.f, "bsclip_gemm_bf16: dropout_p=%f", args->dropout_p);
         BSCLIP_REQUIRE(args->dropout_p == 0.f || epilogue == BSCLIP_EPI_RESID_F32,
                        "bsclip_gemm_bf16: dropout is only defined for BSCLIP_EPI_RESID_F32");
@@ -961,6 +1076,117 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
             break;
         default: BSCLIP_REQUIRE(false, "bsclip_gemm_bf16: unknown epilogue %d", epilogue);
     }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp8 entry points (BASELINE configs[4])
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int bsclip_gemm_fp8(const void* A8, int lda, const void* B8, int ldb, void* C, int ldc, int M, int N, int K,
+                               int epilogue, const bsclip_epi_args* args, const bsclip_fp8_args* f8, void* stream) {
+    BSCLIP_REQUIRE(A8 && B8 && C && args && f8, "bsclip_gemm_fp8: null pointer");
+    BSCLIP_REQUIRE(args->struct_size == sizeof(bsclip_epi_args) && f8->struct_size == sizeof(bsclip_fp8_args),
+                   "bsclip_gemm_fp8: struct_size mismatch (epi %u/%zu, fp8 %u/%zu)", args->struct_size,
+                   sizeof(bsclip_epi_args), f8->struct_size, sizeof(bsclip_fp8_args));
+    BSCLIP_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0 && N % 256 == 0, "bsclip_gemm_fp8: M=%d N=%d K=%d (K %% 128, N %% 256)",
+                   M, N, K);
+    BSCLIP_REQUIRE(lda >= K && ldb >= K && lda % 16 == 0 && ldb % 16 == 0, "bsclip_gemm_fp8: lda=%d ldb=%d (K=%d)", lda, ldb, K);
+    BSCLIP_REQUIRE(ldc >= N && ldc % 4 == 0 && (epilogue != BSCLIP_EPI_GELU_FP8 || ldc % 16 == 0), "bsclip_gemm_fp8: ldc=%d", ldc);
+    BSCLIP_REQUIRE((((uintptr_t)A8 | (uintptr_t)B8 | (uintptr_t)C) & 15) == 0, "bsclip_gemm_fp8: 16-B alignment");
+    BSCLIP_REQUIRE(args->bias && f8->alpha && ((((uintptr_t)args->bias | (uintptr_t)f8->alpha)) & 15) == 0,
+                   "bsclip_gemm_fp8: bias and alpha are required, 16-B aligned");
+    BSCLIP_REQUIRE((f8->a_aug == nullptr) == (f8->b_aug == nullptr), "bsclip_gemm_fp8: a_aug and b_aug go together");
+    BSCLIP_REQUIRE(!f8->a_aug || (f8->ld_a_aug >= 64 && f8->ld_b_aug >= 64 && f8->ld_a_aug % 8 == 0 && f8->ld_b_aug % 8 == 0 &&
+                                  (((uintptr_t)f8->a_aug | (uintptr_t)f8->b_aug) & 15) == 0),
+                   "bsclip_gemm_fp8: K-augmentation block needs ld >= 64, ld %% 8 == 0, 16-B alignment");
+    BSCLIP_REQUIRE(f8->form == 1 || f8->form == 2, "bsclip_gemm_fp8: form %d (1 or 2)", f8->form);
+    EpiArgs e{};
+    e.bias = args->bias;
+    e.resid = args->resid;
+    e.ld_resid = args->ld_resid;
+    e.aux = static_cast<unsigned char*>(args->aux);
+    e.ld_aux = args->ld_aux;
+    BSCLIP_REQUIRE(!e.aux || (e.ld_aux >= N && e.ld_aux % 16 == 0 && (((uintptr_t)e.aux) & 15) == 0), "bsclip_gemm_fp8: aux band");
+    BSCLIP_REQUIRE(args->dropout_p >= 0.f && args->dropout_p < 1.f && (args->dropout_p == 0.f || epilogue == BSCLIP_EPI_RESID_F32),
+                   "bsclip_gemm_fp8: dropout_p=%f", args->dropout_p);
+    e.drop = make_drop(args->dropout_p, args->dropout_seed);
+    e.n_total = N;
+    e.alpha = f8->alpha;
+    e.a_aug = static_cast<const bf16_t*>(f8->a_aug);
+    e.b_aug = static_cast<const bf16_t*>(f8->b_aug);
+    e.ld_a_aug = f8->ld_a_aug;
+    e.ld_b_aug = f8->ld_b_aug;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define F8_CASE(EPI)                                                                   \
+    case EPI:                                                                          \
+        if (f8->form == 1) launch_f8<EPI, 1>(A8, lda, B8, ldb, C, ldc, M, N, K, e, s); \
+        else launch_f8<EPI, 2>(A8, lda, B8, ldb, C, ldc, M, N, K, e, s);               \
+        break;
+    switch (epilogue) {
+        F8_CASE(BSCLIP_EPI_BF16)
+        F8_CASE(BSCLIP_EPI_F32)
+        F8_CASE(BSCLIP_EPI_GELU_FP8)
+        case BSCLIP_EPI_RESID_F32:
+            BSCLIP_REQUIRE(e.resid && e.ld_resid >= N, "bsclip_gemm_fp8: RESID needs resid/ld_resid");
+            if (f8->form == 1) launch_f8<BSCLIP_EPI_RESID_F32, 1>(A8, lda, B8, ldb, C, ldc, M, N, K, e, s);
+            else launch_f8<BSCLIP_EPI_RESID_F32, 2>(A8, lda, B8, ldb, C, ldc, M, N, K, e, s);
+            break;
+        default: BSCLIP_REQUIRE(false, "bsclip_gemm_fp8: epilogue %d not available with fp8 operands", epilogue);
+    }
+#undef F8_CASE
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+namespace {
+// one wave per row: amax -> scale = amax / 448, then e4m3 codes of src / scale
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const float* __restrict__ src, int R, int C,
+                                                                unsigned char* __restrict__ dst, int ld, float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (row >= R) return;
+    const float* p = src + (size_t)row * C;
+    float m = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    m = wave_max(m);
+    const float sc = m > 0.f ? m * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+        *reinterpret_cast<unsigned*>(dst + (size_t)row * ld + c) = pack_fp8x4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+    }
+}
+
+__global__ void lora_baug_set_kernel(bf16_t* __restrict__ b_aug, int ld, int H, const float* __restrict__ bq,
+                                     const float* __restrict__ bv, const float* __restrict__ alpha) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over H * 4
+    if (i >= H * 4) return;
+    const int n = i >> 2, r = i & 3;
+    b_aug[(size_t)n * ld + r] = f2bf(bq[i] / alpha[n]);
+    b_aug[(size_t)(2 * H + n) * ld + 4 + r] = f2bf(bv[i] / alpha[2 * H + n]);
+}
+}  // namespace
+
+extern "C" int bsclip_quantize_rows_fp8(const float* src, int R, int C, void* dst, int ld_dst, float* scale, void* stream) {
+    BSCLIP_REQUIRE(src && dst && scale && R > 0 && C > 0 && C % 4 == 0 && ld_dst >= C && ld_dst % 4 == 0,
+                   "bsclip_quantize_rows_fp8: R=%d C=%d ld_dst=%d", R, C, ld_dst);
+    BSCLIP_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "bsclip_quantize_rows_fp8: 16-B alignment");
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), src, R, C,
+                       static_cast<unsigned char*>(dst), ld_dst, scale);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_lora_baug_set(void* b_aug, int ld_b, int H, const float* lora_bq, const float* lora_bv,
+                                    const float* alpha, void* stream) {
+    BSCLIP_REQUIRE(b_aug && lora_bq && lora_bv && alpha && H > 0 && ld_b >= 8, "bsclip_lora_baug_set: bad args");
+    hipLaunchKernelGGL(lora_baug_set_kernel, dim3(ceil_div(H * 4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<bf16_t*>(b_aug), ld_b, H, lora_bq, lora_bv, alpha);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void meanpool_tokens_bwd_kernel(const float* _
     *reinterpret_cast<f32x4*>(dx + (size_t)row * H + c) = g;
 }
 
-// out = g * d (d = gelu'(pre-activation) saved by the forward GELU epilogue), 4 bf16 per thread
+// out = g * d (d = gelu'(pre-activation) saved by the forward GELU epilogue as 8-bit codes), 4 values per thread
 __global__ __launch_bounds__(256) void dgelu_mul_kernel(const bf16_t* __restrict__ g, int ld_g,
-                                                         const bf16_t* __restrict__ z, int ld_z, int M, int N,
+                                                         const unsigned char* __restrict__ z, int ld_z, int M, int N,
                                                          bf16_t* __restrict__ out, int ld_o) {
     const int per = N / 4;
     const long total = (long)M * per;
@@ -133,10 +133,10 @@ __global__ __launch_bounds__(256) void dgelu_mul_kernel(const bf16_t* __restrict
         const long row = it / per;
         const int c = (int)(it % per) * 4;
         const uint2 gu = *reinterpret_cast<const uint2*>(g + row * ld_g + c);
-        const uint2 zu = *reinterpret_cast<const uint2*>(z + row * ld_z + c);
+        const f32x4 d = dg8_unpack4(*reinterpret_cast<const unsigned*>(z + row * ld_z + c));
         uint2 o;
-        o.x = pack_bf2(bf2f(gu.x & 0xffff) * bf2f(zu.x & 0xffff), bf2f(gu.x >> 16) * bf2f(zu.x >> 16));
-        o.y = pack_bf2(bf2f(gu.y & 0xffff) * bf2f(zu.y & 0xffff), bf2f(gu.y >> 16) * bf2f(zu.y >> 16));
+        o.x = pack_bf2(bf2f(gu.x & 0xffff) * d[0], bf2f(gu.x >> 16) * d[1]);
+        o.y = pack_bf2(bf2f(gu.y & 0xffff) * d[2], bf2f(gu.y >> 16) * d[3]);
         *reinterpret_cast<uint2*>(out + row * ld_o + c) = o;
     }
 }
@@ -151,7 +151,7 @@ extern "C" int bsclip_dgelu_mul(const void* g, int ld_g, const void* z, int ld_z
     long blocks = ((long)M * (N / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(dgelu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16_t*>(g), ld_g, static_cast<const bf16_t*>(z), ld_z, M, N,
+                       static_cast<const bf16_t*>(g), ld_g, static_cast<const unsigned char*>(z), ld_z, M, N,
                        static_cast<bf16_t*>(out), ld_o);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;

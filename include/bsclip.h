@@ -42,17 +42,19 @@ int bsclip_abi_version(void);
 enum bsclip_epilogue {
     BSCLIP_EPI_BF16 = 0,       /* C bf16 = acc + bias                                               */
     BSCLIP_EPI_F32 = 1,        /* C f32  = acc + bias                                               */
-    BSCLIP_EPI_GELU_BF16 = 2,  /* C bf16 = gelu(acc + bias); aux (bf16, optional) = gelu'(acc + bias) */
+    BSCLIP_EPI_GELU_BF16 = 2,  /* C bf16 = gelu(acc + bias); aux (uint8 codes, optional) = gelu'(acc + bias) */
     BSCLIP_EPI_RESID_F32 = 3,  /* C f32  = acc + bias + resid                                       */
-    BSCLIP_EPI_DGELU_BF16 = 4, /* C bf16 = acc * aux          (aux bf16 = gelu' saved by the forward) */
-    BSCLIP_EPI_PATCH_F32 = 5   /* C f32 row (b*197+1+p) = acc + bias + pos[1+p], input row b*196+p  */
+    BSCLIP_EPI_DGELU_BF16 = 4, /* C bf16 = acc * aux          (aux = gelu' codes saved by the forward) */
+    BSCLIP_EPI_PATCH_F32 = 5,  /* C f32 row (b*197+1+p) = acc + bias + pos[1+p], input row b*196+p  */
+    BSCLIP_EPI_GELU_FP8 = 6    /* bsclip_gemm_fp8 only: C fp8 e4m3 = gelu(..) (the next GEMM's operand); aux as GELU_BF16 */
 };
 typedef struct bsclip_epi_args {
     uint32_t struct_size; /* = sizeof(bsclip_epi_args) = bsclip_epi_args_size(); a mismatch is rejected (ABI drift guard) */
     const float* bias;    /* [N] or NULL */
     const float* resid; /* RESID: f32 [M, ld_resid]; PATCH: pos_embed f32 [197, N] */
     int ld_resid;
-    void* aux; /* GELU: bf16 out (nullable); DGELU: bf16 in */
+    void* aux; /* gelu' side band, uint8 [M, ld_aux]: code = round((gelu' + 0.13) * 255 / 1.26); GELU: out (nullable), DGELU: in;
+                * ld_aux % 16 == 0, 16-byte aligned */
     int ld_aux;
     float dropout_p;        /* RESID only: C = dropout(acc + bias) + resid (HF hidden_dropout_prob); 0 = off */
     uint32_t dropout_seed;  /* decision of element (m,n) = f(seed, m*N + n): see bsclip_layernorm_bwd */
@@ -61,6 +63,35 @@ int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, in
                      int epilogue, const bsclip_epi_args* args, void* stream);
 /* sizeof(bsclip_epi_args) as this library was compiled; bindings assert their own struct against it */
 int bsclip_epi_args_size(void);
+
+/* ---- fp8 GEMM (BASELINE.json configs[4]: fp8 MFMA encoders, bf16 LoRA / loss) ------------------------------------
+ * C = epilogue(alpha[n] * (A8[M,K] . B8[N,K]^T + A_aug[M,64] . B_aug[N,64]^T) + bias[n]) on the 256x256 ping-pong kernel.
+ * A8 / B8: OCP fp8 e4m3 bytes, row-major, lda/ldb in elements (= bytes), K % 128 == 0, N % 256 == 0, lda/ldb % 16 == 0.
+ * alpha f32 [N]: dequantisation scale per output column (activation scale x weight-row scale; bsclip_quantize_rows_fp8).
+ * a_aug / b_aug (both or neither): bf16 K-augmentation block multiplied on the bf16 MFMA as the last K-tile -- the LoRA
+ *   branch: a_aug = t columns written by bsclip_layernorm_fwd (y_fp8 mode), b_aug = LoRA-B columns / alpha[n]
+ *   (bsclip_lora_baug_set).  ld_* in bf16 elements, % 8 == 0.
+ * form: 1 = v_mfma_f32_16x16x32_fp8_fp8 (bf16 MFMA rate, half the operand bytes); 2 = v_mfma_scale_f32_16x16x128_f8f6f4 with
+ *   unit block scales (2x the bf16 MFMA rate).  Identical results (exact products, f32 accumulation; summation order differs).
+ * epilogue: BSCLIP_EPI_BF16, _F32, _RESID_F32 (+ dropout), _GELU_FP8.  args->bias is required. */
+typedef struct bsclip_fp8_args {
+    uint32_t struct_size; /* = sizeof(bsclip_fp8_args) */
+    int form;
+    const float* alpha;
+    const void* a_aug;
+    int ld_a_aug;
+    const void* b_aug;
+    int ld_b_aug;
+} bsclip_fp8_args;
+int bsclip_gemm_fp8(const void* A8, int lda, const void* B8, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
+                    const bsclip_epi_args* args, const bsclip_fp8_args* f8, void* stream);
+/* Row-wise quantisation of frozen weights: src f32 [R, C] -> dst fp8 e4m3 [R, ld_dst], scale[r] = amax(src[r,:]) / 448
+ * (1 for an all-zero row), dst = round(src / scale[r]).  C % 4 == 0. */
+int bsclip_quantize_rows_fp8(const float* src, int R, int C, void* dst, int ld_dst, float* scale, void* stream);
+/* b_aug[3H, 64] bf16 (zero outside the LoRA columns): cols [0,4) of rows [0,H) = B_q / alpha, cols [4,8) of rows [2H,3H) =
+ * B_v / alpha, refreshed every step from the f32 masters (the fp8 counterpart of bsclip_waug_set_lora). */
+int bsclip_lora_baug_set(void* b_aug, int ld_b, int H, const float* lora_bq, const float* lora_bv, const float* alpha,
+                         void* stream);
 /* one-time device tables (GELU Phi/phi table of the 256x256 kernel's epilogue).  bsclip_gemm_bf16 fills them lazily on
  * its own stream; call this once (and synchronise) before launching GEMMs from several streams. */
 int bsclip_init_tables(void* stream);
@@ -145,7 +176,7 @@ int bsclip_softmax_meanpool_bwd(const float* logits, const float* stats, const f
 int bsclip_meanpool_tokens_fwd(const float* x, int B, int S, int H, void* out_bf16, int ld_out, void* stream);
 /* autograd of the mean: dx[b,t,:] = d_pooled[b,:] / S  (f32 [B*S, H]) */
 int bsclip_meanpool_tokens_bwd(const float* d_pooled, int ld_d, int B, int S, int H, float* dx, void* stream);
-/* out = g * z elementwise (bf16 [M,N]), z = gelu'(pre-activation) as saved by BSCLIP_EPI_GELU_BF16: autograd of the
+/* out = g * z elementwise (g, out bf16 [M,N]; z uint8 codes), z = gelu'(pre-activation) as saved by BSCLIP_EPI_GELU_BF16: autograd of the
  * GELU inside cls.predictions.transform, where the producer of g is the LayerNorm backward rather than a GEMM. */
 int bsclip_dgelu_mul(const void* g, int ld_g, const void* z, int ld_z, int M, int N, void* out, int ld_o, void* stream);
 int bsclip_l2norm_fwd(const float* x, int M, int D, float* y, float* inv_norm, void* stream);

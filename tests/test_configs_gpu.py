@@ -1,0 +1,148 @@
+"""Full-size correctness properties for the BASELINE.json configurations the fixture-sized parity tests cannot reach:
+
+  configs[1] / [2]  local batch 256 (the bench shape, 256x256 ping-pong GEMM tiles, 50 432-row operands)
+  configs[3]        local batch 1 024 and the N = 8 192 global-batch loss (one rank's eighth of the rows)
+  a9                the four LR schedulers of scripts/train_cl.py:160-181 driving FusedAdamW
+
+The CPU oracle cannot run B = 256 in seconds, so the encoders are held to a size-independent property instead: samples are
+independent (LayerNorm only, no batch statistics), hence rows 0..7 of a B-sample forward equal the 8-sample forward of the
+same samples, and with a cotangent that is zero outside those rows the trainable gradients are equal too.  The 8-sample run
+is the shape the golden fixtures pin (tests/test_encoders_gpu.py); the large run takes different kernels (tile shapes, grids,
+workspace strides), so the comparison is not vacuous.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import rel_err  # noqa: E402
+from oracle import refcpu, synth  # noqa: E402
+
+NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _towers(with_text):
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from bioscanclip.model.language_encoder import LoRA_bert
+    from bioscanclip.model.simple_clip import SimpleCLIP
+    model = SimpleCLIP(LoRA_ViT_timm(arch.vit_base_patch16_224(), r=4, num_classes=768),
+                       LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(**NODROP)), r=4, num_classes=768),
+                       LoRA_bert(arch.BertModelParams(arch.bert_small_config(**NODROP)), r=4, num_classes=768)
+                       if with_text else None)
+    model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=61))
+    return model.cuda().train()
+
+
+def _run(model, image, dna, text, cot, n_keep):
+    """Forward + backward with the cotangent applied to the first n_keep rows of every modality only."""
+    for p in model.parameters():
+        p.grad = None
+    outs = [o for o in model(image, dna, text) if o is not None]
+    total = sum((o[:n_keep] * c).sum() for o, c in zip(outs, cot))
+    total.backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+    return [o.detach()[:n_keep].clone() for o in outs], grads
+
+
+@pytest.mark.parametrize("B,with_text", [(256, False), (256, True), (1024, False)])
+def test_large_batch_equals_small_batch_on_shared_rows(B, with_text):
+    n = 8
+    model = _towers(with_text)
+    image, dna, text, _ = synth.synth_batch(n, seed=71, with_text=with_text)
+    # the other B - n samples: more synthetic samples, tiled (their content only has to be valid input)
+    fill_i, fill_d, fill_t, _ = synth.synth_batch(56, seed=72, with_text=with_text)
+    reps = (B - n + 55) // 56
+    big_i = torch.cat([image, fill_i.repeat(reps, 1, 1, 1)[:B - n]]).cuda()
+    big_d = torch.cat([dna, fill_d.repeat(reps, 1)[:B - n]]).cuda()
+    big_t = None
+    if with_text:
+        big_t = {k: torch.cat([text[k], fill_t[k].repeat(reps, 1)[:B - n]]).cuda() for k in text}
+        text = {k: v.cuda() for k, v in text.items()}
+    nmod = 3 if with_text else 2
+    cot = [synth.synth_tensor(f"cfg.cot.{i}", (n, 768), seed=5).cuda() for i in range(nmod)]
+    y_small, g_small = _run(model, image.cuda(), dna.cuda(), text, cot, n)
+    y_big, g_big = _run(model, big_i, big_d, big_t, cot, n)
+    for a, b in zip(y_big, y_small):
+        assert rel_err(a, b) < 2e-6, rel_err(a, b)          # same arithmetic per row: f32 accumulation order at most
+    worst = max(rel_err(g_big[k], g_small[k]) for k in g_small)
+    # gradients are sums over all rows of the batch: the B - n rows with zero cotangent contribute exact zeros, the only
+    # difference is the reduction tree (per-workgroup partial slabs summed in a fixed order that depends on the grid)
+    assert worst < 2e-4, (worst, max(g_small, key=lambda k: rel_err(g_big[k], g_small[k])))
+    model2_bytes = torch.cuda.max_memory_allocated() / 2 ** 30
+    assert model2_bytes < 200, model2_bytes               # configs[3]: B = 1 024 activations fit the 288 GB part
+
+
+@pytest.mark.timeout(900)
+def test_infonce_global_batch_8192_one_eighth_of_the_rows():
+    """configs[3]: 8 ranks x local batch 1 024 -> N = 8 192, three modalities, duplicated labels; a rank evaluates the whole
+    N x N loss and keeps dLoss/dz for its own 1 024 rows (row0 = rank * 1024).  Checked against the f32 CPU oracle."""
+    from bioscanclip.hip import ops
+    N, nl = 8192, 1024
+    g = torch.Generator().manual_seed(5)
+    zs = [torch.nn.functional.normalize(torch.randn(N, 768, generator=g) + 0.5 * torch.randn(1, 768, generator=g), dim=-1)
+          for _ in range(3)]
+    label = torch.arange(N) // 3 * 3   # triples share a label: soft targets with three ones per row
+    torch.set_num_threads(16)
+    zc = [z.clone().requires_grad_(True) for z in zs]
+    ref = refcpu.contrastive_loss(zc[0], zc[1], zc[2], label)
+    ref.backward()
+    zd = [z.cuda() for z in zs]
+    loss = torch.zeros(1, device="cuda")
+    ws = torch.empty(ops.infonce_workspace_floats(N, 3), device="cuda")
+    for row0 in (0, 5 * nl):
+        dz = [torch.empty(nl, 768, device="cuda") for _ in range(3)]
+        ops.infonce_fwd_bwd(zd, label.cuda(), 1 / 0.07, loss, dz, row0=row0, n_local=nl, workspace=ws)
+        torch.cuda.synchronize()
+        assert abs(loss.item() - ref.item()) < 2e-5 * abs(ref.item()), (loss.item(), ref.item())
+        for i in range(3):
+            assert rel_err(dz[i], zc[i].grad[row0:row0 + nl]) < 3e-4, (row0, i)
+
+
+class _NS:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+@pytest.mark.parametrize("name", ["one_cycle", "exponential", "step", "cosine"])
+def test_lr_schedulers_drive_fused_adamw(name):
+    """scripts/train_cl.py:160-181 (stepped per iteration, train_epoch.py:41-42): the scheduler objects the reference builds,
+    attached to FusedAdamW, must give the parameter trajectory torch.optim.AdamW gives under the same schedule."""
+    import os
+    import sys
+    scripts = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bioscan-clip_amd", "scripts")
+    sys.path.insert(0, scripts)
+    import train_cl
+    from bioscanclip.hip.optim import FusedAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(768, 4), (4, 768), (768, 768), (768,)]
+    p_hip = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.05).cuda()) for s in shapes]
+    p_ref = [torch.nn.Parameter(p.detach().clone()) for p in p_hip]
+    mc = _NS(lr_scheduler=name, lr_config=_NS(lr=1e-3, max_lr=4e-3, min_lr=1e-6))
+    args = _NS(model_config=mc)
+    steps = 12
+    o_hip, o_ref = FusedAdamW(p_hip, lr=1e-3), torch.optim.AdamW(p_ref, lr=1e-3)
+    s_hip, s_ref = train_cl.build_scheduler(args, o_hip, steps), train_cl.build_scheduler(args, o_ref, steps)
+    assert type(s_hip) is type(s_ref) and s_hip is not None
+    lrs = []
+    for it in range(steps):
+        for a, b in zip(p_hip, p_ref):
+            gr = (torch.randn(a.shape, generator=g) * 0.1).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+        o_hip.step()
+        o_ref.step()
+        s_hip.step()
+        s_ref.step()
+        assert o_hip.param_groups[0]["lr"] == o_ref.param_groups[0]["lr"]
+        lrs.append(o_hip.param_groups[0]["lr"])
+    assert len(set(lrs)) > 1                              # the schedule really moved the learning rate
+    for a, b in zip(p_hip, p_ref):
+        assert rel_err(a, b) < 2e-6

@@ -15,7 +15,7 @@ for name in sys.argv[1:]:
     out = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi == EPI_RESID_F32 else torch.bfloat16)
     kw = {}
     if epi == EPI_RESID_F32: kw["resid"] = torch.randn(M, N, device="cuda")
-    if epi in (EPI_GELU_BF16, EPI_DGELU_BF16): kw["aux"] = torch.randn(M, N, device="cuda").bfloat16()
+    if epi in (EPI_GELU_BF16, EPI_DGELU_BF16): kw["aux"] = torch.randint(0, 256, (M, N), device="cuda", dtype=torch.uint8)
     for _ in range(3):
         ops.gemm(a, w, out, epi, bias=bias, **kw)
     torch.cuda.synchronize()

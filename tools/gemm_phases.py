@@ -17,7 +17,7 @@ for name, N, K, epi in (("qkv", 2304, 832, EPI_BF16), ("dfc1", 768, 3072, EPI_BF
     if epi == EPI_RESID_F32:
         r = torch.randn(M, N, device="cuda"); keep.append(r); args.resid = r.data_ptr(); args.ld_resid = N
     if epi in (EPI_GELU_BF16, EPI_DGELU_BF16):
-        z = torch.randn(M, N, device="cuda").bfloat16(); keep.append(z); args.aux = z.data_ptr(); args.ld_aux = N
+        z = torch.randint(0, 256, (M, N), device="cuda", dtype=torch.uint8); keep.append(z); args.aux = z.data_ptr(); args.ld_aux = N
     grid = (M // 256) * (N // 256)
     diag = torch.zeros(grid * 16, dtype=torch.int64, device="cuda")
     for _ in range(3):
