@@ -389,27 +389,65 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 for (int j = 0; j < 2; ++j) fb[a][k][j] = bf16x8{8, 7, 6, 5, 4, 3, 2, 1};
             }
     }
+    // OP 2 keeps a tile's two 16-byte fragments in ONE 8-register vector (the operand of the block-scaled MFMA), so no
+    // register copies are needed to form it; the peeled bf16 tile takes its halves
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    i32x8 fa8[OP == 2 ? 2 : 1][OP == 2 ? 4 : 1];
+    i32x8 fb8[OP == 2 ? 2 : 1][OP == 2 ? 2 : 1];
     auto readA = [&](const char* base, int mi) {
         if constexpr (ABL & 2) return;
+        if constexpr (OP == 2) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int i = 0; i < 4; ++i) {
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(base + (a_off + (64 * mi + 16 * i) * ROW_BYTES));
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(base + ((a_off ^ 64) + (64 * mi + 16 * i) * ROW_BYTES));
+                fa8[mi][i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                fa[mi][ks][i] = *reinterpret_cast<const bf16x8*>(base + ((a_off ^ (ks << 6)) + (64 * mi + 16 * i) * ROW_BYTES));
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    fa[mi][ks][i] = *reinterpret_cast<const bf16x8*>(base + ((a_off ^ (ks << 6)) + (64 * mi + 16 * i) * ROW_BYTES));
+        }
     };
     auto readB = [&](const char* base, int ni) {
         if constexpr (ABL & 2) return;
+        if constexpr (OP == 2) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int j = 0; j < 2; ++j) {
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(base + (b_off + (32 * ni + 16 * j) * ROW_BYTES));
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(base + ((b_off ^ 64) + (32 * ni + 16 * j) * ROW_BYTES));
+                fb8[ni][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                fb[ni][ks][j] = *reinterpret_cast<const bf16x8*>(base + ((b_off ^ (ks << 6)) + (32 * ni + 16 * j) * ROW_BYTES));
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fb[ni][ks][j] = *reinterpret_cast<const bf16x8*>(base + ((b_off ^ (ks << 6)) + (32 * ni + 16 * j) * ROW_BYTES));
+        }
     };
-    bool bf16_tile = OP == 0;   // fp8 builds: true only while the K-augmentation tile is being multiplied (wave-uniform)
-    auto mma = [&](int mi, int ni) {
+    // BF16TILE (compile-time tag): bf16 MFMAs -- always for OP 0, for the peeled K-augmentation tile of the fp8 builds
+    auto mma = [&](int mi, int ni, auto bf16_tag = std::true_type{}) {
         if constexpr (ABL & 1) return;
+        constexpr bool BF16TILE = OP == 0 || decltype(bf16_tag)::value;
         __builtin_amdgcn_s_setprio(1);
-        if (OP == 0 || bf16_tile) {
+        if constexpr (BF16TILE && OP == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const i32x8 a = fa8[mi][i], b = fb8[ni][j];
+                    acc[mi][ni][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, __builtin_shufflevector(b, b, 0, 1, 2, 3)),
+                        __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, a, 0, 1, 2, 3)), acc[mi][ni][i][j], 0, 0, 0);
+                    acc[mi][ni][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, __builtin_shufflevector(b, b, 4, 5, 6, 7)),
+                        __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, a, 4, 5, 6, 7)), acc[mi][ni][i][j], 0, 0, 0);
+                }
+        } else if constexpr (BF16TILE) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -430,20 +468,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                         acc[mi][ni][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[1], a2[1], acc[mi][ni][i][j], 0, 0, 0);
                     }
         } else if constexpr (OP == 2) {
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            typedef int i32x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const i32x4 a0 = __builtin_bit_cast(i32x4, fa[mi][0][i]), a1 = __builtin_bit_cast(i32x4, fa[mi][1][i]);
-                    const i32x4 b0 = __builtin_bit_cast(i32x4, fb[ni][0][j]), b1 = __builtin_bit_cast(i32x4, fb[ni][1][j]);
-                    const i32x8 a8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                    const i32x8 b8 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                for (int j = 0; j < 2; ++j)
                     // cbsz = blgp = 0: both operands OCP e4m3; block scales 2^(127-127) = 1 for every 32-element block
-                    acc[mi][ni][i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8, a8, acc[mi][ni][i][j], 0, 0, 0,
-                                                                                         0x7f7f7f7f, 0, 0x7f7f7f7f);
-                }
+                    acc[mi][ni][i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[ni][j], fa8[mi][i], acc[mi][ni][i][j], 0, 0,
+                                                                                         0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -632,30 +663,29 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         if (g == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
         stamp(1);
 
-        for (int t = 0; t < nk; ++t) {
+        auto k_tile = [&](int t, auto tag) {
             const int set = t & 1;
             const char* base = smem + set * SET;
             const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
             const int k1 = (t + 1) * 2 * BK, k2 = (t + 2) * 2 * BK;   // byte offsets of K-tiles t+1, t+2
-            if constexpr (OP != 0) bf16_tile = aug && t == nk - 1;
             // ---- phase 0 ----
             if (has1) dmaA(set ^ 1, 1, k1);
             readA(base, 0);
             readB(base, 0);
             PP_BARRIER();
-            mma(0, 0);
+            mma(0, 0, tag);
             PP_BARRIER();
             // ---- phase 1 ----
             if (has1) dmaB(set ^ 1, 0, k1);
             readA(base, 1);
             PP_BARRIER();
-            mma(1, 0);
+            mma(1, 0, tag);
             PP_BARRIER();
             // ---- phase 2 ----
             if (has1) dmaB(set ^ 1, 1, k1);
             readB(base, 1);
             PP_BARRIER();
-            mma(1, 1);
+            mma(1, 1, tag);
             PP_BARRIER();
             // ---- phase 3 ----
             if (has2) {
@@ -665,8 +695,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             PP_BARRIER();
-            mma(0, 1);
+            mma(0, 1, tag);
             PP_BARRIER();
+        };
+        if constexpr (OP == 0) {
+            for (int t = 0; t < nk; ++t) k_tile(t, std::true_type{});
+        } else {  // fp8 tiles, then the peeled bf16 K-augmentation tile (same schedule, bf16 MFMAs)
+            for (int t = 0; t < nk_main; ++t) k_tile(t, std::false_type{});
+            if (aug) k_tile(nk_main, std::true_type{});
         }
     }
     if constexpr (SCHED != 2) {

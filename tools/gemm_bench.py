@@ -31,7 +31,7 @@ def run(M, N, K, epi, iters):
         kw["aux"] = torch.randint(0, 256, (M, N), device="cuda", dtype=torch.uint8)
     res = {}
     for rnd in range(3):
-        for tile in (1, 2, 3, 4, 6, 7):
+        for tile in (1, 2, 3, 4):
             ops.set_gemm_tile(tile)
             ops.gemm(a, w, out, epi, bias=bias, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -59,14 +59,14 @@ def run(M, N, K, epi, iters):
     return {t: min(v) for t, v in res.items()}
 
 
-tot = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0, 6: 0.0, 7: 0.0, "best": 0.0, "lib": 0.0}
+tot = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0, "best": 0.0, "lib": 0.0}
 for name, M, N, K, epi in SHAPES:
     r = run(M, N, K, epi, 10)
     fl = 2.0 * M * N * K
     best = min((t for t in r if t != 'lib'), key=r.get)
     print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}  " + "  ".join(
-        f"t{t}: {r[t]*1e3:7.1f}us {fl/r[t]/1e9:7.1f}TF" for t in (1, 2, 3, 4, 6, 7, "lib")) + f"   best=t{best}", flush=True)
-    for t in (1, 2, 3, 4, 6, 7, 'lib'):
+        f"t{t}: {r[t]*1e3:7.1f}us {fl/r[t]/1e9:7.1f}TF" for t in (1, 2, 3, 4, "lib")) + f"   best=t{best}", flush=True)
+    for t in (1, 2, 3, 4, "lib"):
         tot[t] += r[t]
     tot["best"] += r[best]
 print("sum per layer (ms):", {k: round(v, 3) for k, v in tot.items()})
