@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="local (per-GPU) batch")
     ap.add_argument("--text", action="store_true", help="add the BERT-small text tower (BASELINE configs[2])")
+    ap.add_argument("--fp8", action="store_true", help="fp8 e4m3 frozen-trunk GEMMs for ViT + BarcodeBERT (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -237,6 +238,9 @@ def main():
     from bioscanclip.model.loss_func import ContrastiveLoss, GlobalBatchContrastiveLoss
 
     model = build_model(a.text, device)
+    if a.fp8:
+        from bioscanclip.hip.engine import set_precision
+        set_precision(model, "fp8")
     model.train()
     nodrop = os.environ.get("BSCLIP_BENCH_NODROP", "0") == "1"  # diagnostic: what the dropout masks cost (not a valid bench line)
     if nodrop:
@@ -301,10 +305,12 @@ def main():
             "metric": "paired samples/sec/node (I+D%s, global batch)" % ("+T" if a.text else ""),
             "value": round(N / (ms * 1e-3), 1), "unit": "paired samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": "configs[%d]: Image+DNA%s (LoRA ViT-B/16 + LoRA BarcodeBERT%s), local batch %d, "
                                    "224x224 images + 133-token barcodes, %s InfoNCE, fused AdamW"
-                                   % (2 if a.text else 1, "+Text" if a.text else "", " + BERT-small" if a.text else "", B,
+                                   % (4 if a.fp8 else 2 if a.text else 1, "+Text" if a.text else "",
+                                      (" + BERT-small" if a.text else "") + (", fp8 e4m3 QKV/fc1/fc2 forward GEMMs with bf16 LoRA, "
+                                                                             "attention, backward and loss" if a.fp8 else ""), B,
                                       "RCCL all-gather global-batch" if world > 1 else "local-batch"),
                        "local_batch": B, "global_batch": N, "parallelism": f"dp{world}",
                        "dropout": ("DISABLED (diagnostic run, not the benchmark configuration)" if nodrop else

@@ -2,7 +2,7 @@
 (language_encoder.py:87-89)."""
 import torch
 
-from .engine import BertEngine, run_encoder
+from .engine import BertEngine, run_encoder, wants_fp8
 
 
 def _need_gpu(t, who):
@@ -14,7 +14,7 @@ def barcode_bert_forward(module, ids):
     _need_gpu(ids, "LoRA_barcode_bert.forward")
     m = module.lora_barcode_bert
     build = lambda: BertEngine(m.bert, "mlm_softmax_mean", (m.cls.predictions.transform, m.cls.predictions.decoder),
-                               ids.device)
+                               ids.device, fp8=wants_fp8(module))
     # the reference passes input_ids only: token_type 0, no attention mask
     return run_encoder(module, build, (ids.to(torch.int64), None, None))
 

@@ -14,7 +14,7 @@ Reference call shapes: SURVEY.md 2.3 (K1-K15), 3.2; semantics App. A.1-A.3.
 import torch
 
 from . import ops
-from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_PATCH_F32, EPI_RESID_F32, KPAD)
+from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_GELU_FP8, EPI_PATCH_F32, EPI_RESID_F32, KPAD)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -136,14 +136,29 @@ class EncoderEngineBase:
             b = self.lora_b(l)
             if b is not None:
                 ops.waug_set_lora(lay.waug, self.H, b[0], b[1])
+                if self.fp8:  # LoRA-B columns of the bf16 K-augmentation tile, in the fp8 accumulator's units
+                    ops.lora_baug_set(lay.baug, self.H, b[0], b[1], lay.s_qkv)
+
+    fp8 = False
+
+    def _pack_fp8(self, lay, w_qkv, w_fc1, w_fc2, dev):
+        """BASELINE configs[4]: the frozen QKV / fc1 / fc2 weights as OCP fp8 e4m3 with one scale per output row (row amax
+        -> 448); activations are quantised with scale 1 by their producers (LayerNorm, GELU epilogue), so a GEMM's
+        dequantisation vector alpha is the weight-row scale itself.  LoRA, attention, out-projection, heads, loss and the
+        whole backward stay in bf16 / f32."""
+        lay.w_qkv8, lay.s_qkv = ops.quantize_rows_fp8(_f32(w_qkv, dev))
+        lay.w_fc1_8, lay.s_fc1 = ops.quantize_rows_fp8(_f32(w_fc1, dev))
+        lay.w_fc2_8, lay.s_fc2 = ops.quantize_rows_fp8(_f32(w_fc2, dev))
+        lay.baug = torch.zeros(3 * self.H, KPAD, dtype=BF16, device=dev)
 
 
 # ======================================================================================================== ViT
 class ViTEngine(EncoderEngineBase):
     """LoRA ViT-B/16 forward/backward (reference image_encoder.py:15-109 over timm vit_base_patch16_224)."""
 
-    def __init__(self, module, device):
+    def __init__(self, module, device, fp8=False):
         vit = module.lora_vit
+        self.fp8 = bool(fp8)
         self.device = dev = device
         self.H = H = vit.blocks[0].norm1.weight.numel()
         self.heads = vit.blocks[0].attn.num_heads
@@ -170,6 +185,8 @@ class ViTEngine(EncoderEngineBase):
             lay.w_proj, lay.w_proj_t, lay.b_proj = _pack_linear(blk.attn.proj, dev)
             lay.w_fc1, lay.w_fc1_t, lay.b_fc1 = _pack_linear(blk.mlp.fc1, dev)
             lay.w_fc2, lay.w_fc2_t, lay.b_fc2 = _pack_linear(blk.mlp.fc2, dev)
+            if self.fp8:
+                self._pack_fp8(lay, base.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight, dev)
             self.layers.append(lay)
         self.ln_f = (_f32(vit.norm.weight, dev), _f32(vit.norm.bias, dev))
         self.FF = self.layers[0].w_fc1.shape[0]
@@ -199,6 +216,10 @@ class ViTEngine(EncoderEngineBase):
         ws["z"] = [z(M, FF, dt=torch.uint8) for _ in range(L)]        # gelu'(fc1 pre-activation), 8-bit codes
         ws["h2"] = z(M, H)
         ws["act"] = z(M, FF)
+        if self.fp8:  # fp8 GEMM operands: LN1 output per block (lora_grad reads it again) + its bf16 t block, LN2 / GELU shared
+            ws["h1_8"] = [z(M, H, dt=ops.FP8) for _ in range(L)]
+            ws["t"] = [z(M, KPAD) for _ in range(L)]
+            ws["h2_8"], ws["act8"] = z(M, H, dt=ops.FP8), z(M, FF, dt=ops.FP8)
         ws["clsn"] = z(B, H)
         ws["st_f"] = z(B, 2, dt=F32)
         # backward temporaries
@@ -233,9 +254,15 @@ class ViTEngine(EncoderEngineBase):
         ops.vit_cls_rows(x[0], self.cls, self.pos, B, S, H)
         L = len(self.layers)
         for l, lay in enumerate(self.layers):
-            ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_bf16=ws["h1"][l], lora_a=self.lora_a(l),
-                              stats=ws["st1"][l])
-            ops.gemm(ws["h1"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
+            if self.fp8:
+                ops.layernorm_fwd_fp8(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, ws["h1_8"][l], t_aug=ws["t"][l],
+                                      lora_a=self.lora_a(l), stats=ws["st1"][l])
+                ops.gemm_fp8(ws["h1_8"][l], lay.w_qkv8, ws["qkv"][l], lay.s_qkv, lay.b_qkv, EPI_BF16, a_aug=ws["t"][l],
+                             b_aug=lay.baug)
+            else:
+                ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_bf16=ws["h1"][l], lora_a=self.lora_a(l),
+                                  stats=ws["st1"][l])
+                ops.gemm(ws["h1"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
             if l == L - 1:
                 # The head reads token 0 of the last block only (timm global_pool='token'), and within a block a token's
                 # output depends on the other tokens through K and V alone: attention for query 0, then proj / LN2 / MLP on
@@ -252,6 +279,11 @@ class ViTEngine(EncoderEngineBase):
                 continue
             ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l])
             ops.gemm(ws["ctx"][l], lay.w_proj, x[2 * l + 1], EPI_RESID_F32, bias=lay.b_proj, resid=x[2 * l])
+            if self.fp8:
+                ops.layernorm_fwd_fp8(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, ws["h2_8"], stats=ws["st2"][l])
+                ops.gemm_fp8(ws["h2_8"], lay.w_fc1_8, ws["act8"], lay.s_fc1, lay.b_fc1, EPI_GELU_FP8, aux=ws["z"][l])
+                ops.gemm_fp8(ws["act8"], lay.w_fc2_8, x[2 * l + 2], lay.s_fc2, lay.b_fc2, EPI_RESID_F32, resid=x[2 * l + 1])
+                continue
             ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2"], stats=ws["st2"][l])
             ops.gemm(ws["h2"], lay.w_fc1, ws["act"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
             ops.gemm(ws["act"], lay.w_fc2, x[2 * l + 2], EPI_RESID_F32, bias=lay.b_fc2, resid=x[2 * l + 1])
@@ -310,7 +342,11 @@ class ViTEngine(EncoderEngineBase):
             lb = self.lora_b(l)
             if lb is not None:
                 gb = self.lora_b(l, grad=True)
-                ops.lora_grad(ws["dqkv"], ws["h1"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gb[0], gb[1])
+                if self.fp8:
+                    ops.lora_grad_fp8(ws["dqkv"], ws["h1_8"][l], ws["t"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True),
+                                      gb[0], gb[1])
+                else:
+                    ops.lora_grad(ws["dqkv"], ws["h1"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gb[0], gb[1])
             if l > 0:  # nothing trainable sits below block 0 (patch-embed, cls, pos are frozen)
                 ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
                 ops.layernorm_bwd(x[2 * l], ws["st1"][l], lay.ln1[0], 0, g_resid=dx, g_gemm=ws["dh"],
@@ -327,7 +363,8 @@ class BertEngine(EncoderEngineBase):
       'mean_proj'        : mean over tokens -> proj Linear (text)
     """
 
-    def __init__(self, bert, head, head_modules, device):
+    def __init__(self, bert, head, head_modules, device, fp8=False):
+        self.fp8 = bool(fp8)
         self.device = dev = device
         cfg = getattr(bert, "config", None)
         emb = bert.embeddings
@@ -362,6 +399,8 @@ class BertEngine(EncoderEngineBase):
             lay.w_fc1, lay.w_fc1_t, lay.b_fc1 = _pack_linear(layer.intermediate.dense, dev)
             lay.w_fc2, lay.w_fc2_t, lay.b_fc2 = _pack_linear(layer.output.dense, dev)
             lay.ln_b = (_f32(layer.output.LayerNorm.weight, dev), _f32(layer.output.LayerNorm.bias, dev))
+            if self.fp8:
+                self._pack_fp8(lay, w, layer.intermediate.dense.weight, layer.output.dense.weight, dev)
             self.layers.append(lay)
         self.FF = self.layers[0].w_fc1.shape[0]
         self.head = head
@@ -404,6 +443,10 @@ class BertEngine(EncoderEngineBase):
         ws["stb"] = [z(M, 2, dt=F32) for _ in range(L)]
         ws["z"] = [z(M, FF, dt=torch.uint8) for _ in range(L)]       # gelu'(intermediate pre-activation), 8-bit codes
         ws["act"] = z(M, FF)
+        if self.fp8:  # fp8 GEMM operands (the last LN output stays bf16: it feeds the head)
+            ws["yb8"] = [z(M, H, dt=ops.FP8) for _ in range(L)]
+            ws["t"] = [z(M, KPAD) for _ in range(L)]
+            ws["ymb8"], ws["act8"] = z(M, H, dt=ops.FP8), z(M, FF, dt=ops.FP8)
         ws["key_bias"] = None
         ws["kb_buf"] = z(B, S, dt=F32)
         # backward temporaries
@@ -467,22 +510,42 @@ class BertEngine(EncoderEngineBase):
         ws["key_bias"] = key_bias
         ops.bert_embed(input_ids.contiguous(), None if token_type_ids is None else token_type_ids.contiguous(),
                        self.word, self.posw, self.typew, ws["emb"])
-        ops.layernorm_fwd(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, y_bf16=ws["yb"][0], y_f32=ws["y"],
-                          lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0))
+        f8 = self.fp8
+        if f8:
+            ops.layernorm_fwd_fp8(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, ws["yb8"][0], t_aug=ws["t"][0], y_f32=ws["y"],
+                                  lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0))
+        else:
+            ops.layernorm_fwd(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, y_bf16=ws["yb"][0], y_f32=ws["y"],
+                              lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0))
         for l, lay in enumerate(self.layers):
-            ops.gemm(ws["yb"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
+            if f8:
+                ops.gemm_fp8(ws["yb8"][l], lay.w_qkv8, ws["qkv"][l], lay.s_qkv, lay.b_qkv, EPI_BF16, a_aug=ws["t"][l],
+                             b_aug=lay.baug)
+            else:
+                ops.gemm(ws["yb"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
             ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], key_bias=key_bias,
                          dropout=self._drop(ws, self.p_attn, l, 1))
             ops.gemm(ws["ctx"][l], lay.w_o, ws["s1"][l], EPI_RESID_F32, bias=lay.b_o, resid=ws["y"],
                      dropout=self._drop(ws, self.p_hidden, l, 2))
-            ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ws["ymb"], y_f32=ws["ym"],
-                              stats=ws["sta"][l])
-            ops.gemm(ws["ymb"], lay.w_fc1, ws["act"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
-            ops.gemm(ws["act"], lay.w_fc2, ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"],
-                     dropout=self._drop(ws, self.p_hidden, l, 3))
+            if f8:
+                ops.layernorm_fwd_fp8(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, ws["ymb8"], y_f32=ws["ym"],
+                                      stats=ws["sta"][l])
+                ops.gemm_fp8(ws["ymb8"], lay.w_fc1_8, ws["act8"], lay.s_fc1, lay.b_fc1, EPI_GELU_FP8, aux=ws["z"][l])
+                ops.gemm_fp8(ws["act8"], lay.w_fc2_8, ws["s2"][l], lay.s_fc2, lay.b_fc2, EPI_RESID_F32, resid=ws["ym"],
+                             dropout=self._drop(ws, self.p_hidden, l, 3))
+            else:
+                ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ws["ymb"], y_f32=ws["ym"],
+                                  stats=ws["sta"][l])
+                ops.gemm(ws["ymb"], lay.w_fc1, ws["act"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
+                ops.gemm(ws["act"], lay.w_fc2, ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"],
+                         dropout=self._drop(ws, self.p_hidden, l, 3))
             nxt = self.lora_a(l + 1) if l + 1 < L else self._zero_a
-            ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1], y_f32=ws["y"],
-                              lora_a=nxt, stats=ws["stb"][l])
+            if f8 and l + 1 < L:
+                ops.layernorm_fwd_fp8(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, ws["yb8"][l + 1], t_aug=ws["t"][l + 1],
+                                      y_f32=ws["y"], lora_a=nxt, stats=ws["stb"][l])
+            else:
+                ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1], y_f32=ws["y"],
+                                  lora_a=nxt, stats=ws["stb"][l])
         out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
         if self.head == "mlm_softmax_mean":
             ops.gemm(ws["yb"][L], self.w_tr, ws["tg"], EPI_GELU_BF16, bias=self.b_tr, aux=ws["tz"], K=H)
@@ -538,7 +601,11 @@ class BertEngine(EncoderEngineBase):
             lb = self.lora_b(l)
             if lb is not None:
                 gbb = self.lora_b(l, grad=True)
-                ops.lora_grad(ws["dqkv"], ws["yb"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gbb[0], gbb[1])
+                if self.fp8:
+                    ops.lora_grad_fp8(ws["dqkv"], ws["yb8"][l], ws["t"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True),
+                                      gbb[0], gbb[1])
+                else:
+                    ops.lora_grad(ws["dqkv"], ws["yb"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gbb[0], gbb[1])
             if l > 0:  # embeddings are frozen: nothing to do below layer 0
                 ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
                 g_resid, g_gemm = ws["ds1"], ws["dh"]
@@ -598,8 +665,26 @@ def _frozen_signature(module, eng):
                  if id(t) not in mine)
 
 
+def wants_fp8(module):
+    """``module.hip_precision = "fp8"`` (set_precision) selects the fp8 frozen-trunk GEMMs (BASELINE configs[4])."""
+    return getattr(module, "hip_precision", "bf16") == "fp8"
+
+
+def set_precision(model, precision):
+    """Select "bf16" (default) or "fp8" frozen-trunk GEMMs for the ViT and BarcodeBERT encoders under ``model``; engines
+    are rebuilt on the next forward (the text tower stays bf16: its GEMMs are latency-sized)."""
+    if precision not in ("bf16", "fp8"):
+        raise ValueError(f"precision must be 'bf16' or 'fp8', not {precision!r}")
+    for m in model.modules():
+        if hasattr(m, "lora_vit") or hasattr(m, "lora_barcode_bert"):
+            m.hip_precision = precision
+            m._engine = None
+
+
 def _engine_for(module, build):
     eng = getattr(module, "_engine", None)
+    if eng is not None and eng.fp8 != wants_fp8(module):
+        eng = None
     if eng is not None and eng.flat.valid() and _frozen_signature(module, eng) != eng._frozen_sig:
         eng = None  # frozen weights were overwritten (checkpoint loaded after the first forward): repack
     if eng is None or not eng.flat.valid():

@@ -49,6 +49,7 @@ SIGNATURES = {
     "bsclip_quantize_rows_fp8": (I, [P, I, I, P, I, P, P]),
     "bsclip_lora_baug_set": (I, [P, I, I, P, P, P, P]),
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
+    "bsclip_layernorm_fwd_fp8": (I, [P, I, I, I, I, P, P, F, P, I, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "bsclip_topk_ip": (I, [P, I, P, I, I, I, P, P, P, P]),
     "bsclip_lora_grad_workspace_floats": (L, [I]),
     "bsclip_lora_grad": (I, [P, I, P, I, I, I, P, P, P, P, P, P, P]),
+    "bsclip_lora_grad_fp8": (I, [P, I, P, I, P, I, I, I, P, P, P, P, P, P, P]),
     "bsclip_colsum": (I, [P, I, I, I, I, P, P]),
     "bsclip_transpose_bf16": (I, [P, I, I, I, P, I, P]),
     "bsclip_cast_f32_bf16": (I, [P, L, P, P]),

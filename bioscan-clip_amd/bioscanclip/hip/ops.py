@@ -76,7 +76,7 @@ def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, 
 
 
 FP8 = torch.float8_e4m3fn   # OCP e4m3 (gfx950); one byte per element
-FP8_FORM = int(__import__("os").environ.get("BSCLIP_FP8_FORM", "2"))   # 1: 16x16x32 fp8 MFMA, 2: block-scaled 16x16x128 (2x rate)
+FP8_FORM = int(__import__("os").environ.get("BSCLIP_FP8_FORM", "1"))   # 1: 16x16x32 fp8 MFMA (faster here), 2: block-scaled 16x16x128
 
 
 def gemm_fp8(a8, b8, out, alpha, bias, epilogue=EPI_BF16, resid=None, aux=None, a_aug=None, b_aug=None, M=None, K=None,
@@ -172,6 +172,30 @@ def layernorm_fwd(x, gamma, beta, eps, y_bf16=None, y_f32=None, lora_a=None, sta
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_layernorm_fwd(_p(x), ld_x, int(x.dtype == BF16), M, H, _p(gamma), _p(beta), float(eps),
                                          _p(y_bf16), ld_y, _p(y_f32), _p(lora_a), _p(stats), dp, ds, _stream()))
+
+
+def layernorm_fwd_fp8(x, gamma, beta, eps, y_fp8, t_aug=None, y_f32=None, lora_a=None, stats=None, M=None, dropout=None):
+    """LayerNorm whose GEMM operand comes out as fp8 e4m3 (y_fp8 [M, >=H]) with the LoRA t block in its own bf16 buffer."""
+    ld_x = _rowmajor(x, "x")
+    H = gamma.numel()
+    M = x.shape[0] if M is None else M
+    _req(x.dtype in (F32, BF16) and x.shape[1] >= H and M <= x.shape[0], "layernorm_fwd_fp8: bad x")
+    _req(gamma.dtype == F32 and beta.dtype == F32 and beta.numel() == H, "layernorm_fwd_fp8: gamma/beta f32 [H]")
+    _req(y_fp8.dtype == FP8 and y_fp8.shape[0] >= M and y_fp8.shape[1] >= H, "layernorm_fwd_fp8: y_fp8 [M, >=H]")
+    _req((lora_a is None) == (t_aug is None), "layernorm_fwd_fp8: lora_a and t_aug go together")
+    ld_t = 0
+    if t_aug is not None:
+        ld_t = _rowmajor(t_aug, "t_aug")
+        _req(t_aug.dtype == BF16 and t_aug.shape[0] >= M and t_aug.shape[1] >= KPAD, "t_aug bf16 [M, >=64]")
+        _req(lora_a.dtype == F32 and lora_a.is_contiguous() and tuple(lora_a.shape) == (8, H), "lora_a must be f32 [8,H]")
+    if y_f32 is not None:
+        _req(y_f32.dtype == F32 and y_f32.is_contiguous() and y_f32.shape[0] >= M and y_f32.shape[1] == H, "y_f32 f32 [M,H]")
+    if stats is not None:
+        _req(stats.dtype == F32 and stats.is_contiguous() and stats.numel() >= 2 * M, "stats must be f32 [M,2]")
+    dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
+    check(_l.load().bsclip_layernorm_fwd_fp8(_p(x), ld_x, int(x.dtype == BF16), M, H, _p(gamma), _p(beta), float(eps),
+                                             _p(y_fp8), _rowmajor(y_fp8, "y_fp8"), _p(t_aug), ld_t, _p(y_f32), _p(lora_a),
+                                             _p(stats), dp, ds, _stream()))
 
 
 def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lora_a=None, dx_f32=None, dx_bf16=None,
@@ -381,6 +405,19 @@ def lora_grad(dqkv, h_aug, M, H, lora_b, dt, dA, dBq, dBv):
     check(_l.load().bsclip_lora_grad(_p(dqkv), _rowmajor(dqkv, "dqkv"), _p(h_aug), _rowmajor(h_aug, "h_aug"), M, H,
                                      _p(lora_b), _p(dt), _p(dA), _p(dBq), _p(dBv),
                                      _p(_lora_grad_workspace(H, dqkv.device)), _stream()))
+
+
+def lora_grad_fp8(dqkv, y_fp8, t_aug, M, H, lora_b, dt, dA, dBq, dBv):
+    _req(dqkv.dtype == BF16 and y_fp8.dtype == FP8 and t_aug.dtype == BF16, "lora_grad_fp8: dtypes")
+    _req(dqkv.shape[0] >= M and dqkv.shape[1] >= 3 * H and y_fp8.shape[0] >= M and y_fp8.shape[1] >= H
+         and t_aug.shape[0] >= M and t_aug.shape[1] >= 8, "lora_grad_fp8 shapes")
+    _req(lora_b.dtype == F32 and lora_b.is_contiguous() and tuple(lora_b.shape) == (2, H, 4), "lora_b f32 [2,H,4]")
+    _req(dt.dtype == F32 and dt.is_contiguous() and dt.numel() >= 8 * M, "dt f32 [M,8]")
+    _req(dA.dtype == F32 and dA.is_contiguous() and tuple(dA.shape) == (8, H), "dA f32 [8,H]")
+    _req(all(t.dtype == F32 and t.is_contiguous() and tuple(t.shape) == (H, 4) for t in (dBq, dBv)), "dB f32 [H,4]")
+    check(_l.load().bsclip_lora_grad_fp8(_p(dqkv), _rowmajor(dqkv, "dqkv"), _p(y_fp8), _rowmajor(y_fp8, "y_fp8"), _p(t_aug),
+                                         _rowmajor(t_aug, "t_aug"), M, H, _p(lora_b), _p(dt), _p(dA), _p(dBq), _p(dBv),
+                                         _p(_lora_grad_workspace(H, dqkv.device)), _stream()))
 
 
 def colsum(g, M, N, out):

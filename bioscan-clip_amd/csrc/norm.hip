@@ -56,14 +56,18 @@ __device__ __forceinline__ void load_row(const void* x, int ld_x, int row, int l
     }
 }
 
-template <int H, bool X_BF16, bool LORA>
+// Y_FP8: the GEMM operand is written as OCP fp8 e4m3 (scale 1: LayerNorm outputs are O(1); saturated at +-448) into y_bf16
+// reinterpreted as bytes (row stride ld_y BYTES), and the LoRA t block as bf16 into its own buffer t_aug (row stride ld_t
+// elements, 64 columns: t in [0,8), zeros after) -- the bf16 K-augmentation tile of bsclip_gemm_fp8 (BASELINE configs[4]).
+template <int H, bool X_BF16, bool LORA, bool Y_FP8 = false>
 __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __restrict__ x, int ld_x, int M,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float eps,
                                                                   bf16_t* __restrict__ y_bf16, int ld_y,
                                                                   float* __restrict__ y_f32,
                                                                   const float* __restrict__ lora_a,
-                                                                  float* __restrict__ stats, DropCfg drop) {
+                                                                  float* __restrict__ stats, DropCfg drop,
+                                                                  bf16_t* __restrict__ t_aug = nullptr, int ld_t = 0) {
     constexpr int NV = H / 256;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;
@@ -122,12 +126,20 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
         }
         if (y_bf16) {
             bf16_t* yr = y_bf16 + (size_t)row * ld_y;
+            if constexpr (Y_FP8) {
+                unsigned char* y8 = reinterpret_cast<unsigned char*>(y_bf16) + (size_t)row * ld_y;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                uint2 o;
-                o.x = pack_bf2(v[j][0], v[j][1]);
-                o.y = pack_bf2(v[j][2], v[j][3]);
-                *reinterpret_cast<uint2*>(yr + j * 256 + lane * 4) = o;
+                for (int j = 0; j < NV; ++j)
+                    *reinterpret_cast<unsigned*>(y8 + j * 256 + lane * 4) = pack_fp8x4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                yr = t_aug + (size_t)row * ld_t - H;   // so that yr[H + lane] below is t_aug[row][lane]
+            } else {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    uint2 o;
+                    o.x = pack_bf2(v[j][0], v[j][1]);
+                    o.y = pack_bf2(v[j][2], v[j][3]);
+                    *reinterpret_cast<uint2*>(yr + j * 256 + lane * 4) = o;
+                }
             }
             if constexpr (LORA) {
                 float p[8];
@@ -317,6 +329,34 @@ extern "C" int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, 
     } else {
         if (x_bf16) { if (lo) LN_FWD_LAUNCH(512, true, true); else LN_FWD_LAUNCH(512, true, false); }
         else        { if (lo) LN_FWD_LAUNCH(512, false, true); else LN_FWD_LAUNCH(512, false, false); }
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+#define LN_FWD8_LAUNCH(HH, XB, LO)                                                                                   \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<HH, XB, LO, true>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, M, gamma, \
+                       beta, eps, static_cast<bf16_t*>(y_fp8), ld_y, y_f32, lora_a, stats, drop, static_cast<bf16_t*>(t_aug), ld_t)
+
+extern "C" int bsclip_layernorm_fwd_fp8(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma,
+                                        const float* beta, float eps, void* y_fp8, int ld_y, void* t_aug, int ld_t,
+                                        float* y_f32, const float* lora_a, float* stats, float dropout_p,
+                                        uint32_t dropout_seed, void* stream) {
+    BSCLIP_REQUIRE(x && gamma && beta && y_fp8 && M > 0, "bsclip_layernorm_fwd_fp8: null/empty input");
+    BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_fwd_fp8: H=%d (supported: 768, 512)", H);
+    BSCLIP_REQUIRE(ld_x >= H && ld_x % 4 == 0 && ld_y >= H && ld_y % 16 == 0, "bsclip_layernorm_fwd_fp8: ld_x=%d ld_y=%d", ld_x, ld_y);
+    BSCLIP_REQUIRE((lora_a == nullptr) == (t_aug == nullptr) && (!t_aug || (ld_t >= BSCLIP_KPAD && ld_t % 8 == 0)),
+                   "bsclip_layernorm_fwd_fp8: lora_a and t_aug go together, ld_t >= %d (ld_t=%d)", BSCLIP_KPAD, ld_t);
+    BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_layernorm_fwd_fp8: dropout_p=%f", dropout_p);
+    const DropCfg drop = make_drop(dropout_p, dropout_seed);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool lo = lora_a != nullptr;
+    if (H == 768) {
+        if (x_bf16) { if (lo) LN_FWD8_LAUNCH(768, true, true); else LN_FWD8_LAUNCH(768, true, false); }
+        else        { if (lo) LN_FWD8_LAUNCH(768, false, true); else LN_FWD8_LAUNCH(768, false, false); }
+    } else {
+        if (x_bf16) { if (lo) LN_FWD8_LAUNCH(512, true, true); else LN_FWD8_LAUNCH(512, true, false); }
+        else        { if (lo) LN_FWD8_LAUNCH(512, false, true); else LN_FWD8_LAUNCH(512, false, false); }
     }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;

@@ -45,6 +45,8 @@ __device__ __forceinline__ float reduce8(float (&p)[8], int lane) {
 constexpr int LG_BLOCK = 256;
 
 // pass 1: dt[M,8] = [dq.B_q | dv.B_v];  dBq[H,4] += dq^T t_q;  dBv[H,4] += dv^T t_v
+// haug / ld_h: the bf16 block holding t -- the LN output row (t at column H, bf16 path) or the separate t_aug buffer
+// (t at column 0, fp8 path; the caller passes haug = t_aug - H)
 template <int H>
 __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t* __restrict__ dqkv, int ld,
                                                                     const bf16_t* __restrict__ haug, int ld_h, int M,
@@ -144,8 +146,8 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t*
         partial[(size_t)blockIdx.x * (2 * NV * 16 * 64) + idx] = red[idx];
 }
 
-// pass 2: dA[8,H] += dt^T y
-template <int H>
+// pass 2: dA[8,H] += dt^T y.  Y_FP8: y is the fp8 e4m3 LN output (row stride ld_h bytes) instead of bf16.
+template <int H, bool Y_FP8 = false>
 __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __restrict__ haug, int ld_h, int M,
                                                                  const float* __restrict__ dt,
                                                                  float* __restrict__ partial) {
@@ -171,16 +173,26 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __
             d0[p] = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8);
             d1[p] = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8 + 4);
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
-                yr[p][j] = *reinterpret_cast<const uint2*>(haug + (size_t)row * ld_h + j * 256 + lane * 4);
+            for (int j = 0; j < NV; ++j) {
+                if constexpr (Y_FP8) {
+                    yr[p][j].x = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(haug) +
+                                                                    (size_t)row * ld_h + j * 256 + lane * 4);
+                    yr[p][j].y = 0;
+                } else {
+                    yr[p][j] = *reinterpret_cast<const uint2*>(haug + (size_t)row * ld_h + j * 256 + lane * 4);
+                }
+            }
         }
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             if (row0 + p * nwaves >= M) break;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const f32x4 y = {bf2f(yr[p][j].x & 0xffff), bf2f(yr[p][j].x >> 16), bf2f(yr[p][j].y & 0xffff),
-                                 bf2f(yr[p][j].y >> 16)};
+                f32x4 y;
+                if constexpr (Y_FP8)
+                    y = f32x4{fp8_to_f32(yr[p][j].x, 0), fp8_to_f32(yr[p][j].x, 1), fp8_to_f32(yr[p][j].x, 2), fp8_to_f32(yr[p][j].x, 3)};
+                else
+                    y = f32x4{bf2f(yr[p][j].x & 0xffff), bf2f(yr[p][j].x >> 16), bf2f(yr[p][j].y & 0xffff), bf2f(yr[p][j].y >> 16)};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc[r][j] += d0[p][r] * y;
@@ -380,6 +392,37 @@ extern "C" int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, in
         hipLaunchKernelGGL((lora_grad_da_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, pb);
         hipLaunchKernelGGL((lora_grad_reduce_kernel<512>), dim3(16 * 512 / 32), dim3(256), 0, s, pa, pb,
                            blocks, dA, dBq, dBv);
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+// fp8 operand path (BASELINE configs[4]): y is the fp8 LN output [M, ld_y bytes], t the separate bf16 block [M, ld_t]
+extern "C" int bsclip_lora_grad_fp8(const void* dqkv, int ld_dqkv, const void* y_fp8, int ld_y, const void* t_aug, int ld_t,
+                                    int M, int H, const float* lora_b, float* dt, float* dA, float* dBq, float* dBv,
+                                    float* workspace, void* stream) {
+    BSCLIP_REQUIRE(dqkv && y_fp8 && t_aug && lora_b && dt && dA && dBq && dBv && workspace && M > 0,
+                   "bsclip_lora_grad_fp8: null/empty input");
+    BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_lora_grad_fp8: H=%d (supported: 768, 512)", H);
+    BSCLIP_REQUIRE(ld_dqkv >= 3 * H && ld_dqkv % 4 == 0 && ld_y >= H && ld_y % 4 == 0 && ld_t >= 8 && ld_t % 8 == 0,
+                   "bsclip_lora_grad_fp8: ld_dqkv=%d ld_y=%d ld_t=%d", ld_dqkv, ld_y, ld_t);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int blocks = ceil_div(M, 4 * 8);
+    if (blocks > LG_MAX_BLOCKS) blocks = LG_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    const bf16_t* g = static_cast<const bf16_t*>(dqkv);
+    const bf16_t* tt = static_cast<const bf16_t*>(t_aug) - H;   // the kernel reads t at column H of its "haug" row
+    const bf16_t* yy = static_cast<const bf16_t*>(y_fp8);
+    float* pa = workspace;
+    float* pb = workspace + (size_t)LG_MAX_BLOCKS * 8 * H;
+    if (H == 768) {
+        hipLaunchKernelGGL((lora_grad_dt_db_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, g, ld_dqkv, tt, ld_t, M, lora_b, dt, pa);
+        hipLaunchKernelGGL((lora_grad_da_kernel<768, true>), dim3(blocks), dim3(LG_BLOCK), 0, s, yy, ld_y, M, dt, pb);
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<768>), dim3(16 * 768 / 32), dim3(256), 0, s, pa, pb, blocks, dA, dBq, dBv);
+    } else {
+        hipLaunchKernelGGL((lora_grad_dt_db_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, g, ld_dqkv, tt, ld_t, M, lora_b, dt, pa);
+        hipLaunchKernelGGL((lora_grad_da_kernel<512, true>), dim3(blocks), dim3(LG_BLOCK), 0, s, yy, ld_y, M, dt, pb);
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<512>), dim3(16 * 512 / 32), dim3(256), 0, s, pa, pb, blocks, dA, dBq, dBv);
     }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;

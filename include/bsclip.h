@@ -132,6 +132,11 @@ int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_c
 int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma, const float* beta,
                          float eps, void* y_bf16, int ld_y, float* y_f32, const float* lora_a, float* stats,
                          float dropout_p, uint32_t dropout_seed, void* stream);
+/* fp8 operand variant (configs[4]): y_fp8 [M, ld_y bytes] = e4m3(LN(x)) (scale 1, saturated), t_aug bf16 [M, ld_t] = the LoRA
+ * block (t in cols [0,8), zeros to col 64) when lora_a != NULL -- the operands of bsclip_gemm_fp8.  Other arguments as above. */
+int bsclip_layernorm_fwd_fp8(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma, const float* beta,
+                             float eps, void* y_fp8, int ld_y, void* t_aug, int ld_t, float* y_f32, const float* lora_a,
+                             float* stats, float dropout_p, uint32_t dropout_seed, void* stream);
 int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M, int H,
                          const float* g_resid, int ld_gr, const void* g_gemm, int ld_g, const float* dt,
                          const float* lora_a, int mode, float* dx_f32, int ld_dx, void* dx_bf16, int ld_dxb,
@@ -216,6 +221,10 @@ int bsclip_topk_ip(const float* queries, int Q, const float* keys, int K, int D,
 int64_t bsclip_lora_grad_workspace_floats(int H);
 int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, int ld_h, int M, int H, const float* lora_b,
                      float* dt, float* dA, float* dBq, float* dBv, float* workspace, void* stream);
+/* lora_grad with the fp8 operand layout: y_fp8 [M, ld_y bytes] (LN output, e4m3) and t_aug bf16 [M, ld_t] (t in cols [0,8)) */
+int bsclip_lora_grad_fp8(const void* dqkv, int ld_dqkv, const void* y_fp8, int ld_y, const void* t_aug, int ld_t, int M,
+                         int H, const float* lora_b, float* dt, float* dA, float* dBq, float* dBv, float* workspace,
+                         void* stream);
 int bsclip_colsum(const void* g, int ld_g, int g_is_bf16, int M, int N, float* out, void* stream);
 int bsclip_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
 int bsclip_cast_f32_bf16(const float* in, int64_t n, void* out, void* stream);
