@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="local (per-GPU) batch")
     ap.add_argument("--text", action="store_true", help="add the BERT-small text tower (BASELINE configs[2])")
     ap.add_argument("--fp8", action="store_true", help="fp8 e4m3 frozen-trunk GEMMs for ViT + BarcodeBERT (BASELINE configs[4])")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -251,7 +252,17 @@ def main():
     crit = (GlobalBatchContrastiveLoss if world > 1 or force_dist else ContrastiveLoss)(torch.nn.CrossEntropyLoss(), 1 / 0.07)
     opt = FusedAdamW(model.parameters(), lr=1e-3)
 
+    # One process, one GPU: the whole step is captured once into a hipGraph and replayed (bioscanclip/hip/graph.py) -- the
+    # host does three calls per step instead of ~1 500.  With a process group the step stays eager: the collectives are issued
+    # from Python (tower-stream all-gathers, per-encoder all-reduces).
+    graphed = None
+    if not (world > 1 or force_dist or a.no_graph):
+        from bioscanclip.hip.graph import GraphedStep
+        graphed = GraphedStep(model, opt, crit, warmup=2)
+
     def step():
+        if graphed is not None:
+            return graphed(image, dna, text, label)
         opt.zero_grad()
         if hasattr(crit, "prefetch_labels"):
             crit.prefetch_labels(label)  # global batch: label all-gather at the top of the step (as train_epoch does)
@@ -259,6 +270,8 @@ def main():
         loss = crit(io, do, to, label)
         loss.backward()
         hdist.allreduce_grads(model)
+        if opt.needs_attach():
+            opt.attach(model)
         opt.step()
         return loss
 
@@ -266,9 +279,8 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] first step done, loss {loss.item():.5f}", file=sys.stderr, flush=True)
-    opt.attach(model)
     hdist.broadcast_trainable(model)
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, 3 if graphed is not None else 0)):   # graph mode: 2 eager steps, then the capture
         loss = step()
 
     def fence():
@@ -315,6 +327,7 @@ def main():
                        "local_batch": B, "global_batch": N, "parallelism": f"dp{world}",
                        "dropout": ("DISABLED (diagnostic run, not the benchmark configuration)" if nodrop else
                                    "HF defaults active (BERT hidden 0.1, attention-probs 0.1; timm ViT drop 0), train mode"),
+                       "launch_path": "hipGraph replay (one captured step)" if graphed is not None else "eager (Python enqueue)",
                        "final_loss": round(final_loss, 6)},
             "step_roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),

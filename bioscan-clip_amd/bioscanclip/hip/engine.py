@@ -483,10 +483,23 @@ class BertEngine(EncoderEngineBase):
         return ws
 
     def _drop(self, ws, p, layer, site):
-        """(p, seed) of one dropout site for the current step, or None when dropout is off (eval mode / p = 0)."""
+        """(p, seed) of one dropout site, or None when dropout is off (eval mode / p = 0).  The seed names the site; what
+        makes the masks differ from step to step is the engine's device step word, mixed in when the kernel runs."""
         if not ws["train"] or p <= 0.0:
             return None
         return (p, (ws["drop_base"] + 0x9E3779B1 * (layer + 2) + 0x85EBCA6B * site) & 0xFFFFFFFF)
+
+    def _begin_dropout(self, ws, advance):
+        """Point this thread's dropout launches at the engine's step word (``bsclip_set_dropout_step``) and, in forward,
+        advance it by one (a captured launch: a replayed hipGraph draws fresh masks, its backward re-reads the same value)."""
+        if not (ws["train"] and (self.p_hidden > 0.0 or self.p_attn > 0.0)):
+            ops.set_dropout_step(None)
+            return
+        if getattr(self, "_step_word", None) is None:
+            self._step_word = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if advance:
+            ops.counter_add(self._step_word, 1)
+        ops.set_dropout_step(self._step_word)
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None):
         B, S = input_ids.shape
@@ -495,11 +508,10 @@ class BertEngine(EncoderEngineBase):
         scale = 0.125
         # HF BERT dropout (hidden 0.1 / attention-probs 0.1) is active in train mode (reference train_epoch.py:20);
         # masks are functions of (seed, element index), regenerated in backward from the seeds kept here
-        self._fwd_calls = getattr(self, "_fwd_calls", 0) + 1
         ws["train"] = bool(getattr(self, "training", False))
         # the rank is mixed in: ranks seeded alike (bench.py, train_cl.py) must not draw the same masks for their shards
-        ws["drop_base"] = (torch.initial_seed() * 0x2545F491 + self._fwd_calls * 0x9E3779B9
-                           + _rank() * 0x632BE5AB) & 0xFFFFFFFF
+        ws["drop_base"] = (torch.initial_seed() * 0x2545F491 + _rank() * 0x632BE5AB) & 0xFFFFFFFF
+        self._begin_dropout(ws, advance=True)
         self.refresh_lora_weights()
         ops.cast_f32_bf16(self.extra(0), self.w_head_bf)
         key_bias = None
@@ -555,6 +567,7 @@ class BertEngine(EncoderEngineBase):
         else:
             ops.meanpool_tokens_fwd(ws["y"], B, S, ws["mp"])
             ops.gemm(ws["mp"], self.w_head_bf, out, EPI_F32, bias=self.extra(1))
+        ops.set_dropout_step(None)   # the pointer is per thread: do not leak it into the caller's own launches
         return out
 
     def backward(self, dout):
@@ -562,6 +575,7 @@ class BertEngine(EncoderEngineBase):
         B, S, M, H, L = ws["B"], ws["S"], ws["M"], self.H, len(self.layers)
         scale = 0.125
         self.flat.bind_grads()
+        self._begin_dropout(ws, advance=False)   # backward runs on autograd's thread: the pointer is per thread
         gw, gb = self.extra(0, grad=True), self.extra(1, grad=True)
         ops.transpose_bf16(self.w_head_bf, self.out_dim, self.head_in, self.w_head_t)
         if self.head == "mlm_softmax_mean":
@@ -610,6 +624,7 @@ class BertEngine(EncoderEngineBase):
                 ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
                 g_resid, g_gemm = ws["ds1"], ws["dh"]
                 dt_in, a_in = (ws["dt"], self.lora_a(l)) if lb is not None else (None, None)
+        ops.set_dropout_step(None)
 
 
 # ====================================================================================== autograd integration
@@ -651,9 +666,13 @@ class _EncoderFn(torch.autograd.Function):
         from .dist import start_allreduce
         start_allreduce(ctx.engine.flat)  # global-batch step: this tower's gradients are complete on this stream
         here = torch.cuda.current_stream()
-        for parent in {ctx.parent, torch.cuda.default_stream(here.device)}:
+        # gradients are complete before anything queued afterwards on the stream the tower was forked from -- and, outside a
+        # stream capture, on the default stream (inside a capture that wait would pull the default stream into the graph and
+        # leave it unjoined)
+        parents = {ctx.parent} if torch.cuda.is_current_stream_capturing() else {ctx.parent, torch.cuda.default_stream(here.device)}
+        for parent in parents:
             if parent is not None and parent != here:
-                parent.wait_stream(here)  # gradients are complete before anything queued on the parent afterwards
+                parent.wait_stream(here)
         return (None, None) + (None,) * len(ctx.engine.flat.params)
 
 

@@ -76,6 +76,9 @@ SIGNATURES = {
     "bsclip_cast_f32_bf16": (I, [P, L, P, P]),
     "bsclip_waug_set_lora": (I, [P, I, I, P, P, P]),
     "bsclip_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, F, P]),
+    "bsclip_adamw_step_dev": (I, [P, P, P, P, L, P, F, F, F, F, F, P]),
+    "bsclip_set_dropout_step": (I, [P]),
+    "bsclip_counter_add": (I, [P, U, P]),
 }
 
 # only in libbsclip_hip_diag.so (`make -C bioscan-clip_amd/csrc diag`, -DBSCLIP_DIAG); used by tools/, never by the product

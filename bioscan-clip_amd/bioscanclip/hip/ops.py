@@ -448,3 +448,24 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
     _req(all(t.dtype == F32 and t.is_contiguous() and t.numel() == p.numel() for t in (p, g, m, v)), "adamw: flat f32 buffers")
     check(_l.load().bsclip_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
                                       float(eps), float(weight_decay), int(step), float(grad_scale), _stream()))
+
+
+def adamw_step_dev(p, g, m, v, hyper, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    """AdamW with (lr, step) read from the device tensor ``hyper`` (f32 [2]) when the kernel runs: graph-capturable."""
+    _req(all(t.dtype == F32 and t.is_contiguous() and t.numel() == p.numel() for t in (p, g, m, v)), "adamw: flat f32 buffers")
+    _req(hyper.dtype == F32 and hyper.is_cuda and hyper.numel() >= 2, "adamw: hyper must be a device f32 [2] = (lr, step)")
+    check(_l.load().bsclip_adamw_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), float(beta1), float(beta2),
+                                          float(eps), float(weight_decay), float(grad_scale), _stream()))
+
+
+def set_dropout_step(counter):
+    """Every dropout-carrying launch this thread makes from now on mixes the device word ``counter`` (uint32/int32 [1]) into
+    its seed at run time (None: seeds are used as passed)."""
+    if counter is not None:
+        _req(counter.is_cuda and counter.numel() >= 1 and counter.element_size() == 4, "dropout step: 4-byte device word")
+    check(_l.load().bsclip_set_dropout_step(_p(counter)))
+
+
+def counter_add(counter, inc=1):
+    _req(counter.is_cuda and counter.numel() >= 1 and counter.element_size() == 4, "counter: 4-byte device word")
+    check(_l.load().bsclip_counter_add(_p(counter), int(inc) & 0xFFFFFFFF, _stream()))

@@ -16,6 +16,23 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._flat_state = {}
         self._flats = []
+        self._dev_hyper = False
+
+    def enable_device_hyper(self, on=True):
+        """Read (lr, step) from device memory inside the kernel (``bsclip_adamw_step_dev``) instead of passing them as launch
+        arguments: required when the step is captured into a hipGraph (arguments freeze at capture).  Each flat buffer gets a
+        pinned host pair and a device pair; ``step()`` refreshes the host pair and enqueues the 8-byte copy (captured as a
+        memcpy node that reads the pinned pair at replay), ``advance_host_state()`` does the host half for a replay."""
+        self._dev_hyper = bool(on)
+
+    def advance_host_state(self):
+        """Host half of one optimizer step, for a graph replay: step counts += 1, pinned (lr, step) pairs refreshed."""
+        for f in self._flats:
+            st = self._flat_state.get(id(f))
+            if st is not None and "hyper_host" in st:
+                st["step"] += 1
+                st["hyper_host"][0] = float(self.param_groups[0]["lr"])
+                st["hyper_host"][1] = float(st["step"])
 
     def attach(self, model):
         """Tell the optimizer which engines' flat buffers exist (called by train_epoch after the first forward)."""
@@ -58,13 +75,24 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._flat_state[id(f)] = st
             f.bind_grads()
             st["step"] += 1
-            ops.adamw_step(f.data, f.grad, st["m"], st["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                           g["weight_decay"], st["step"])
+            if self._dev_hyper:
+                if "hyper" not in st:
+                    st["hyper_host"] = torch.zeros(2, dtype=torch.float32).pin_memory()
+                    st["hyper"] = torch.zeros(2, dtype=torch.float32, device=f.data.device)
+                st["hyper_host"][0], st["hyper_host"][1] = float(g["lr"]), float(st["step"])
+                st["hyper"].copy_(st["hyper_host"], non_blocking=True)
+                ops.adamw_step_dev(f.data, f.grad, st["m"], st["v"], st["hyper"], g["betas"][0], g["betas"][1], g["eps"],
+                                   g["weight_decay"])
+            else:
+                ops.adamw_step(f.data, f.grad, st["m"], st["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                               g["weight_decay"], st["step"])
             handled.update(id(p) for p in f.params)
         for group in self.param_groups:
             for p in group["params"]:
                 if id(p) in handled or p.grad is None:
                     continue
+                if self._dev_hyper:
+                    raise RuntimeError("FusedAdamW: device-side (lr, step) needs every trainable tensor in an engine's flat buffer")
                 if not (p.is_cuda and p.dtype == torch.float32 and p.data.is_contiguous() and p.grad.is_contiguous()):
                     raise RuntimeError("FusedAdamW: parameters must be contiguous f32 GPU tensors (no CPU path)")
                 st = self.state[p]

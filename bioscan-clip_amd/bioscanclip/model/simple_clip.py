@@ -65,7 +65,8 @@ class SimpleCLIP(nn.Module):
                 with torch.cuda.stream(side), forked_from(cur):
                     # global-batch loss: this modality's all-gather starts here, ordered behind this tower's stream only
                     y = start_gather(l2_normalize(enc(x)))
-                y.record_stream(cur)
+                if not torch.cuda.is_current_stream_capturing():   # a capture's private pool owns the tensor's lifetime
+                    y.record_stream(cur)
                 outs[k] = (y, side)
             else:
                 outs[k] = (start_gather(l2_normalize(enc(x))), None)

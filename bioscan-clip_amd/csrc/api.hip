@@ -15,3 +15,23 @@ void bsclip_set_error(const char* fmt, ...) {
 
 extern "C" const char* bsclip_last_error(void) { return g_err; }
 extern "C" int bsclip_abi_version(void) { return 3; }  // 3: bsclip_epi_args.struct_size (leading), bsclip_epi_args_size; diag builds moved out
+
+// ---- dropout step word ------------------------------------------------------------------------------------------
+static thread_local const unsigned* g_drop_step = nullptr;
+const unsigned* bsclip_current_dropout_step() { return g_drop_step; }
+
+extern "C" int bsclip_set_dropout_step(const uint32_t* step_dev) {
+    g_drop_step = step_dev;
+    return BSCLIP_OK;
+}
+
+namespace {
+__global__ void counter_add_kernel(unsigned* p, unsigned inc) { *p += inc; }
+}  // namespace
+
+extern "C" int bsclip_counter_add(uint32_t* counter_dev, uint32_t inc, void* stream) {
+    BSCLIP_REQUIRE(counter_dev, "bsclip_counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), counter_dev, inc);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
                                                                    float scale, bf16_t* __restrict__ ctx, int ld_ctx,
                                                                    float* __restrict__ lse, DropCfg drop, int nqb) {
     constexpr int SP = NB * 32;
+    BSCLIP_DROP_RESOLVE(drop);
     __shared__ __attribute__((aligned(16))) char smem[2 * SP * ROWB + SP * 4];
     char* sK = smem;
     char* sV = smem + SP * ROWB;
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                                                                    int nqb, unsigned long long* diag = nullptr) {
     constexpr int SP = NB * 32;
     constexpr int RM = SP * ROWB;
+    BSCLIP_DROP_RESOLVE(drop);
     auto stamp = [&](int i) {  // diagnostic build: per-wave section times (100 MHz wall clock); tools/attn_phases.py
         if constexpr (DIAG) {
             if ((threadIdx.x & 63) == 0) diag[((size_t)blockIdx.x * ATT_WAVES + (threadIdx.x >> 6)) * 8 + i] = wall_clock64();

@@ -56,7 +56,14 @@ struct DropCfg {
     unsigned thr16;  // 0 = dropout off
     unsigned seed;
     float scale;     // 1 / (1 - p)
+    const unsigned* step;  // device word mixed into the seed when the kernel RUNS (nullable): lets a captured hipGraph draw new
+                           // masks on every replay -- kernel arguments are frozen at capture, device memory is not
 };
+// first statement of every kernel that takes a DropCfg by value
+#define BSCLIP_DROP_RESOLVE(d)                                        \
+    do {                                                              \
+        if ((d).thr16 && (d).step) (d).seed += *(d).step * 0x9E3779B9U; \
+    } while (0)
 __device__ __forceinline__ unsigned hash32(unsigned x) {  // "lowbias32" integer mixer
     x ^= x >> 16;
     x *= 0x7feb352dU;
@@ -81,10 +88,12 @@ __device__ __forceinline__ f32x4 drop4(const DropCfg& d, unsigned idx, f32x4 v) 
     v[3] = (b1 >> 16) >= d.thr16 ? v[3] * d.scale : 0.f;
     return v;
 }
+const unsigned* bsclip_current_dropout_step();  // api.hip: the calling thread's bsclip_set_dropout_step pointer
 static inline DropCfg make_drop(float p, unsigned seed) {
     DropCfg d;
     d.thr16 = p > 0.f ? (unsigned)(p * 65536.0f + 0.5f) : 0u;
     d.seed = seed;
+    d.step = p > 0.f ? bsclip_current_dropout_step() : nullptr;
     d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     return d;
 }

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const bf
                                                                          int K, int tiles_n, EpiArgs e) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // per-wave output tile
+    if constexpr (EPI == BSCLIP_EPI_RESID_F32) BSCLIP_DROP_RESOLVE(e.drop);
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                                                           const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                           int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
     static_assert(OP == 0 || (SCHED == 0 && ABL == 0), "fp8 operands: production schedule only");
+    if constexpr (EPI == BSCLIP_EPI_RESID_F32) BSCLIP_DROP_RESOLVE(e.drop);
     constexpr int ESZ = OP == 0 ? 2 : 1;   // bytes per element of the main operands
     constexpr int SET = 65536, HALF = 16384, B_OFF = 32768;
     // main loop 128 KiB; epilogue slabs 2x64x1040 (f32) or 4x64x528 (bf16 x2) = 132 KiB, + 16 KiB GELU table

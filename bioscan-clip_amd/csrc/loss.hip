@@ -146,12 +146,17 @@ __global__ __launch_bounds__(256) void loss_w_kernel(const float* __restrict__ G
     }
 }
 
-// loss = scale * sum of contrib[0 .. n) -- single workgroup, fixed order (bitwise reproducible)
-__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ contrib, int n, float scale,
+// loss = scale * sum over the directed pairs a != b of contrib[(a*nmod+b)*Np + i], i < N -- single workgroup, fixed order
+// (bitwise reproducible).  Only entries pass 1 wrote are read: the (a,a) slots and the padding rows [N, Np) are skipped, so no
+// hipMemsetAsync is needed (memset nodes inside a captured stream came back mis-ordered on replay: garbage loss, exact gradients)
+__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ contrib, int nmod, int Np, int N, float scale,
                                                           float* __restrict__ loss_out) {
     __shared__ float red[256];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += contrib[i];
+    for (int slot = 0; slot < nmod * nmod; ++slot) {
+        if (slot / nmod == slot % nmod) continue;
+        for (int i = threadIdx.x; i < N; i += 256) s += contrib[(size_t)slot * Np + i];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -252,13 +257,8 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
                                    labels, cnt, lse + (size_t)slot * Np, contrib + (size_t)slot * Np);
             }
         }
-    // contrib slots of (a,a) are unused: zero them so the final sum can run over the whole array
-    for (int a = 0; a < nmod; ++a)
-        (void)hipMemsetAsync(contrib + (size_t)(a * nmod + a) * Np, 0, sizeof(float) * Np, s);
-    if (Np > N)
-        for (int k = 0; k < nmod * nmod; ++k) (void)hipMemsetAsync(contrib + (size_t)k * Np + N, 0, sizeof(float) * (Np - N), s);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, contrib, nmod * nmod * Np,
-                       1.0f / ((float)ndir * (float)N), loss_out);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, contrib, nmod, Np, N, 1.0f / ((float)ndir * (float)N),
+                       loss_out);
     BSCLIP_LAUNCH_CHECK();
     if (!dz || n_local == 0) return BSCLIP_OK;
 

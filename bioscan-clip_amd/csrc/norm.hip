@@ -69,6 +69,7 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
                                                                   float* __restrict__ stats, DropCfg drop,
                                                                   bf16_t* __restrict__ t_aug = nullptr, int ld_t = 0) {
     constexpr int NV = H / 256;
+    BSCLIP_DROP_RESOLVE(drop);
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * LN_BLOCK) >> 6;
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
                                                                   float* __restrict__ dx_f32, int ld_dx,
                                                                   bf16_t* __restrict__ dx_bf16, int ld_dxb,
                                                                   DropCfg drop) {
+    BSCLIP_DROP_RESOLVE(drop);
     constexpr int NV = H / 256;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;

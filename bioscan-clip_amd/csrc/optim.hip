@@ -358,6 +358,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// lr and step come from device memory (hyper[0], hyper[1]); the bias corrections are formed in f64 like the host form does
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, long n,
+                                                         const float* __restrict__ hyper, float beta1, float beta2, float eps,
+                                                         float wd, float grad_scale) {
+    const float lr = hyper[0];
+    const double step = (double)hyper[1];
+    const float inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, step)));
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, step)));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        pi -= (lr * inv_bc1) * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
 }  // namespace
 
 constexpr int LG_MAX_BLOCKS = 512;
@@ -455,6 +477,17 @@ extern "C" int bsclip_adamw_step(float* p, const float* g, float* m, float* v, i
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
                        (long)n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
                        grad_scale);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev,
+                                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    BSCLIP_REQUIRE(p && g && m && v && hyper_dev && n > 0, "bsclip_adamw_step_dev: null/empty input");
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
+                       (long)n, hyper_dev, beta1, beta2, eps, weight_decay, grad_scale);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

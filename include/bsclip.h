@@ -31,6 +31,14 @@ extern "C" {
 const char* bsclip_last_error(void);
 int bsclip_abi_version(void);
 
+/* Dropout step word (hipGraph support).  Kernel arguments are frozen when a launch is captured into a graph, so a seed passed
+ * by value would repeat its mask on every replay.  After bsclip_set_dropout_step(ptr) every dropout-carrying launch made BY
+ * THE CALLING THREAD adds (*ptr * 0x9E3779B9) to its seed when the kernel runs (NULL: seeds are used as passed).  The word
+ * is advanced once per training step with bsclip_counter_add (itself a capturable launch); forward and backward of a step read
+ * the same value, so regenerated masks match. */
+int bsclip_set_dropout_step(const uint32_t* step_dev);
+int bsclip_counter_add(uint32_t* counter_dev, uint32_t inc, void* stream);
+
 /* ---- GEMM family: C = epilogue(A[M,K] * B[N,K]^T), bf16 operands, f32 accumulate (MFMA 16x16x32) -------------
  * Replaces every torch.nn.Linear on the path: timm Attention.qkv/proj, Mlp.fc1/fc2 (via
  * bioscanclip/model/image_encoder.py:108-109), HF BertSelfAttention q/k/v, BertSelfOutput.dense,
@@ -235,6 +243,10 @@ int bsclip_waug_set_lora(void* w_aug, int ld_w, int H, const float* lora_bq, con
 /* ---- optimiser: torch.optim.AdamW defaults (scripts/train_cl.py:158), one launch over a flat f32 buffer ---------- */
 int bsclip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* the same update with the two per-step quantities read from device memory when the kernel runs: hyper_dev[0] = lr,
+ * hyper_dev[1] = step (as a float, exact below 2^24) -- the form a captured hipGraph replays with a moving LR schedule */
+int bsclip_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, float beta1,
+                          float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }
