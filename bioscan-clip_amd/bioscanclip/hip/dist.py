@@ -211,3 +211,77 @@ def broadcast_trainable(model_or_buffers, src=0, group=None):
                                           if p.requires_grad and id(p) not in covered]
     for b in bufs:
         dist.broadcast(b, src=src, group=group)
+
+
+class NativeComm:
+    """The C-ABI collectives (``bsclip_comm_*`` / ``bsclip_allgather_*`` / ``bsclip_allreduce_grads``, include/bsclip.h) with
+    their own RCCL communicator and communication stream -- what a caller without ``torch.distributed`` binds.  The 128-byte
+    unique id travels from rank 0 through whatever channel the caller has (here: an existing ``torch.distributed`` group of any
+    backend, or nothing at world_size 1).  The product path keeps ``torch.distributed`` (identical collectives, same RCCL
+    underneath); this class is the drop-in for it and is exercised at world_size 1 on the one-GPU test box
+    (tests/test_dist_gpu.py)."""
+
+    def __init__(self, rank=0, world=1, group=None, device=None):
+        import ctypes
+        from . import lib as _l
+        self._l, self._ct = _l, ctypes
+        self.rank, self.world = int(rank), int(world)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        h = _l.load()
+        n = h.bsclip_comm_unique_id_bytes()
+        buf = ctypes.create_string_buffer(n)
+        if self.rank == 0:
+            _l.check(h.bsclip_comm_unique_id(buf))
+        if self.world > 1:
+            t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            if dist.get_backend(group) == "nccl":
+                t = t.to(self.device)
+            dist.broadcast(t, src=0, group=group)
+            buf = ctypes.create_string_buffer(bytes(t.cpu().tolist()), n)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _l.check(h.bsclip_comm_init(ctypes.byref(comm), buf, self.rank, self.world))
+        self.comm = comm
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def _events(self):
+        """(event recorded now on the current stream = the payload's producer, event the collective records when done)."""
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        return ready, done
+
+    def _ev(self, e):
+        return self._ct.c_void_p(e.cuda_event)
+
+    def all_gather(self, local):
+        """local: contiguous f32 [B, D] or int64 [B] on this device.  Returns (gathered, done_event); the collective is
+        ordered behind the CURRENT stream's work and runs on the communicator's stream."""
+        h = self._l.load()
+        local = local.contiguous()
+        out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        ready, done = self._events()
+        fn = h.bsclip_allgather_embeddings if local.dtype == torch.float32 else h.bsclip_allgather_labels
+        if local.dtype not in (torch.float32, torch.int64):
+            raise TypeError("NativeComm.all_gather: f32 embeddings or int64 labels")
+        self._l.check(fn(self.comm, self._ct.c_void_p(local.data_ptr()), self._ct.c_void_p(out.data_ptr()), local.numel(),
+                         self._ct.c_void_p(self.stream.cuda_stream), self._ev(ready), self._ev(done)))
+        local.record_stream(self.stream)
+        out.record_stream(self.stream)
+        return out, done
+
+    def all_reduce_sum_(self, flat):
+        """In-place SUM over ranks of a flat f32 buffer; returns the done event."""
+        if flat.dtype != torch.float32 or not flat.is_contiguous():
+            raise TypeError("NativeComm.all_reduce_sum_: contiguous f32 buffer")
+        ready, done = self._events()
+        self._l.check(self._l.load().bsclip_allreduce_grads(self.comm, self._ct.c_void_p(flat.data_ptr()), flat.numel(),
+                                                            self._ct.c_void_p(self.stream.cuda_stream), self._ev(ready),
+                                                            self._ev(done)))
+        flat.record_stream(self.stream)
+        return done
+
+    def close(self):
+        if self.comm is not None:
+            self.stream.synchronize()
+            self._l.check(self._l.load().bsclip_comm_destroy(self.comm))
+            self.comm = None

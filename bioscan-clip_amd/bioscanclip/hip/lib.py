@@ -68,6 +68,15 @@ SIGNATURES = {
     "bsclip_infonce_fwd_bwd": (I, [POINTER(c_void_p), I, P, I, I, F, I, I, P, POINTER(c_void_p), P, P]),
     "bsclip_topk_ip_workspace_floats": (L, [I, I, I]),
     "bsclip_topk_ip": (I, [P, I, P, I, I, I, P, P, P, P]),
+    "bsclip_comm_unique_id_bytes": (I, []),
+    "bsclip_comm_unique_id": (I, [P]),
+    "bsclip_comm_init": (I, [POINTER(c_void_p), P, I, I]),
+    "bsclip_comm_destroy": (I, [P]),
+    "bsclip_allgather_embeddings": (I, [P, P, P, L, P, P, P]),
+    "bsclip_allgather_labels": (I, [P, P, P, L, P, P, P]),
+    "bsclip_allreduce_grads": (I, [P, P, L, P, P, P]),
+    "bsclip_kmer_tokenize": (I, [P, P, I, I, I, P, P]),
+    "bsclip_augment_images": (I, [P, P, I, L, P, I, P, P]),
     "bsclip_lora_grad_workspace_floats": (L, [I]),
     "bsclip_lora_grad": (I, [P, I, P, I, I, I, P, P, P, P, P, P, P]),
     "bsclip_lora_grad_fp8": (I, [P, I, P, I, P, I, I, I, P, P, P, P, P, P, P]),

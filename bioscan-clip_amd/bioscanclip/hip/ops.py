@@ -469,3 +469,19 @@ def set_dropout_step(counter):
 def counter_add(counter, inc=1):
     _req(counter.is_cuda and counter.numel() >= 1 and counter.element_size() == 4, "counter: 4-byte device word")
     check(_l.load().bsclip_counter_add(_p(counter), int(inc) & 0xFFFFFFFF, _stream()))
+
+
+def kmer_tokenize(blob, offsets, B, max_len, k, ids):
+    _req(blob.dtype == torch.uint8 and blob.is_cuda and blob.is_contiguous(), "kmer_tokenize: uint8 GPU byte buffer")
+    _req(offsets.dtype == torch.int64 and offsets.is_cuda and offsets.numel() == B + 1, "kmer_tokenize: offsets int64 [B+1]")
+    _req(ids.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous() and tuple(ids.shape) == (B, max_len // k + 1),
+         "kmer_tokenize: ids int64 [B, max_len/k + 1]")
+    check(_l.load().bsclip_kmer_tokenize(_p(blob), _p(offsets), B, max_len, k, _p(ids), _stream()))
+
+
+def augment_images(src, records, B, mid_capacity, mid, out_size, out):
+    _req(src.dtype == torch.uint8 and src.is_cuda and src.is_contiguous(), "augment_images: uint8 GPU source buffer")
+    _req(records.dtype == torch.int32 and records.is_cuda and records.numel() == 16 * B, "augment_images: records int32 [B,16]")
+    _req(mid.dtype == F32 and mid.is_cuda and mid.numel() >= 3 * B * mid_capacity, "augment_images: mid f32 [B,3,cap]")
+    _req(out.dtype == F32 and out.is_contiguous() and tuple(out.shape) == (B, 3, out_size, out_size), "augment_images: out")
+    check(_l.load().bsclip_augment_images(_p(src), _p(records), B, mid_capacity, _p(mid), out_size, _p(out), _stream()))

@@ -215,6 +215,42 @@ int64_t bsclip_topk_ip_workspace_floats(int Q, int K, int D);
 int bsclip_topk_ip(const float* queries, int Q, const float* keys, int K, int D, int k, float* scores_out,
                    int64_t* idx_out, float* workspace, void* stream);
 
+/* ---- RCCL collectives of the global-batch step ---------------------------------------------------
+ * One process per GPU.  bsclip_comm_unique_id on rank 0 -> the caller ships the bsclip_comm_unique_id_bytes() bytes to the
+ * other ranks (any channel) -> bsclip_comm_init on every rank (ncclCommInitRank).  The collectives run on `comm_stream`;
+ * `wait_event` (hipEvent_t as void*, nullable) is waited for on that stream first -- record it on the stream that produced
+ * the payload -- and `done_event` (nullable) is recorded behind the collective for the consumer to wait on.  No host sync.
+ *   allgather_embeddings: gather_features (bioscanclip/model/loss_func.py:58-91, :84-89): local f32 [count] (= B*D) ->
+ *     gathered f32 [world*count], rank-major = row-major [world*B, D]; remote rows carry no gradient.
+ *   allgather_labels: the label all-gather of ClipLoss (loss_func.py:122), int64.
+ *   allreduce_grads: SUM over ranks of a flat f32 trainable-gradient buffer, in place (the gradient synchronisation
+ *     scripts/train_cl.py lacks).
+ * RCCL is bound with dlopen at first use; every call fails with a message when it cannot be found. */
+int bsclip_comm_unique_id_bytes(void);
+int bsclip_comm_unique_id(void* id_out);
+int bsclip_comm_init(void** comm_out, const void* unique_id, int rank, int world);
+int bsclip_comm_destroy(void* comm);
+int bsclip_allgather_embeddings(void* comm, const float* local, float* gathered, int64_t count, void* comm_stream,
+                                void* wait_event, void* done_event);
+int bsclip_allgather_labels(void* comm, const int64_t* local, int64_t* gathered, int64_t count, void* comm_stream,
+                            void* wait_event, void* done_event);
+int bsclip_allreduce_grads(void* comm, float* grads, int64_t count, void* comm_stream, void* wait_event, void* done_event);
+
+/* ---- input pipeline --------------------------------------------------------------------------------
+ * kmer_tokenize: get_sequence_pipeline(k) (bioscanclip/model/dna_encoder.py:25-35; PadSequence / KmerTokenizer,
+ *   bioscanclip/util/util.py:48-69).  seqs: the batch's nucleotide bytes back to back, offsets int64 [B+1]; each sequence is
+ *   truncated to max_len or right-padded with 'N', cut into max_len/k non-overlapping k-mers, id = 3 + base-4 value over
+ *   A,C,G,T (any other byte in the k-mer -> 2 = <UNK>), and a literal 0 (<MASK>) is put in front: ids int64 [B, max_len/k + 1].
+ * augment_images: the image transforms of Dataset_for_CL (bioscanclip/util/dataset.py:171-200) for B decoded uint8 HWC images
+ *   stored back to back in src_u8.  records int32 [B, 16] per image: {src offset lo, hi, H0, W0, H1, W1 (size after
+ *   Resize(256)), crop top, left, height, width (in the resized image), hflip, vflip, rotate flag, cos(angle), sin(angle) as
+ *   f32 bits, 0}.  mid: f32 scratch [B, 3, mid_capacity] (mid_capacity >= max H1*W1); out: f32 [B, 3, out_size, out_size].
+ *   Arithmetic: ToTensor, antialiased bilinear resize (torch _upsample_bilinear2d_aa) twice, flips, nearest-neighbour
+ *   rotation with zeros outside (torchvision functional_tensor.rotate).  The random draws are the caller's. */
+int bsclip_kmer_tokenize(const void* seqs, const int64_t* offsets, int B, int max_len, int k, int64_t* ids, void* stream);
+int bsclip_augment_images(const void* src_u8, const int32_t* records, int B, int64_t mid_capacity, float* mid, int out_size,
+                          float* out, void* stream);
+
 /* ---- LoRA / head gradients -------------------------------------------------------------------------------------
  * lora_grad: for one layer, from dqkv (bf16 [M, ld_dqkv], q cols [0,H), v cols [2H,3H)) and the augmented LN
  *   output h (bf16 [M, ld_h]: cols [0,H) = y, [H,H+4) = t_q, [H+4,H+8) = t_v):

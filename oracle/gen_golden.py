@@ -222,13 +222,30 @@ def gen_retrieval():
             "label_batch": batch, "label_list": convert_label_dict_to_list_of_dict(batch)}
 
 
+def gen_pipeline():
+    """PadSequence / KmerTokenizer of the reference (bioscanclip/util/util.py:48-69) on seeded strings: the pad + k-mer half
+    of get_sequence_pipeline.  (Its vocab is torchtext's, absent here: the id map stays restated, see oracle/pipeline.py.)"""
+    from bioscanclip.util.util import KmerTokenizer, PadSequence   # reference
+    g = torch.Generator().manual_seed(9)
+    seqs = []
+    for i in range(12):
+        L = int(torch.randint(0, 800, (1,), generator=g))
+        s = "".join("ACGT"[int(c)] for c in torch.randint(0, 4, (L,), generator=g))
+        if i % 3 == 1 and L > 40:
+            s = s[:17] + "N" + s[18:30] + "-" + s[31:]
+        seqs.append(s)
+    seqs += ["", "ACGTA", "T" * 700]
+    pad, tok = PadSequence(660), KmerTokenizer(5, stride=5)
+    return {"seqs": seqs, "kmers": [tok(pad(s)) for s in seqs]}
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     meta = {"torch": torch.__version__, "transformers": transformers.__version__,
             "reference": "bioscan-ml/bioscan-clip @ 2024-10-24 (/root/reference)"}
     jobs = {"loss": gen_loss, "encoders": gen_encoders, "state_dict_keys": gen_state_dict_keys,
-            "trajectory_id": gen_trajectory, "retrieval": gen_retrieval,
+            "trajectory_id": gen_trajectory, "retrieval": gen_retrieval, "pipeline": gen_pipeline,
             "trajectory_idt": lambda: gen_trajectory(steps=6, B=4, with_text=True, seed=32)}
     only = sys.argv[1:]
     for name, fn in jobs.items():

@@ -110,9 +110,38 @@ def test_rccl_collectives_at_world_size_one():
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     outs = {}
     for name, e in (("dist", env), ("plain", {k: v for k, v in env.items() if k != "BSCLIP_FORCE_DIST"})):
-        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--text", "--batch", "16", "--steps", "3", "--warmup", "1",
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--text", "--batch", "16", "--steps", "3", "--warmup", "3",
                             "--no-cpu-baseline"], env=e, capture_output=True, text=True, timeout=800)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = json.loads(r.stdout.strip().splitlines()[-1])
     # same seeds, same batch, dropout masks keyed on (seed, call count, rank 0): the collectives must not change the numbers
     assert outs["dist"]["config"]["final_loss"] == outs["plain"]["config"]["final_loss"], outs
+
+
+def test_native_comm_c_abi_collectives_world_size_one():
+    """include/bsclip.h's RCCL entry points (bsclip_comm_*, bsclip_allgather_*, bsclip_allreduce_grads) through their own
+    communicator at world_size 1: an all-gather returns the local rows, a SUM all-reduce leaves the buffer unchanged, and the
+    event wiring orders the collective behind a producer running on ANOTHER stream (the tower-stream pattern)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bioscanclip.hip.dist import NativeComm
+    comm = NativeComm(rank=0, world=1)
+    try:
+        tower = torch.cuda.Stream()
+        big = torch.randn(4096, 4096, device="cuda")
+        with torch.cuda.stream(tower):
+            z = (big @ big)[:256, :768].contiguous() * 1e-3          # a long-running producer on the tower stream
+            gathered, done = comm.all_gather(z)                       # ordered behind the tower stream only
+        torch.cuda.current_stream().wait_event(done)                  # the consumer (loss) waits for the collective
+        assert torch.equal(gathered, z)
+        lab = torch.arange(256, device="cuda")
+        gl, done = comm.all_gather(lab)
+        torch.cuda.current_stream().wait_event(done)
+        assert torch.equal(gl, lab)
+        flat = torch.randn(1_476_096, device="cuda")                  # the I+D trainable-gradient count
+        ref = flat.clone()
+        done = comm.all_reduce_sum_(flat)
+        torch.cuda.current_stream().wait_event(done)
+        assert torch.equal(flat, ref)
+    finally:
+        comm.close()

@@ -135,3 +135,36 @@ def test_retrieval_oracle_normalize_is_sklearn():
     keys = np.concatenate([x[:4], x[:4]])
     _, idx2 = R.topk_ip(x[:4], keys, 2)
     assert (idx2 == np.stack([np.arange(4), np.arange(4) + 4], 1)).all()
+
+
+def test_tokenizer_oracle_vs_reference_kmers():
+    """oracle/pipeline.py's pad + k-mer split against the reference's own PadSequence / KmerTokenizer (fixture), and the id map
+    against its definition (specials 0..2, then itertools.product('ACGT') order)."""
+    from oracle import pipeline as P
+    g = load_golden("pipeline")
+    for s, kmers in zip(g["seqs"], g["kmers"]):
+        assert P.pad_and_kmers(s) == kmers
+    ids = P.kmer_tokenize(g["seqs"])
+    assert ids.shape == (len(g["seqs"]), 133) and (ids[:, 0] == 0).all()
+    v = P.kmer_vocab(5)
+    assert v["AAAAA"] == 3 and v["AAAAC"] == 4 and v["TTTTT"] == 1026 and len(v) == 1027
+    assert ids[-1, 1:].tolist() == [1026] * 132 and (ids[-3, 1:] == 2).all()
+
+
+def test_augment_oracle_properties():
+    """The oracle chain on CPU: identity geometry reproduces torch's own antialiased resize; flips commute as expected."""
+    import torch
+    from oracle import pipeline as P
+    g = torch.Generator().manual_seed(1)
+    im = (torch.rand(300, 280, 3, generator=g) * 255).to(torch.uint8)
+    h1, w1 = P.resized_size(300, 280)
+    assert (h1, w1) == (274, 256)
+    base = P.augment(im, {"box": (0, 0, h1, w1), "hflip": False, "vflip": False, "angle": 0.0})
+    x = im.permute(2, 0, 1).float().div(255)
+    ref = torch.nn.functional.interpolate(torch.nn.functional.interpolate(x[None], size=[h1, w1], mode="bilinear", antialias=True),
+                                          size=[224, 224], mode="bilinear", antialias=True)[0]
+    assert torch.equal(base, ref)
+    fl = P.augment(im, {"box": (0, 0, h1, w1), "hflip": True, "vflip": True, "angle": 0.0})
+    assert torch.equal(fl, base.flip(-1).flip(-2))
+    r180 = P.augment(im, {"box": (0, 0, h1, w1), "hflip": False, "vflip": False, "angle": 180.0})
+    assert torch.allclose(r180, base.flip(-1).flip(-2))
