@@ -34,7 +34,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md chip table)
 GFLOP_PER_PAIR_ID = 118.3   # fwd 58.8 + LoRA-regime bwd
 GFLOP_PER_TRIPLE_IDT = 119.3
-FC1_TRAFFIC_BYTES_B256 = 892.5e6  # (11 x 1113.5 + 12 x 749.2 + 180.5) / 24 MB: the per-shape PMC figures, this build's launch mix
+FC1_TRAFFIC_BYTES_B256 = 765.8e6  # (11 x 953.3 + 12 x 644.9 + 154.5) / 24 MB: per-shape PMC figures (profiles/r02_c_fc1_pmc.txt), this build's launch mix
 
 
 class _Cfg:
@@ -121,9 +121,9 @@ def time_dominant_gemm(B, device, reps=4):
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             # bytes per launch at the L2's memory side, FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, averaged over the
-            # same launch mix; collected offline with rocprofv3 --pmc (profiles/r01_c_fc1_traffic.txt), valid for B=256
+            # same launch mix; collected offline with rocprofv3 --pmc (profiles/r02_c_fc1_pmc.txt), valid for B=256
             "traffic": FC1_TRAFFIC_BYTES_B256 if B == 256 else None,
-            "traffic_note": "rocprofv3 PMC, profiles/r01_c_fc1_traffic.txt; algorithmic bytes per launch: "
+            "traffic_note": "rocprofv3 PMC, profiles/r02_c_fc1_pmc.txt; algorithmic bytes per launch: "
                             "%.1f MB (A + W bf16, gelu bf16, gelu' 8-bit)" % (sum(((M * K + N * K) * 2.0 + 3.0 * M * N) * c for M, N, K, c in shapes)
                                                                              / launches / 1e6),
             "kernel": "gemm_nt_pp_kernel<2 = EPI_GELU_BF16, true> (fc1 + bias + GELU; 24 launches per step)",
