@@ -65,6 +65,7 @@ SIGNATURES = {
     "bsclip_l2norm_fwd": (I, [P, I, I, P, P, P]),
     "bsclip_l2norm_bwd": (I, [P, P, P, I, I, P, P]),
     "bsclip_infonce_workspace_floats": (L, [I, I]),
+    "bsclip_infonce_set_impl": (I, [I]),
     "bsclip_infonce_fwd_bwd": (I, [POINTER(c_void_p), I, P, I, I, F, I, I, P, POINTER(c_void_p), P, P]),
     "bsclip_topk_ip_workspace_floats": (L, [I, I, I]),
     "bsclip_topk_ip": (I, [P, I, P, I, I, I, P, P, P, P]),

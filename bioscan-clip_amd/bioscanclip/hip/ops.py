@@ -338,6 +338,11 @@ def l2norm_bwd(y, inv_norm, dy, dx):
     check(_l.load().bsclip_l2norm_bwd(_p(y), _p(inv_norm), _p(dy), M, D, _p(dx), _stream()))
 
 
+def infonce_set_impl(impl):
+    """0 = fused InfoNCE epilogues (default), 1 = f32 logits slabs (kept for timing / cross-checks)."""
+    check(_l.load().bsclip_infonce_set_impl(int(impl)))
+
+
 def infonce_workspace_floats(N, nmod):
     n = _l.load().bsclip_infonce_workspace_floats(N, nmod)
     if n < 0:

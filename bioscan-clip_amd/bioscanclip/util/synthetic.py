@@ -50,3 +50,35 @@ class SyntheticEvalLoader(SyntheticCLIPLoader):
             lab = {"order": [f"o{v % 2}" for v in sp], "family": [f"f{v % 3}" for v in sp],
                    "genus": [f"g{v % 5}" for v in sp], "species": [f"s{v}" for v in sp]}
             yield pid, image, dna, ids, tt, am, lab
+
+
+class SyntheticRawLoader(SyntheticCLIPLoader):
+    """``dataset=synthetic_raw``: the stored form of the data -- decoded uint8 images of assorted sizes and nucleotide strings of
+    assorted lengths -- pushed through the GPU input pipeline (bioscanclip/util/gpu_pipeline.py: the reference's Dataset_for_CL
+    transforms, dataset.py:171-181, and get_sequence_pipeline, dna_encoder.py:25-35) inside the loader, so a training run
+    exercises it end to end.  Yields the same 7-tuple as SyntheticCLIPLoader, with image / dna already on the device."""
+
+    SIZES = [(256, 256), (288, 256), (256, 341), (320, 320)]
+
+    def __init__(self, batch_size, steps, with_text=False, seed=1234, rank=0, world_size=1, for_training=True, device="cuda"):
+        super().__init__(batch_size, steps, with_text=with_text, seed=seed, rank=rank, world_size=world_size)
+        from bioscanclip.util.gpu_pipeline import GpuAugment
+        self.augment = GpuAugment(for_training=for_training, seed=seed + 17 * rank)
+        self.device = device
+
+    def __iter__(self):
+        from bioscanclip.util.gpu_pipeline import tokenize_barcodes
+        B = self.batch_size
+        for s, (pid, _, _, ids, tt, am, label) in enumerate(super().__iter__()):
+            g = torch.Generator().manual_seed(self.seed + 7919 * s + self.rank)
+            images = []
+            for i in range(B):
+                h, w = self.SIZES[int(torch.randint(0, len(self.SIZES), (1,), generator=g))]
+                images.append(torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8))
+            seqs = []
+            for i in range(B):
+                L = int(torch.randint(500, 720, (1,), generator=g))
+                seqs.append("".join("ACGT"[int(c)] for c in torch.randint(0, 4, (L,), generator=g)))
+            image, _ = self.augment(images, device=self.device)
+            dna = tokenize_barcodes(seqs, device=self.device)
+            yield pid, image, dna, ids, tt, am, label

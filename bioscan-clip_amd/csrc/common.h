@@ -188,3 +188,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// gemm.hip, internal: the fused InfoNCE products on the 256x256 ping-pong GEMM (see the EPI_LSE_PART / EPI_LOSS_W epilogues)
+int bsclip_gemm_infonce(int mode, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                        const int64_t* labels, const float* cnt, const float* lse_row, const float* lse_col, float* part,
+                        float logit_scale, float coef, int n_valid, int row_base, void* stream);

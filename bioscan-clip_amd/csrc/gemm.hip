@@ -52,7 +52,17 @@ struct EpiArgs {
     const bf16_t* a_aug;                  // bf16 [M, 64] K-augmentation block (LoRA t columns), nullable
     const bf16_t* b_aug;                  // bf16 [N, 64] matching weight columns (LoRA B / alpha[n])
     int ld_a_aug, ld_b_aug;
+    // fused InfoNCE epilogues (EPI_LSE_PART / EPI_LOSS_W, internal: bsclip_gemm_infonce): the accumulator tile holds cosines
+    const int64_t* labels;                // [>= n_valid]
+    const float* cnt;                     // cnt[i] = #{j : label_j == label_i}
+    const float* lse_row;                 // LSE of the rows of THIS product (a -> b), indexed by global row
+    const float* lse_col;                 // LSE of the transposed product (b -> a), indexed by column
+    float* part;                          // EPI_LSE_PART out: [M, tiles_n, 4] = (row max, sum exp, sum_j T_ij x_ij, -)
+    float logit_scale, coef;              // x = logit_scale * cosine;  w = coef * (...)
+    int n_valid, row_base;                // columns >= n_valid are padding; global row of local row 0
 };
+constexpr int EPI_LSE_PART = 100;  // internal epilogues, not part of the public enum
+constexpr int EPI_LOSS_W = 101;
 
 // ---------------------------------------------------------------------------------------------------------------
 // GELU table for the 256x256 kernel's epilogue
@@ -749,6 +759,148 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[mi][ni][i][j] += bias[ni][j];
     }
+    // ---- fused InfoNCE, pass 1: the logits tile never leaves the accumulators --------------------------------------
+    // Per output row the tile's 256 columns live in 4 waves (wc) x 4 lanes (fq) x 16 registers: in-lane reduction, two xor
+    // shuffles (16, 32) across the lanes that share a row, LDS across the four waves.  Written per (row, column tile):
+    // (max, sum exp(x - max), sum over same-label columns of x); infonce_combine_kernel merges the column tiles.
+    if constexpr (EPI == EPI_LSE_PART) {
+        __syncthreads();  // every wave is past its last fragment read: the staging LDS is free
+        float* red = reinterpret_cast<float*>(smem);  // [256 rows][4 waves][4]
+        long lcol[2][2][4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int n = n0 + 64 * wc + 32 * ni + 16 * j + 4 * fq + c;
+                    lcol[ni][j][c] = n < e.n_valid ? (long)e.labels[n] : (long)0x7fffffffffffffffLL;
+                }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 128 * g + 64 * mi + 16 * i + fr;
+                const int grow = e.row_base + min(m0 + r, M - 1);
+                const long li = (long)e.labels[min(grow, e.n_valid - 1)];
+                float x[16];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int n = n0 + 64 * wc + 32 * ni + 16 * j + 4 * fq + c;
+                            const float v = n < e.n_valid ? acc[mi][ni][i][j][c] * e.logit_scale : -INFINITY;
+                            x[(ni * 2 + j) * 4 + c] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float se = 0.f, dot = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float v = x[(ni * 2 + j) * 4 + c];
+                            se += mx == -INFINITY ? 0.f : __expf(v - mx);
+                            dot += lcol[ni][j][c] == li ? v : 0.f;
+                        }
+                se += __shfl_xor(se, 16, 64);
+                se += __shfl_xor(se, 32, 64);
+                dot += __shfl_xor(dot, 16, 64);
+                dot += __shfl_xor(dot, 32, 64);
+                if (fq == 0) *reinterpret_cast<f32x4*>(red + (r * 4 + wc) * 4) = f32x4{mx, se, dot, 0.f};
+            }
+        __syncthreads();
+        if (tid < 256 && m0 + tid < M) {
+            float mm = -INFINITY, ss = 0.f, dd = 0.f;
+            f32x4 p[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                p[w] = *reinterpret_cast<const f32x4*>(red + (tid * 4 + w) * 4);
+                mm = fmaxf(mm, p[w][0]);
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                ss += p[w][0] == -INFINITY ? 0.f : p[w][1] * __expf(p[w][0] - mm);
+                dd += p[w][2];
+            }
+            *reinterpret_cast<f32x4*>(e.part + ((size_t)(m0 + tid) * tiles_n + tile_n) * 4) = f32x4{mm, ss, dd, 0.f};
+        }
+        return;
+    }
+    // ---- fused InfoNCE, pass 2: dLoss/dG of the tile, straight from the accumulators, in split-bf16 form --------------
+    // w_ij = coef (cnt_i exp(x - lse_ab[i]) + cnt_j exp(x - lse_ba[j]) - 2 T_ij) for j < n_valid, else 0; written as the
+    // operand [hi | hi | lo] of the gradient GEMM (C bf16 [M, ldc = 3 * Np]) -- the logits themselves are never stored.
+    if constexpr (EPI == EPI_LOSS_W) {
+        constexpr int SBW = 528;
+        __syncthreads();
+        char* slab_hi = smem + g * (64 * SBW);
+        char* slab_lo = smem + 2 * 64 * SBW + g * (64 * SBW);
+        long lcol[2][2][4];
+        float ccol[2][2][4], lcolse[2][2][4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int n = n0 + 64 * wc + 32 * ni + 16 * j + 4 * fq + c;
+                    const bool ok = n < e.n_valid;
+                    lcol[ni][j][c] = ok ? (long)e.labels[n] : (long)0x7fffffffffffffffLL;
+                    ccol[ni][j][c] = ok ? e.cnt[n] : 0.f;
+                    lcolse[ni][j][c] = ok ? e.lse_col[n] : 0.f;
+                }
+        const int np = ldc / 3;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 128 * g + 64 * mi + 16 * i + fr;
+                const int grow = min(e.row_base + min(m0 + r, M - 1), e.n_valid - 1);
+                const long li = (long)e.labels[grow];
+                const float ci = e.cnt[grow], lr = e.lse_row[grow];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float wv[4], hi[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int n = n0 + 64 * wc + 32 * ni + 16 * j + 4 * fq + c;
+                            const float xv = acc[mi][ni][i][j][c] * e.logit_scale;
+                            const float t = lcol[ni][j][c] == li ? 2.0f : 0.0f;
+                            wv[c] = n < e.n_valid ? e.coef * (ci * __expf(xv - lr) + ccol[ni][j][c] * __expf(xv - lcolse[ni][j][c]) - t) : 0.f;
+                            hi[c] = bf2f(f2bf(wv[c]));
+                        }
+                        const int off = (16 * i + fr) * SBW + (64 * wc + 32 * ni + 16 * j + 4 * fq) * 2;
+                        *reinterpret_cast<uint2*>(slab_hi + off) = uint2{pack_bf2(wv[0], wv[1]), pack_bf2(wv[2], wv[3])};
+                        *reinterpret_cast<uint2*>(slab_lo + off) =
+                            uint2{pack_bf2(wv[0] - hi[0], wv[1] - hi[1]), pack_bf2(wv[2] - hi[2], wv[3] - hi[3])};
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 8 + (wave & 3) * 2 + (lane >> 5);
+                const int m = m0 + 128 * g + 64 * mi + r;
+                const uint4 vh = *reinterpret_cast<const uint4*>(slab_hi + r * SBW + (lane & 31) * 16);
+                const uint4 vl = *reinterpret_cast<const uint4*>(slab_lo + r * SBW + (lane & 31) * 16);
+                if (m < M) {
+                    bf16_t* dst = static_cast<bf16_t*>(C) + (size_t)m * ldc + n0 + (lane & 31) * 8;
+                    *reinterpret_cast<uint4*>(dst) = vh;
+                    *reinterpret_cast<uint4*>(dst + np) = vh;
+                    *reinterpret_cast<uint4*>(dst + 2 * np) = vl;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // ---- LDS-staged, row-coalesced stores --------------------------------------------------------------------
     // In the accumulator layout a lane owns 4 consecutive columns of 16 different rows, so direct stores are 8-B
     // (bf16) pieces of 32-B row segments: 64-128 store instructions per lane, store-ISSUE bound (the epilogue cost
@@ -1113,6 +1265,43 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
             launch_bias<BSCLIP_EPI_PATCH_F32>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
             break;
         default: BSCLIP_REQUIRE(false, "bsclip_gemm_bf16: unknown epilogue %d", epilogue);
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused InfoNCE products (called by loss.hip; not part of the public ABI)
+// ---------------------------------------------------------------------------------------------------------------
+// mode 0: pass 1 -- part[M, N/256, 4] from cosines A[M,K] . B[N,K]^T;  mode 1: pass 2 -- C = dL/dG in split form [M, 3*Np].
+int bsclip_gemm_infonce(int mode, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                        const int64_t* labels, const float* cnt, const float* lse_row, const float* lse_col, float* part,
+                        float logit_scale, float coef, int n_valid, int row_base, void* stream) {
+    BSCLIP_REQUIRE(A && B && labels && M > 0 && N % 256 == 0 && K % 64 == 0, "bsclip_gemm_infonce: bad shape M=%d N=%d K=%d", M, N, K);
+    EpiArgs e{};
+    e.labels = labels;
+    e.cnt = cnt;
+    e.lse_row = lse_row;
+    e.lse_col = lse_col;
+    e.part = part;
+    e.logit_scale = logit_scale;
+    e.coef = coef;
+    e.n_valid = n_valid;
+    e.row_base = row_base;
+    e.n_total = N;
+    e.drop = make_drop(0.f, 0);
+    const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16_t* a = static_cast<const bf16_t*>(A);
+    const bf16_t* b = static_cast<const bf16_t*>(B);
+    if (mode == 0) {
+        BSCLIP_REQUIRE(part, "bsclip_gemm_infonce: part is null");
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI_LSE_PART, false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, lda, b, ldb, C,
+                           ldc, M, N, K, tiles_n, e);
+    } else {
+        BSCLIP_REQUIRE(C && cnt && lse_row && lse_col && ldc % 3 == 0, "bsclip_gemm_infonce: pass 2 operands");
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI_LOSS_W, false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, lda, b, ldb, C,
+                           ldc, M, N, K, tiles_n, e);
     }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;

@@ -6,12 +6,20 @@
 //
 // The temperature (s = 1/0.07) amplifies logit error 14x, so the N x N products must be f32-accurate, but they
 // should still run on the bf16 MFMA GEMM.  Each f32 operand x is split x = hi + lo (two bf16) and the product is
-// formed as hi.hi + hi.lo + lo.hi by concatenating along K ([hi|hi|lo] x [hi|lo|hi]^T): one bsclip_gemm_bf16 call
-// with K = 3*768, relative error ~2^-16.  Per directed pair: pass 1 = logits GEMM + row reduction (LSE, sum T.G);
-// pass 2 (only the rank's own rows) = logits GEMM + dL/dG tile kernel (written directly in split form) + gradient
-// GEMM accumulated in f32.  The second F.normalize (loss_func.py:43-44) and its Jacobian are applied here.
-// Logits are formed in row slabs of <= 1024 rows ([slab x N] f32 in the caller's workspace), reduced (pass 1) or turned
-// into dL/dG (pass 2) and discarded: the N x N matrix never exists in HBM.
+// formed as hi.hi + hi.lo + lo.hi by concatenating along K ([hi|hi|lo] x [hi|lo|hi]^T): one MFMA product with K = 3*768,
+// relative error ~2^-16.  The second F.normalize (loss_func.py:43-44) and its Jacobian are applied here.
+//
+// Fused form (default; north_star's "fused logits kernel"): the logits are never written to memory.
+//   pass 1, one launch per directed pair (a,b): the 256x256 ping-pong GEMM streams z^b's tiles through LDS, keeps the logits
+//     tile in its MFMA accumulators and reduces row max / sum exp / sum_j T_ij x_ij in place -- in-lane, two xor shuffles
+//     across the lanes that share a row, LDS across the four waves (gemm.hip, EPI_LSE_PART) -- to one (max, sum, dot) triple
+//     per row and column tile; infonce_combine_kernel merges the N/256 triples of a row into LSE_i and the loss term.
+//     The column statistics of (a,b) are the row statistics of the transposed pass (b,a).
+//   pass 2 (only the rank's own rows): the same product again, its epilogue turns the accumulator tile into dL/dG
+//     (EPI_LOSS_W: needs LSE of both directions) and writes it as the split-bf16 operand of the gradient GEMM
+//     dz^a += W z^b, accumulated in f32.
+// Slab form (bsclip_infonce_set_impl(1), kept for A/B timing and as a second implementation to test against): logits in row
+// slabs of <= 1024 rows as f32 in the workspace, a separate row-reduce / dL/dG kernel reads them back.
 #include <math.h>
 
 #include "common.h"
@@ -166,18 +174,40 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict
     if (threadIdx.x == 0) loss_out[0] = red[0] * scale;
 }
 
+// merge the per-column-tile triples of pass 1: LSE_i = M + log sum_t s_t exp(m_t - M), contrib_i = cnt_i LSE_i - sum_t dot_t
+__global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __restrict__ part, int N, int tiles,
+                                                              const float* __restrict__ cnt, float* __restrict__ lse,
+                                                              float* __restrict__ contrib) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + (size_t)i * tiles;
+    float m = -INFINITY;
+    for (int t = 0; t < tiles; ++t) m = fmaxf(m, p[t][0]);
+    float s = 0.f, dot = 0.f;
+    for (int t = 0; t < tiles; ++t) {   // fixed order: bitwise reproducible
+        const f32x4 v = p[t];
+        s += v[0] == -INFINITY ? 0.f : v[1] * __expf(v[0] - m);
+        dot += v[2];
+    }
+    const float l = m + __logf(s);
+    lse[i] = l;
+    contrib[i] = cnt[i] * l - dot;
+}
+
+int g_infonce_impl = 0;  // 0 = fused epilogues (default), 1 = f32 logits slabs + separate reduce kernels
+
 inline int64_t align4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
 constexpr int SLAB_ROWS = 1024;  // logits are formed [SLAB_ROWS x N] at a time: the N x N matrix never exists in HBM
 
 struct Layout {
     int Np, slab;
-    int64_t zn, inv, PA, PB, PBt, G, W, lse, contrib, cnt, dacc, total;
+    int64_t zn, inv, PA, PB, PBt, G, W, lse, contrib, cnt, dacc, part, total;
 };
 
 Layout make_layout(int N, int nmod, int D) {
     Layout L;
-    L.Np = (N + 127) / 128 * 128;
+    L.Np = (N + 255) / 256 * 256;   // a whole number of 256-wide column tiles for the fused epilogues
     L.slab = L.Np < SLAB_ROWS ? L.Np : SLAB_ROWS;
     const int64_t Np = L.Np, SL = L.slab;
     int64_t o = 0;
@@ -192,6 +222,7 @@ Layout make_layout(int N, int nmod, int D) {
     L.contrib = o; o += align4((int64_t)nmod * nmod * Np);
     L.cnt = o;     o += align4(Np);
     L.dacc = o;    o += align4((int64_t)nmod * Np * D);
+    L.part = o;    o += align4(Np * (Np / 256) * 4);
     L.total = o;
     return L;
 }
@@ -228,6 +259,8 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
     float* contrib = ws + L.contrib;
     float* cnt = ws + L.cnt;
     float* dacc = ws + L.dacc;
+    float* part = ws + L.part;
+    const bool fused = g_infonce_impl == 0;
     const size_t opA = (size_t)Np * 3 * D;  // elements per modality in PA / PB
     const size_t opT = (size_t)D * 3 * Np;  // elements per modality in PBt
 
@@ -248,6 +281,14 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
         for (int b = 0; b < nmod; ++b) {
             if (a == b) continue;
             const int slot = a * nmod + b;
+            if (fused) {
+                int rc = bsclip_gemm_infonce(0, PA + a * opA, 3 * D, PB + b * opA, 3 * D, nullptr, 0, N, Np, 3 * D, labels, cnt,
+                                             nullptr, nullptr, part, scale, 0.f, N, 0, stream);
+                if (rc) return rc;
+                hipLaunchKernelGGL(infonce_combine_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, part, N, Np / 256, cnt,
+                                   lse + (size_t)slot * Np, contrib + (size_t)slot * Np);
+                continue;
+            }
             for (int r0 = 0; r0 < N; r0 += L.slab) {
                 const int nr = N - r0 < L.slab ? N - r0 : L.slab;
                 int rc = bsclip_gemm_bf16(PA + a * opA + (size_t)r0 * 3 * D, 3 * D, PB + b * opA, 3 * D, G, Np, nr, Np,
@@ -272,15 +313,23 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
             if (a == b) continue;
             for (int l0 = 0; l0 < n_local; l0 += L.slab) {  // row slabs of the rank's own rows
                 const int nr = n_local - l0 < L.slab ? n_local - l0 : L.slab;
-                int rc = bsclip_gemm_bf16(PA + a * opA + (size_t)(row0 + l0) * 3 * D, 3 * D, PB + b * opA, 3 * D, G, Np,
-                                          nr, Np, 3 * D, BSCLIP_EPI_F32, nullptr, stream);
-                if (rc) return rc;
-                long tot = (long)nr * Np;
-                long blocks = (tot + 255) / 256;
-                if (blocks > 4096) blocks = 4096;
-                hipLaunchKernelGGL(loss_w_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, N, Np, row0 + l0, nr, scale,
-                                   coef, labels, cnt, lse + (size_t)(a * nmod + b) * Np, lse + (size_t)(b * nmod + a) * Np,
-                                   W);
+                int rc;
+                if (fused) {
+                    rc = bsclip_gemm_infonce(1, PA + a * opA + (size_t)(row0 + l0) * 3 * D, 3 * D, PB + b * opA, 3 * D, W, 3 * Np,
+                                             nr, Np, 3 * D, labels, cnt, lse + (size_t)(a * nmod + b) * Np,
+                                             lse + (size_t)(b * nmod + a) * Np, nullptr, scale, coef, N, row0 + l0, stream);
+                    if (rc) return rc;
+                } else {
+                    rc = bsclip_gemm_bf16(PA + a * opA + (size_t)(row0 + l0) * 3 * D, 3 * D, PB + b * opA, 3 * D, G, Np, nr, Np,
+                                          3 * D, BSCLIP_EPI_F32, nullptr, stream);
+                    if (rc) return rc;
+                    long tot = (long)nr * Np;
+                    long blocks = (tot + 255) / 256;
+                    if (blocks > 4096) blocks = 4096;
+                    hipLaunchKernelGGL(loss_w_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, N, Np, row0 + l0, nr, scale,
+                                       coef, labels, cnt, lse + (size_t)(a * nmod + b) * Np, lse + (size_t)(b * nmod + a) * Np,
+                                       W);
+                }
                 float* dar = da + (size_t)l0 * D;
                 bsclip_epi_args ea{};
                 ea.struct_size = sizeof(ea);
@@ -298,5 +347,11 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
         if (rc) return rc;
     }
     BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_infonce_set_impl(int impl) {
+    BSCLIP_REQUIRE(impl == 0 || impl == 1, "bsclip_infonce_set_impl: %d (0 = fused epilogues, 1 = logits slabs)", impl);
+    g_infonce_impl = impl;
     return BSCLIP_OK;
 }

@@ -10,7 +10,9 @@ AdamW (+ optional one_cycle / exponential / step / cosine scheduler, stepped per
   * with world_size > 1 the loss is the all-gathered global-batch loss and the flat trainable gradients are
     all-reduced (the reference never synchronises gradients: SURVEY App. B-1);
   * parameters are broadcast as one flat buffer per encoder (reference: one broadcast per tensor, train_cl.py:29-31);
-  * the HDF5 datasets are not available here: ``dataset=synthetic`` (default) feeds synthetic batches of the same layout;
+  * the HDF5 datasets are not available here: ``dataset=synthetic`` (default) feeds synthetic batches of the same layout,
+    ``dataset=synthetic_raw`` feeds raw uint8 images + nucleotide strings through the GPU input pipeline (the reference's
+    augmentation chain and 5-mer tokeniser as HIP kernels, bioscanclip/util/gpu_pipeline.py);
   * the per-epoch evaluation (``eval_phase``, reference train_cl.py:217-243) runs natively: feature extraction with the HIP
     encoders and top-k retrieval with ``bsclip_topk_ip`` in place of faiss.
 """
@@ -34,7 +36,7 @@ from bioscanclip.hip.optim import FusedAdamW  # noqa: E402
 from bioscanclip.model.loss_func import ContrastiveLoss, GlobalBatchContrastiveLoss  # noqa: E402
 from bioscanclip.model.simple_clip import load_clip_model  # noqa: E402
 from bioscanclip.util.config import load_config  # noqa: E402
-from bioscanclip.util.synthetic import SyntheticCLIPLoader, SyntheticEvalLoader  # noqa: E402
+from bioscanclip.util.synthetic import SyntheticCLIPLoader, SyntheticEvalLoader, SyntheticRawLoader  # noqa: E402
 
 
 def print_when_rank_zero(message, rank=0):
@@ -115,10 +117,13 @@ def main_process(rank: int, world_size: int, args):
     print_when_rank_zero("Construct dataloader...", rank)
     steps = int(getattr(args, "synthetic_steps_per_epoch", 20))
     with_text = hasattr(mc, 'language')
-    if getattr(args, "dataset", "synthetic") != "synthetic":
-        raise NotImplementedError("HDF5 datasets are outside the accelerated path (SURVEY 8f-3); use dataset=synthetic")
-    pre_train_dataloader = SyntheticCLIPLoader(int(mc.batch_size), steps, with_text=with_text, rank=rank,
-                                               world_size=world_size)
+    dataset = getattr(args, "dataset", "synthetic")
+    if dataset not in ("synthetic", "synthetic_raw"):
+        raise NotImplementedError("the HDF5 reader is outside the accelerated path (SURVEY 8f-3; h5py is absent): use "
+                                  "dataset=synthetic, or dataset=synthetic_raw to run the GPU input pipeline (augmentation + "
+                                  "5-mer tokeniser) on raw uint8 images / nucleotide strings")
+    Loader = SyntheticRawLoader if dataset == "synthetic_raw" else SyntheticCLIPLoader
+    pre_train_dataloader = Loader(int(mc.batch_size), steps, with_text=with_text, rank=rank, world_size=world_size)
 
     print_when_rank_zero("Initialize model...", rank)
     if not hasattr(args, "allow_random_init"):

@@ -427,3 +427,38 @@ def test_adamw_matches_oracle_and_torch(ops):
         opt.step()
     assert rel_err(p, pr) < 1e-6
     assert rel_err(p, pt) < 1e-6
+
+
+@pytest.mark.parametrize("N,nmod", [(256, 2), (700, 3), (2048, 3)])
+def test_infonce_fused_epilogues_vs_logits_slabs(ops, N, nmod):
+    """The fused form (logits tile reduced in the GEMM's accumulators, dL/dG emitted from them) against round 1's form that
+    writes f32 logits slabs and reduces them with separate kernels: two implementations of the same arithmetic.  Timings of
+    both go to gpurun_out/infonce_timing.jsonl."""
+    import json
+    import os
+    zs = [dev(torch.nn.functional.normalize(rnd(N, 768, seed=40 + i) + 0.3 * rnd(1, 768, seed=50), dim=-1)) for i in range(nmod)]
+    label = dev(torch.arange(N) // 2 * 2)
+    ws = torch.empty(ops.infonce_workspace_floats(N, nmod), device="cuda")
+    res, ms = {}, {}
+    try:
+        for impl in (0, 1):
+            ops.infonce_set_impl(impl)
+            loss = torch.zeros(1, device="cuda")
+            dz = [torch.empty(N, 768, device="cuda") for _ in range(nmod)]
+            ops.infonce_fwd_bwd(zs, label, 1 / 0.07, loss, dz, workspace=ws)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.infonce_fwd_bwd(zs, label, 1 / 0.07, loss, dz, workspace=ws)
+            e1.record()
+            torch.cuda.synchronize()
+            ms[impl] = e0.elapsed_time(e1) / 5
+            res[impl] = (loss.item(), [d.clone() for d in dz])
+    finally:
+        ops.infonce_set_impl(0)
+    assert abs(res[0][0] - res[1][0]) < 2e-6 * abs(res[1][0]), (res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert rel_err(a, b) < 2e-5
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/infonce_timing.jsonl", "a") as f:
+        f.write(json.dumps({"N": N, "nmod": nmod, "fused_ms": ms[0], "slab_ms": ms[1]}) + "\n")

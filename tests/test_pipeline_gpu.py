@@ -79,3 +79,16 @@ def test_augmentation_matches_oracle(for_training):
             assert (want == 0).all(0).float().mean() > 0.01               # the rotation left black corners: it really ran
     if not for_training:
         assert mism_total == 0                                             # no rotation -> no rounding ambiguity at all
+
+
+def test_train_cl_on_raw_synthetic_data(tmp_path, capsys):
+    """scripts/train_cl.py with dataset=synthetic_raw: every batch goes uint8 images / nucleotide strings -> GPU augmentation +
+    tokeniser -> encoders -> loss -> AdamW."""
+    import os
+    import sys
+    scripts = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bioscan-clip_amd", "scripts")
+    sys.path.insert(0, scripts)
+    import train_cl
+    losses = train_cl.main(["model_config=lora_vit_lora_barcode_bert_ssl", "model_config.batch_size=8", "model_config.epochs=1",
+                            "synthetic_steps_per_epoch=3", "dataset=synthetic_raw", f"project_root_path={tmp_path}"])
+    assert len(losses) == 1 and losses[0] == losses[0] and 0.5 < losses[0] < 10
