@@ -34,6 +34,47 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["hyper_host"][0] = float(self.param_groups[0]["lr"])
                 st["hyper_host"][1] = float(st["step"])
 
+    def _state_for(self, f):
+        """Adam moments of one flat buffer.  Keyed by the PARAMETERS it holds (they outlive an engine rebuild: a checkpoint
+        loaded mid-run, a precision switch), not by the buffer object; every parameter's slice is also published in
+        ``self.state[p]`` as views (``exp_avg``, ``exp_avg_sq``, ``step``) so ``state_dict()`` / ``load_state_dict()`` carry
+        the moments like torch.optim.AdamW's do."""
+        key = tuple(id(p) for p in f.params)
+        st = self._flat_state.get(id(f))
+        if st is None or st["m"].numel() != f.data.numel() or st.get("key") != key:
+            prev = next((v for v in self._flat_state.values() if v.get("key") == key and v["m"].numel() == f.data.numel()), None)
+            st = {"m": torch.zeros_like(f.data), "v": torch.zeros_like(f.data), "step": 0, "key": key}
+            if prev is not None:                      # engine rebuilt: the optimisation continues, it does not restart
+                st["m"].copy_(prev["m"])
+                st["v"].copy_(prev["v"])
+                st["step"] = prev["step"]
+            else:                                     # moments restored by load_state_dict() before the buffer existed
+                for p, o in zip(f.params, f.offsets):
+                    ps = self.state.get(p)
+                    if ps and "exp_avg" in ps and ps["exp_avg"].numel() == p.numel():
+                        st["m"][o:o + p.numel()].copy_(ps["exp_avg"].reshape(-1).to(st["m"].device))
+                        st["v"][o:o + p.numel()].copy_(ps["exp_avg_sq"].reshape(-1).to(st["v"].device))
+                        st["step"] = max(st["step"], int(ps.get("step", 0)))
+            self._flat_state = {k: v for k, v in self._flat_state.items() if v.get("key") != key}
+            self._flat_state[id(f)] = st
+            for p, o in zip(f.params, f.offsets):
+                self.state[p] = {"step": st["step"], "exp_avg": st["m"][o:o + p.numel()].view(p.shape),
+                                 "exp_avg_sq": st["v"][o:o + p.numel()].view(p.shape)}
+        return st
+
+    def state_dict(self):
+        for f in self._flats:                         # the per-parameter step counts follow the flat buffer's
+            st = self._flat_state.get(id(f))
+            if st is not None:
+                for p in f.params:
+                    if p in self.state:
+                        self.state[p]["step"] = st["step"]
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat_state = {}                         # next step(): moments are copied from self.state into the flat buffers
+
     def attach(self, model):
         """Tell the optimizer which engines' flat buffers exist (called by train_epoch after the first forward)."""
         from .dist import flat_buffers
@@ -69,10 +110,7 @@ class FusedAdamW(torch.optim.Optimizer):
             if not f.valid() or not all(id(p) in in_opt for p in f.params):
                 continue
             g = in_opt[id(f.params[0])]
-            st = self._flat_state.get(id(f))
-            if st is None or st["m"].numel() != f.data.numel():
-                st = {"m": torch.zeros_like(f.data), "v": torch.zeros_like(f.data), "step": 0}
-                self._flat_state[id(f)] = st
+            st = self._state_for(f)
             f.bind_grads()
             st["step"] += 1
             if self._dev_hyper:

@@ -52,7 +52,9 @@ def load_pre_trained_bioscan_bert(bioscan_bert_checkpoint, k=5):
             raise FileNotFoundError(bioscan_bert_checkpoint)
         state_dict = torch.load(bioscan_bert_checkpoint, map_location=torch.device("cpu"))
         state_dict = {(k_[7:] if k_.startswith("module.") else k_): v for k_, v in state_dict.items()}
-        model.load_state_dict(state_dict, strict=False)
+        from bioscanclip.util.util import load_checked
+        load_checked(model, state_dict, f"BarcodeBERT checkpoint {bioscan_bert_checkpoint}",
+                     allow_unexpected=("bert.embeddings.position_ids",))   # a buffer older transformers versions saved
     return model
 
 

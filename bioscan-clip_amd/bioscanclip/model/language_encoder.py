@@ -22,7 +22,9 @@ def load_pre_trained_bert(checkpoint=None):
     pre-computed from the HDF5 file)."""
     model = BertModelParams(bert_small_config())
     if checkpoint is not None:
-        model.load_state_dict(torch.load(checkpoint, map_location="cpu"), strict=False)
+        from bioscanclip.util.util import load_checked
+        load_checked(model, torch.load(checkpoint, map_location="cpu"), f"BERT-small checkpoint {checkpoint}",
+                     allow_unexpected=("embeddings.position_ids",))
     for param in model.parameters():
         param.requires_grad = False
     return None, model

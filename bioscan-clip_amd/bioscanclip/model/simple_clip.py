@@ -87,7 +87,10 @@ def _load_vit(args):
     vit = vit_base_patch16_224()
     ckpt = getattr(args, "vit_checkpoint", None) if args is not None else None
     if ckpt:
-        vit.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=False)
+        from bioscanclip.util.util import load_checked
+        # timm checkpoints carry the 1000-class ImageNet head; the head is replaced by reset_classifier right after
+        load_checked(vit, torch.load(ckpt, map_location="cpu"), f"ViT checkpoint {ckpt}", allow_missing=("head.",),
+                     allow_unexpected=("head.", "fc_norm."))
     return vit
 
 

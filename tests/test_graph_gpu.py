@@ -85,3 +85,63 @@ def test_adamw_device_hyper_equals_host_arguments():
         hyper.copy_(torch.tensor([lr, float(step)]))
         ops.adamw_step_dev(pb, gr, mb, vb, hyper, 0.9, 0.999, 1e-8, 0.01)
     assert rel_err(pb, pa) < 1e-7
+
+
+def test_optimizer_state_survives_rebuild_and_state_dict_roundtrip():
+    """the Adam moments must appear in ``state_dict()``, survive an engine rebuild (checkpoint loaded mid-run) and a
+    ``load_state_dict`` into a fresh optimizer -- a continued run equals an uninterrupted one."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bioscanclip.hip.optim import FusedAdamW
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+    def build():
+        m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2, **NODROP)), r=4, num_classes=768)
+        sd = synth.synth_state_dict({"dna_encoder." + k: v for k, v in synth.shapes_of(m).items()}, 7)
+        m.load_state_dict({k[len("dna_encoder."):]: v for k, v in sd.items()})
+        return m.cuda().train()
+
+    _, dna, _, _ = synth.synth_batch(8, seed=4)
+    dna = dna.cuda()
+    w = synth.synth_tensor("opt.cot", (8, 768), seed=5).cuda()
+
+    def step(m, opt):
+        opt.zero_grad()
+        (m(dna) * w).sum().backward()
+        if opt.needs_attach():
+            opt.attach(m)
+        opt.step()
+
+    ref = build()
+    o_ref = FusedAdamW(ref.parameters(), lr=1e-3)
+    for _ in range(6):
+        step(ref, o_ref)
+    want = {k: p.detach().clone() for k, p in ref.named_parameters() if p.requires_grad}
+
+    a = build()
+    o_a = FusedAdamW(a.parameters(), lr=1e-3)
+    for _ in range(3):
+        step(a, o_a)
+    sd_opt = o_a.state_dict()
+    assert any("exp_avg" in v for v in sd_opt["state"].values()) and all(int(v["step"]) == 3 for v in sd_opt["state"].values())
+    # (1) engine rebuild mid-run: reload the model's own weights in place -> the engine repacks, the moments must carry over
+    a.load_state_dict({k: v.clone() for k, v in a.state_dict().items()})
+    for _ in range(3):
+        step(a, o_a)
+    for k, v in want.items():
+        assert torch.equal(dict(a.named_parameters())[k], v), k
+    # (2) fresh model + fresh optimizer restored from the two state_dicts taken after step 3
+    b = build()
+    o_b = FusedAdamW(b.parameters(), lr=1e-3)
+    c = build()
+    o_c = FusedAdamW(c.parameters(), lr=1e-3)
+    for _ in range(3):
+        step(c, o_c)
+    b.load_state_dict({k: v.clone() for k, v in c.state_dict().items()})
+    o_b.load_state_dict(o_c.state_dict())
+    for _ in range(3):
+        step(b, o_b)
+    for k, v in want.items():
+        assert torch.equal(dict(b.named_parameters())[k], v), k
