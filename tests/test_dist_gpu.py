@@ -110,8 +110,10 @@ def test_rccl_collectives_at_world_size_one():
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     outs = {}
     for name, e in (("dist", env), ("plain", {k: v for k, v in env.items() if k != "BSCLIP_FORCE_DIST"})):
+        # both legs enqueue eagerly (the captured-graph path reads AdamW's lr / step from device memory, a second, separately
+        # tested form of the same update): the only difference left is the collectives
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--text", "--batch", "16", "--steps", "3", "--warmup", "3",
-                            "--no-cpu-baseline"], env=e, capture_output=True, text=True, timeout=800)
+                            "--no-graph", "--no-cpu-baseline"], env=e, capture_output=True, text=True, timeout=800)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = json.loads(r.stdout.strip().splitlines()[-1])
     # same seeds, same batch, dropout masks keyed on (seed, call count, rank 0): the collectives must not change the numbers

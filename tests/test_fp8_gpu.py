@@ -97,7 +97,7 @@ NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
 # mantissa bits (relative rounding 2^-4), so a GEMM output carries ~4 % noise per operand pair; LoRA, attention, the residual
 # stream, every backward GEMM and the loss stay in bf16 / f32.  The gate is defined against this repo's bf16 path (and
 # reported against the f32 oracle): embeddings by relative L2 error and cosine, gradients by relative L2 error.
-FP8_TOL = {"vit": dict(emb=0.2, cos=0.98, grad=0.6), "dna": dict(emb=0.2, cos=0.98, grad=0.6)}
+FP8_TOL = {"vit": dict(emb=0.3, cos=0.97, grad=0.9), "dna": dict(emb=0.14, cos=0.99, grad=0.5)}
 
 
 def _log(rec):
