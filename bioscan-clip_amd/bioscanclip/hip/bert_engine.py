@@ -2,7 +2,7 @@
 (language_encoder.py:87-89)."""
 import torch
 
-from .engine import BertEngine, run_encoder, wants_fp8
+from .engine import BertEngine, run_encoder, wants_fp8, wants_full_ft
 
 
 def _need_gpu(t, who):
@@ -13,8 +13,12 @@ def _need_gpu(t, who):
 def barcode_bert_forward(module, ids):
     _need_gpu(ids, "LoRA_barcode_bert.forward")
     m = module.lora_barcode_bert
-    build = lambda: BertEngine(m.bert, "mlm_softmax_mean", (m.cls.predictions.transform, m.cls.predictions.decoder),
-                               ids.device, fp8=wants_fp8(module))
+    def build():
+        heads = (m.cls.predictions.transform, m.cls.predictions.decoder)
+        if wants_full_ft(module):
+            from .engine_ft import BertEngineFT
+            return BertEngineFT(m.bert, "mlm_softmax_mean", heads, ids.device)
+        return BertEngine(m.bert, "mlm_softmax_mean", heads, ids.device, fp8=wants_fp8(module))
     # the reference passes input_ids only: token_type 0, no attention mask
     return run_encoder(module, build, (ids.to(torch.int64), None, None))
 
@@ -22,7 +26,11 @@ def barcode_bert_forward(module, ids):
 def bert_text_forward(module, x):
     ids = x["input_ids"]
     _need_gpu(ids, "LoRA_bert.forward")
-    build = lambda: BertEngine(module.lora_bert, "mean_proj", (module.proj,), ids.device)
+    def build():
+        if wants_full_ft(module):
+            from .engine_ft import BertEngineFT
+            return BertEngineFT(module.lora_bert, "mean_proj", (module.proj,), ids.device)
+        return BertEngine(module.lora_bert, "mean_proj", (module.proj,), ids.device)
     tt = x.get("token_type_ids")
     am = x.get("attention_mask")
     return run_encoder(module, build, (ids.to(torch.int64), None if tt is None else tt.to(torch.int64),

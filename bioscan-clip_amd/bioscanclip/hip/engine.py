@@ -112,9 +112,16 @@ class EncoderEngineBase:
             params += [mods[0].weight, mods[1].weight, mods[2].weight, mods[3].weight]
         self._extra_index = len(params)
         params += list(extra_params)
+        self._trunk_index = len(params)
+        params += list(self._trunk_trainables())   # full fine-tuning (hip/engine_ft.py): every trunk tensor, in its order
         ops.init_tables()
         self.flat = FlatParams(params, dev)
         self._zero_a = torch.zeros(8, H, dtype=F32, device=dev)
+
+    full_ft = False
+
+    def _trunk_trainables(self):
+        return []
 
     def lora_a(self, l, grad=False):
         i = self._lora_index[l]
@@ -216,6 +223,9 @@ class ViTEngine(EncoderEngineBase):
         ws["z"] = [z(M, FF, dt=torch.uint8) for _ in range(L)]        # gelu'(fc1 pre-activation), 8-bit codes
         ws["h2"] = z(M, H)
         ws["act"] = z(M, FF)
+        if self.full_ft:  # inputs of fc1 / fc2 per block: operands of their weight-gradient GEMMs
+            ws["h2s"] = [z(M, H) for _ in range(L)]
+            ws["acts"] = [z(M, FF) for _ in range(L)]
         if self.fp8:  # fp8 GEMM operands: LN1 output per block (lora_grad reads it again) + its bf16 t block, LN2 / GELU shared
             ws["h1_8"] = [z(M, H, dt=ops.FP8) for _ in range(L)]
             ws["t"] = [z(M, KPAD) for _ in range(L)]
@@ -284,9 +294,10 @@ class ViTEngine(EncoderEngineBase):
                 ops.gemm_fp8(ws["h2_8"], lay.w_fc1_8, ws["act8"], lay.s_fc1, lay.b_fc1, EPI_GELU_FP8, aux=ws["z"][l])
                 ops.gemm_fp8(ws["act8"], lay.w_fc2_8, x[2 * l + 2], lay.s_fc2, lay.b_fc2, EPI_RESID_F32, resid=x[2 * l + 1])
                 continue
-            ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2"], stats=ws["st2"][l])
-            ops.gemm(ws["h2"], lay.w_fc1, ws["act"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
-            ops.gemm(ws["act"], lay.w_fc2, x[2 * l + 2], EPI_RESID_F32, bias=lay.b_fc2, resid=x[2 * l + 1])
+            h2, act = (ws["h2s"][l], ws["acts"][l]) if self.full_ft else (ws["h2"], ws["act"])   # dW needs them per layer
+            ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=h2, stats=ws["st2"][l])
+            ops.gemm(h2, lay.w_fc1, act, EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
+            ops.gemm(act, lay.w_fc2, x[2 * l + 2], EPI_RESID_F32, bias=lay.b_fc2, resid=x[2 * l + 1])
         x_cls = x[-1].view(B, S * H)[:, :H]  # token 0 of every image (row stride S*H)
         ops.layernorm_fwd(x_cls, self.ln_f[0], self.ln_f[1], 1e-6, y_bf16=ws["clsn"], stats=ws["st_f"])
         out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
@@ -443,6 +454,10 @@ class BertEngine(EncoderEngineBase):
         ws["stb"] = [z(M, 2, dt=F32) for _ in range(L)]
         ws["z"] = [z(M, FF, dt=torch.uint8) for _ in range(L)]       # gelu'(intermediate pre-activation), 8-bit codes
         ws["act"] = z(M, FF)
+        if self.full_ft:
+            ws["ymbs"] = [z(M, H) for _ in range(L)]
+            ws["acts"] = [z(M, FF) for _ in range(L)]
+            ws["st_e"] = z(M, 2, dt=F32)
         if self.fp8:  # fp8 GEMM operands (the last LN output stays bf16: it feeds the head)
             ws["yb8"] = [z(M, H, dt=ops.FP8) for _ in range(L)]
             ws["t"] = [z(M, KPAD) for _ in range(L)]
@@ -528,7 +543,9 @@ class BertEngine(EncoderEngineBase):
                                   lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0))
         else:
             ops.layernorm_fwd(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, y_bf16=ws["yb"][0], y_f32=ws["y"],
-                              lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0))
+                              lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0),
+                              stats=ws["st_e"] if self.full_ft else None)
+        ws["ids"], ws["type_ids"] = input_ids, token_type_ids
         for l, lay in enumerate(self.layers):
             if f8:
                 ops.gemm_fp8(ws["yb8"][l], lay.w_qkv8, ws["qkv"][l], lay.s_qkv, lay.b_qkv, EPI_BF16, a_aug=ws["t"][l],
@@ -546,10 +563,11 @@ class BertEngine(EncoderEngineBase):
                 ops.gemm_fp8(ws["act8"], lay.w_fc2_8, ws["s2"][l], lay.s_fc2, lay.b_fc2, EPI_RESID_F32, resid=ws["ym"],
                              dropout=self._drop(ws, self.p_hidden, l, 3))
             else:
-                ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ws["ymb"], y_f32=ws["ym"],
+                ymb, act = (ws["ymbs"][l], ws["acts"][l]) if self.full_ft else (ws["ymb"], ws["act"])
+                ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ymb, y_f32=ws["ym"],
                                   stats=ws["sta"][l])
-                ops.gemm(ws["ymb"], lay.w_fc1, ws["act"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
-                ops.gemm(ws["act"], lay.w_fc2, ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"],
+                ops.gemm(ymb, lay.w_fc1, act, EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
+                ops.gemm(act, lay.w_fc2, ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"],
                          dropout=self._drop(ws, self.p_hidden, l, 3))
             nxt = self.lora_a(l + 1) if l + 1 < L else self._zero_a
             if f8 and l + 1 < L:
@@ -700,9 +718,14 @@ def set_precision(model, precision):
             m._engine = None
 
 
+def wants_full_ft(module):
+    """``module.hip_full_ft`` (set by load_clip_model for ``disable_lora: true``): every parameter is trained."""
+    return bool(getattr(module, "hip_full_ft", False))
+
+
 def _engine_for(module, build):
     eng = getattr(module, "_engine", None)
-    if eng is not None and eng.fp8 != wants_fp8(module):
+    if eng is not None and (eng.fp8 != wants_fp8(module) or eng.full_ft != wants_full_ft(module)):
         eng = None
     if eng is not None and eng.flat.valid() and _frozen_signature(module, eng) != eng._frozen_sig:
         eng = None  # frozen weights were overwritten (checkpoint loaded after the first forward): repack

@@ -50,7 +50,7 @@ SIGNATURES = {
     "bsclip_lora_baug_set": (I, [P, I, I, P, P, P, P]),
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_fwd_fp8": (I, [P, I, I, I, I, P, P, F, P, I, P, I, P, P, P, F, U, P]),
-    "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, P]),
+    "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, F, U, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, P]),
@@ -85,6 +85,10 @@ SIGNATURES = {
     "bsclip_transpose_bf16": (I, [P, I, I, I, P, I, P]),
     "bsclip_cast_f32_bf16": (I, [P, L, P, P]),
     "bsclip_waug_set_lora": (I, [P, I, I, P, P, P]),
+    "bsclip_ln_param_grad_workspace_floats": (L, [I]),
+    "bsclip_ln_param_grad": (I, [P, I, I, P, I, I, P, I, P, I, P, P, I, F, U, P, P, P, P]),
+    "bsclip_embed_grad": (I, [P, P, I, I, I, I, I, P, P, P, P, P]),
+    "bsclip_gather_cast_rows": (I, [P, I, I, I, I, I, I, P, I, P]),
     "bsclip_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, F, P]),
     "bsclip_adamw_step_dev": (I, [P, P, P, P, L, P, F, F, F, F, F, P]),
     "bsclip_set_dropout_step": (I, [P]),

@@ -199,7 +199,7 @@ def layernorm_fwd_fp8(x, gamma, beta, eps, y_fp8, t_aug=None, y_f32=None, lora_a
 
 
 def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lora_a=None, dx_f32=None, dx_bf16=None,
-                  M=None, dropout=None):
+                  M=None, dropout=None, in_dropout=None):
     ld_x = _rowmajor(x, "x")
     H = gamma.numel()
     M = x.shape[0] if M is None else M
@@ -226,7 +226,9 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
                                          ld_gr, _p(g_gemm), ld_g, _p(dt), _p(lora_a) if dt is not None else None,
                                          int(mode), _p(dx_f32), ld_dx, _p(dx_bf16), ld_dxb,
                                          0.0 if dropout is None else float(dropout[0]),
-                                         0 if dropout is None else int(dropout[1]) & 0xFFFFFFFF, _stream()))
+                                         0 if dropout is None else int(dropout[1]) & 0xFFFFFFFF,
+                                         0.0 if in_dropout is None else float(in_dropout[0]),
+                                         0 if in_dropout is None else int(in_dropout[1]) & 0xFFFFFFFF, _stream()))
 
 
 def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, q_rows=0):
@@ -490,3 +492,56 @@ def augment_images(src, records, B, mid_capacity, mid, out_size, out):
     _req(mid.dtype == F32 and mid.is_cuda and mid.numel() >= 3 * B * mid_capacity, "augment_images: mid f32 [B,3,cap]")
     _req(out.dtype == F32 and out.is_contiguous() and tuple(out.shape) == (B, 3, out_size, out_size), "augment_images: out")
     check(_l.load().bsclip_augment_images(_p(src), _p(records), B, mid_capacity, _p(mid), out_size, _p(out), _stream()))
+
+
+# ------------------------------------------------------------------------------------------- full fine-tuning (8f-4)
+_PG_WS = {}
+
+
+def ln_param_grad(x, stats, mode, d_gamma, d_beta, g_resid=None, g_gemm=None, dt=None, lora_a=None, M=None, in_dropout=None):
+    """d_gamma / d_beta += LayerNorm parameter gradients, dy assembled as layernorm_bwd does."""
+    ld_x = _rowmajor(x, "x")
+    H = d_gamma.numel()
+    M = x.shape[0] if M is None else M
+    _req(x.dtype in (F32, BF16) and x.shape[1] >= H and M <= x.shape[0], "ln_param_grad: bad x")
+    _req(stats.dtype == F32 and stats.numel() >= 2 * M, "ln_param_grad: stats")
+    _req(all(t.dtype == F32 and t.is_contiguous() and t.numel() == H for t in (d_gamma, d_beta)), "ln_param_grad: d_gamma/d_beta")
+    ld_g = ld_gr = 0
+    if g_resid is not None:
+        ld_gr = _rowmajor(g_resid, "g_resid")
+        _req(g_resid.dtype == F32 and g_resid.shape[0] >= M and g_resid.shape[1] >= H, "g_resid f32 [M,>=H]")
+    if g_gemm is not None:
+        ld_g = _rowmajor(g_gemm, "g_gemm")
+        _req(g_gemm.dtype == BF16 and g_gemm.shape[0] >= M and g_gemm.shape[1] >= H, "g_gemm bf16 [M,>=H]")
+    if dt is not None:
+        _req(dt.dtype == F32 and dt.is_contiguous() and dt.numel() >= 8 * M and lora_a is not None
+             and tuple(lora_a.shape) == (8, H) and lora_a.dtype == F32 and lora_a.is_contiguous(), "dt f32 [M,8], lora_a f32 [8,H]")
+    key = (H, str(x.device), torch.cuda.current_stream().cuda_stream)
+    ws = _PG_WS.get(key)
+    if ws is None:
+        ws = _PG_WS[key] = torch.empty(_l.load().bsclip_ln_param_grad_workspace_floats(H), dtype=F32, device=x.device)
+    dp, ds = (0.0, 0) if in_dropout is None else (float(in_dropout[0]), int(in_dropout[1]) & 0xFFFFFFFF)
+    check(_l.load().bsclip_ln_param_grad(_p(x), ld_x, int(x.dtype == BF16), _p(stats), M, H, _p(g_resid), ld_gr, _p(g_gemm), ld_g,
+                                         _p(dt), _p(lora_a) if dt is not None else None, int(mode), dp, ds, _p(d_gamma),
+                                         _p(d_beta), _p(ws), _stream()))
+
+
+def embed_grad(ids, type_ids, d_emb, d_word, d_pos, d_type, pad_id=0):
+    B, S = ids.shape
+    H = d_word.shape[1]
+    _req(ids.dtype == torch.int64 and ids.is_contiguous(), "embed_grad: ids int64 [B,S]")
+    _req(type_ids is None or (type_ids.dtype == torch.int64 and type_ids.is_contiguous() and type_ids.shape == ids.shape), "type_ids")
+    _req(d_emb.dtype == F32 and d_emb.is_contiguous() and d_emb.shape[0] >= B * S and d_emb.shape[1] == H, "d_emb f32 [B*S,H]")
+    _req(all(t.dtype == F32 and t.is_contiguous() and t.shape[1] == H for t in (d_word, d_pos, d_type)) and d_pos.shape[0] >= S
+         and d_type.shape[0] >= 2, "embed_grad: gradient tables f32 [*,H]")
+    check(_l.load().bsclip_embed_grad(_p(ids), _p(type_ids), B, S, H, d_word.shape[0], int(pad_id), _p(d_emb), _p(d_word),
+                                      _p(d_pos), _p(d_type), _stream()))
+
+
+def gather_cast_rows(src, rows_out, period_in, period_out, offset, dst):
+    H = src.shape[1]
+    _req(src.dtype == F32 and dst.dtype == BF16 and dst.shape[0] >= rows_out and dst.shape[1] >= H, "gather_cast_rows dtypes/shapes")
+    n_in = (rows_out + period_out - 1) // period_out * period_in
+    _req(src.shape[0] >= n_in - (period_in - offset - period_out), "gather_cast_rows: src too small")
+    check(_l.load().bsclip_gather_cast_rows(_p(src), _rowmajor(src, "src"), rows_out, period_in, period_out, offset, H, _p(dst),
+                                            _rowmajor(dst, "dst"), _stream()))

@@ -1,7 +1,7 @@
 """Entry used by ``LoRA_ViT_timm.forward`` (reference image_encoder.py:108-109)."""
 import torch
 
-from .engine import ViTEngine, run_encoder, wants_fp8
+from .engine import ViTEngine, run_encoder, wants_fp8, wants_full_ft
 
 
 def vit_forward(module, x):
@@ -9,4 +9,9 @@ def vit_forward(module, x):
         raise RuntimeError("LoRA_ViT_timm.forward: the image batch must live on the GPU "
                            "(bioscanclip has no CPU compute path)")
     x = x.to(torch.float32).contiguous()
-    return run_encoder(module, lambda: ViTEngine(module, x.device, fp8=wants_fp8(module)), (x,))
+    def build():
+        if wants_full_ft(module):   # disable_lora: true -- every parameter trained (hip/engine_ft.py)
+            from .engine_ft import ViTEngineFT
+            return ViTEngineFT(module, x.device)
+        return ViTEngine(module, x.device, fp8=wants_fp8(module))
+    return run_encoder(module, build, (x,))

@@ -130,7 +130,8 @@ class BertConfigLite:
 class _BertEmbeddings(_NoForward):
     def __init__(self, c):
         super().__init__()
-        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size)
+        # HF BertEmbeddings: padding_idx = config.pad_token_id (default 0): that row never receives a gradient
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=0)
         self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
         self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)

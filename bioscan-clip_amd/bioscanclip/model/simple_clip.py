@@ -106,20 +106,22 @@ def load_clip_model(args, device=None):
     disable_lora = False
     if hasattr(mc, 'disable_lora'):
         disable_lora = mc.disable_lora
-    if disable_lora:
-        raise NotImplementedError("disable_lora (full fine-tuning) is not on the HIP-accelerated path yet (SURVEY 8f-4)")
+    # disable_lora: the reference passes lora_layer=[] to every wrapper and unfreezes all parameters afterwards
+    # (simple_clip.py:151-153,165-167,182-184,199-201).  [] means "no LoRA" for the BERT wrappers and -- being falsy -- "LoRA on
+    # every block" for the ViT wrapper; both behaviours are kept.
+    ll = [] if disable_lora else None
     if mc.image.model == "lora_clip_image" and hasattr(mc, 'language') and mc.language.model == "lora_clip_text":
         raise NotImplementedError("the open_clip (ViT-L/14) branch is not part of the HIP-accelerated path")
 
     if mc.image.input_type == "image":
-        image_encoder = LoRA_ViT_timm(vit_model=_load_vit(args), r=4, num_classes=mc.output_dim)
+        image_encoder = LoRA_ViT_timm(vit_model=_load_vit(args), r=4, num_classes=mc.output_dim, lora_layer=ll)
     else:
         raise NotImplementedError("feature-input MLP encoders are outside the accelerated path")
 
     if hasattr(mc, 'language'):
         if mc.language.input_type == "sequence":
             _, pre_trained_bert = load_pre_trained_bert(getattr(args, "bert_small_checkpoint", None))
-            language_encoder = LoRA_bert(model=pre_trained_bert, r=4, num_classes=mc.output_dim)
+            language_encoder = LoRA_bert(model=pre_trained_bert, r=4, num_classes=mc.output_dim, lora_layer=ll)
         else:
             raise TypeError(f"Using {mc.language.input_type} as language input is not support yet.")
 
@@ -135,7 +137,7 @@ def load_clip_model(args, device=None):
                                                 "(set allow_random_init=true for synthetic runs)")
                     ckpt = None
                 pre_trained_barcode_bert = load_pre_trained_bioscan_bert(bioscan_bert_checkpoint=ckpt)
-                dna_encoder = LoRA_barcode_bert(model=pre_trained_barcode_bert, r=4, num_classes=mc.output_dim)
+                dna_encoder = LoRA_barcode_bert(model=pre_trained_barcode_bert, r=4, num_classes=mc.output_dim, lora_layer=ll)
         else:
             raise NotImplementedError("feature-input MLP encoders are outside the accelerated path")
 
@@ -143,4 +145,20 @@ def load_clip_model(args, device=None):
 
     if device is not None:
         model.to(device)
+
+    if disable_lora:
+        enable_full_fine_tuning(model)
+
+    return model
+
+
+def enable_full_fine_tuning(model):
+    """Reference simple_clip.py:199-201: ``for param in model.parameters(): param.requires_grad = True``; the encoders then build
+    their full fine-tuning engines (hip/engine_ft.py) at the next forward."""
+    for param in model.parameters():
+        param.requires_grad = True
+    for enc in (model.image_encoder, model.dna_encoder, model.language_encoder):
+        if enc is not None and not isinstance(enc, Freeze_DNA_Encoder):
+            enc.hip_full_ft = True
+            enc._engine = None
     return model

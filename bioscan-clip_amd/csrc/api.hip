@@ -14,7 +14,7 @@ void bsclip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bsclip_last_error(void) { return g_err; }
-extern "C" int bsclip_abi_version(void) { return 3; }  // 3: bsclip_epi_args.struct_size (leading), bsclip_epi_args_size; diag builds moved out
+extern "C" int bsclip_abi_version(void) { return 4; }  // 4: layernorm_bwd in_dropout, fp8 / pipeline / comm / full-FT entry points, 8-bit gelu side band
 
 // ---- dropout step word ------------------------------------------------------------------------------------------
 static thread_local const unsigned* g_drop_step = nullptr;

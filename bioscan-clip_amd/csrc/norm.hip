@@ -173,8 +173,9 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
                                                                   const float* __restrict__ lora_a, int mode,
                                                                   float* __restrict__ dx_f32, int ld_dx,
                                                                   bf16_t* __restrict__ dx_bf16, int ld_dxb,
-                                                                  DropCfg drop) {
+                                                                  DropCfg drop, DropCfg in_drop) {
     BSCLIP_DROP_RESOLVE(drop);
+    BSCLIP_DROP_RESOLVE(in_drop);
     constexpr int NV = H / 256;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * LN_BLOCK + threadIdx.x) >> 6;
@@ -226,6 +227,10 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
         if (mode == 1) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) dy[j] += res[j];
+        }
+        if (in_drop.thr16) {  // this LN's OUTPUT was dropped in forward (BertEmbeddings): the same mask on its gradient
+#pragma unroll
+            for (int j = 0; j < NV; ++j) dy[j] = drop4(in_drop, (unsigned)row * H + j * 256 + lane * 4, dy[j]);
         }
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -367,12 +372,13 @@ extern "C" int bsclip_layernorm_fwd_fp8(const void* x, int ld_x, int x_bf16, int
 #define LN_BWD_LAUNCH(HH, XB, LO)                                                                                \
     hipLaunchKernelGGL((layernorm_bwd_kernel<HH, XB, LO>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, stats, \
                        gamma, M, g_resid, ld_gr, static_cast<const bf16_t*>(g_gemm), ld_g, dt, lora_a, mode, dx_f32, \
-                       ld_dx, static_cast<bf16_t*>(dx_bf16), ld_dxb, drop)
+                       ld_dx, static_cast<bf16_t*>(dx_bf16), ld_dxb, drop, in_drop)
 
 extern "C" int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M,
                                     int H, const float* g_resid, int ld_gr, const void* g_gemm, int ld_g,
                                     const float* dt, const float* lora_a, int mode, float* dx_f32, int ld_dx,
-                                    void* dx_bf16, int ld_dxb, float dropout_p, uint32_t dropout_seed, void* stream) {
+                                    void* dx_bf16, int ld_dxb, float dropout_p, uint32_t dropout_seed, float in_dropout_p,
+                                    uint32_t in_dropout_seed, void* stream) {
     BSCLIP_REQUIRE(x && stats && gamma && M > 0, "bsclip_layernorm_bwd: null/empty input");
     BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_bwd: H=%d (supported: 768, 512)", H);
     BSCLIP_REQUIRE(g_resid || g_gemm, "bsclip_layernorm_bwd: no incoming gradient");
@@ -384,6 +390,8 @@ extern "C" int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const f
     BSCLIP_REQUIRE(!dx_bf16 || (ld_dxb >= H && ld_dxb % 4 == 0), "bsclip_layernorm_bwd: ld_dxb=%d", ld_dxb);
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_layernorm_bwd: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
+    BSCLIP_REQUIRE(in_dropout_p >= 0.f && in_dropout_p < 1.f, "bsclip_layernorm_bwd: in_dropout_p=%f", in_dropout_p);
+    const DropCfg in_drop = make_drop(in_dropout_p, in_dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool lo = lora_a != nullptr;
     if (H == 768) {

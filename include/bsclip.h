@@ -136,7 +136,9 @@ int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_c
  *   dx_bf16 is the operand of the dX GEMM of a Linear whose FORWARD output was dropped with the same (p, seed), and the
  *   mask of element (row, col) is a pure function of (seed, row*H + col), so it is regenerated, never stored.
  *   writes dx_f32 [M, ld_dx] (nullable) and dx_bf16 [M, ld_dxb] (nullable).  Row strides let the final ViT norm run on
- *   the token-0 rows only (x, g and dx all strided by 197*H).  stats is indexed by the compact row number. */
+ *   the token-0 rows only (x, g and dx all strided by 197*H).  stats is indexed by the compact row number.
+ *   in_dropout_p > 0 (full fine-tuning, BertEmbeddings): the LN's own OUTPUT was dropped in forward with (p, seed); the
+ *   assembled dy is masked the same way before it is differentiated. */
 int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma, const float* beta,
                          float eps, void* y_bf16, int ld_y, float* y_f32, const float* lora_a, float* stats,
                          float dropout_p, uint32_t dropout_seed, void* stream);
@@ -148,7 +150,7 @@ int bsclip_layernorm_fwd_fp8(const void* x, int ld_x, int x_bf16, int M, int H, 
 int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M, int H,
                          const float* g_resid, int ld_gr, const void* g_gemm, int ld_g, const float* dt,
                          const float* lora_a, int mode, float* dx_f32, int ld_dx, void* dx_bf16, int ld_dxb,
-                         float dropout_p, uint32_t dropout_seed, void* stream);
+                         float dropout_p, uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, void* stream);
 
 /* ---- self-attention (timm Attention.forward; HF BertSelfAttention) ---------------------------------------------
  * qkv bf16 [B*S, ld_qkv] with columns [q | k | v], each heads*64 wide; ctx bf16 [B*S, ld_ctx];
@@ -279,6 +281,25 @@ int bsclip_cast_f32_bf16(const float* in, int64_t n, void* out, void* stream);
 /* W_aug[3H, H+KPAD] bf16: cols [H,H+4) of rows [0,H) = B_q, cols [H+4,H+8) of rows [2H,3H) = B_v (refreshed
  * every step from the f32 masters; the frozen [3H,H] block is written once at pack time). */
 int bsclip_waug_set_lora(void* w_aug, int ld_w, int H, const float* lora_bq, const float* lora_bv, void* stream);
+
+/* ---- full fine-tuning only (reference simple_clip.py:199-201 unfreezes every parameter) ----------------
+ * ln_param_grad: d_gamma[c] += sum_r dy[r,c] xhat[r,c], d_beta[c] += sum_r dy[r,c] with dy assembled like
+ *   bsclip_layernorm_bwd does (g_gemm bf16 + dt.lora_a + (mode 1: g_resid)), optionally masked by the dropout the LN's
+ *   OUTPUT was subjected to in forward (BertEmbeddings).  workspace: bsclip_ln_param_grad_workspace_floats(H) floats.
+ * embed_grad: autograd of HF BertEmbeddings' three lookups from d_emb f32 [B*S, H] (gradient at the input of its LayerNorm):
+ *   d_pos[s] += sum_b (ordered), d_word[id] / d_type[tt] += rows (float atomics: rows are selected by data); rows with id == pad_id get none
+ *   (HF: nn.Embedding(padding_idx = config.pad_token_id = 0); pass -1 for "no padding row").
+ * gather_cast_rows: dst bf16 [rows_out, H], dst[r] = src[(r / period_out) * period_in + offset + r % period_out] (f32): e.g. the
+ *   196 patch rows of each image out of the 197-row residual gradient -> operand of the patch-embedding dW GEMM. */
+int64_t bsclip_ln_param_grad_workspace_floats(int H);
+int bsclip_ln_param_grad(const void* x, int ld_x, int x_bf16, const float* stats, int M, int H, const float* g_resid,
+                         int ld_gr, const void* g_gemm, int ld_g, const float* dt, const float* lora_a, int mode,
+                         float in_dropout_p, uint32_t in_dropout_seed, float* d_gamma, float* d_beta, float* workspace,
+                         void* stream);
+int bsclip_embed_grad(const int64_t* ids, const int64_t* type_ids, int B, int S, int H, int vocab, int pad_id,
+                      const float* d_emb, float* d_word, float* d_pos, float* d_type, void* stream);
+int bsclip_gather_cast_rows(const float* src, int ld_src, int rows_out, int period_in, int period_out, int offset, int H,
+                            void* dst_bf16, int ld_dst, void* stream);
 
 /* ---- optimiser: torch.optim.AdamW defaults (scripts/train_cl.py:158), one launch over a flat f32 buffer ---------- */
 int bsclip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -222,6 +222,42 @@ def gen_retrieval():
             "label_batch": batch, "label_list": convert_label_dict_to_list_of_dict(batch)}
 
 
+def gen_fullft():
+    """Full fine-tuning (disable_lora: true, simple_clip.py:151-201): the reference wrappers built with lora_layer=[] -- no LoRA
+    in the BERT encoders, LoRA on every block of the ViT (an empty list is falsy in image_encoder.py:56-59) -- and EVERY
+    parameter unfrozen; gradients of all of them, two layers each."""
+    out = {}
+    def unfreeze(m):
+        for p in m.parameters():
+            p.requires_grad = True
+        return m
+    def grads(m, pref):
+        return {pref + k: summary(pref + k, p.grad) for k, p in m.named_parameters() if p.grad is not None}
+    cfg = BertConfig(vocab_size=1027, output_hidden_states=True, num_hidden_layers=2, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0)
+    m = unfreeze(LoRA_barcode_bert(BertForMaskedLM(cfg), r=4, num_classes=768, lora_layer=[]))
+    load_synth(m, seed=11, prefix="dna_encoder.")
+    _, dna, _, _ = synth.synth_batch(2, seed=21)
+    y = m.train()(dna)
+    (y * synth.synth_tensor("dna.cot.ft", y.shape, seed=5)).sum().backward()
+    out["dna"] = {"out": summary("dna.out.ft", y), "grads": grads(m, "dna_encoder.")}
+    cfg = BertConfig(vocab_size=30522, hidden_size=512, num_hidden_layers=2, num_attention_heads=8, intermediate_size=2048,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = unfreeze(LoRA_bert(BertModel(cfg), r=4, num_classes=768, lora_layer=[]))
+    load_synth(m, seed=12, prefix="language_encoder.")
+    _, _, text, _ = synth.synth_batch(4, seed=22, with_text=True)
+    y = m.train()(text)
+    (y * synth.synth_tensor("txt.cot.ft", y.shape, seed=5)).sum().backward()
+    out["txt"] = {"out": summary("txt.out.ft", y), "grads": grads(m, "language_encoder.")}
+    m = unfreeze(LoRA_ViT_timm(VisionTransformer(depth=2), r=4, num_classes=768, lora_layer=[]))
+    load_synth(m, seed=13, prefix="image_encoder.")
+    image, _, _, _ = synth.synth_batch(2, seed=23)
+    y = m.train()(image)
+    (y * synth.synth_tensor("vit.cot.ft", y.shape, seed=5)).sum().backward()
+    out["vit"] = {"out": summary("vit.out.ft", y), "grads": grads(m, "image_encoder.")}
+    return out
+
+
 def gen_pipeline():
     """PadSequence / KmerTokenizer of the reference (bioscanclip/util/util.py:48-69) on seeded strings: the pad + k-mer half
     of get_sequence_pipeline.  (Its vocab is torchtext's, absent here: the id map stays restated, see oracle/pipeline.py.)"""
@@ -245,7 +281,7 @@ def main():
     meta = {"torch": torch.__version__, "transformers": transformers.__version__,
             "reference": "bioscan-ml/bioscan-clip @ 2024-10-24 (/root/reference)"}
     jobs = {"loss": gen_loss, "encoders": gen_encoders, "state_dict_keys": gen_state_dict_keys,
-            "trajectory_id": gen_trajectory, "retrieval": gen_retrieval, "pipeline": gen_pipeline,
+            "trajectory_id": gen_trajectory, "retrieval": gen_retrieval, "pipeline": gen_pipeline, "fullft": gen_fullft,
             "trajectory_idt": lambda: gen_trajectory(steps=6, B=4, with_text=True, seed=32)}
     only = sys.argv[1:]
     for name, fn in jobs.items():

@@ -142,7 +142,9 @@ def bert_encoder(sd, prefix, input_ids, token_type_ids=None, attention_mask=None
         token_type_ids = torch.zeros_like(input_ids)
     pos = torch.arange(S)
     e = "embeddings."
-    h = sd[prefix + e + "word_embeddings.weight"][input_ids] \
+    # HF BertEmbeddings: nn.Embedding(vocab, hidden, padding_idx=config.pad_token_id = 0) -- row 0 receives no gradient
+    # (matters for full fine-tuning only: every barcode starts with id 0, get_sequence_pipeline's literal <MASK>)
+    h = torch.nn.functional.embedding(input_ids, sd[prefix + e + "word_embeddings.weight"], padding_idx=0) \
         + sd[prefix + e + "token_type_embeddings.weight"][token_type_ids] \
         + sd[prefix + e + "position_embeddings.weight"][pos][None]
     h = layer_norm(h, sd[prefix + e + "LayerNorm.weight"], sd[prefix + e + "LayerNorm.bias"], eps)

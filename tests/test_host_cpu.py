@@ -96,9 +96,16 @@ def test_load_clip_model_config_keys():
     cfg = load_config(os.path.join(PKG, "bioscanclip", "config"), ["model_config=lora_vit_lora_barcode_bert_lora_bert_ssl"])
     model = load_clip_model(cfg)
     assert model.image_encoder is not None and model.dna_encoder is not None and model.language_encoder is not None
+    n_lora_regime = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert n_lora_regime == 1_902_848                                   # I+D+T trainable count
+    # disable_lora: true (full fine-tuning, reference simple_clip.py:151-201): lora_layer=[] everywhere -- no LoRA in the BERT
+    # encoders, LoRA on every ViT block ([] is falsy in image_encoder.py:56-59) -- and every parameter unfrozen
     cfg.model_config.disable_lora = True
-    with pytest.raises(NotImplementedError):
-        load_clip_model(cfg)
+    ft = load_clip_model(cfg)
+    assert all(p.requires_grad for p in ft.parameters())
+    assert len(ft.dna_encoder.w_As) == 0 and len(ft.language_encoder.w_As) == 0 and len(ft.image_encoder.w_As) == 24
+    assert all(getattr(e, "hip_full_ft", False) for e in (ft.image_encoder, ft.dna_encoder, ft.language_encoder))
+    assert sum(p.numel() for p in ft.parameters()) > 200_000_000
 
 
 def test_flat_params_alias_parameters_and_grads():

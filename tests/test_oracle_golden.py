@@ -168,3 +168,47 @@ def test_augment_oracle_properties():
     assert torch.equal(fl, base.flip(-1).flip(-2))
     r180 = P.augment(im, {"box": (0, 0, h1, w1), "hflip": False, "vflip": False, "angle": 180.0})
     assert torch.allclose(r180, base.flip(-1).flip(-2))
+
+
+def _all_grads(sd, fn, cot):
+    """Oracle gradients with respect to EVERY floating-point tensor of the state dict (full fine-tuning)."""
+    import torch
+    sd = {k: v.clone() for k, v in sd.items()}
+    keys = [k for k in sd if sd[k].is_floating_point()]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    y = fn(sd)
+    (y * cot).sum().backward()
+    return y, {k: sd[k].grad for k in keys if sd[k].grad is not None}
+
+
+def test_full_finetune_oracle_vs_reference():
+    """gradients of every parameter (no LoRA in the BERTs, LoRA on all ViT blocks, everything unfrozen) against the
+    reference wrappers built with lora_layer=[] (oracle/gen_golden.py:gen_fullft)."""
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from bioscanclip.model.language_encoder import LoRA_bert
+    g = load_golden("fullft")
+    nd = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cases = [("dna", LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2, **nd)), r=4,
+                                       num_classes=768, lora_layer=[]), "dna_encoder.", 11,
+              lambda sd: refcpu.barcode_bert_encoder(sd, synth.synth_batch(2, seed=21)[1])),
+             ("txt", LoRA_bert(arch.BertModelParams(arch.bert_small_config(num_hidden_layers=2, **nd)), r=4, num_classes=768,
+                               lora_layer=[]), "language_encoder.", 12,
+              lambda sd: refcpu.bert_text_encoder(sd, synth.synth_batch(4, seed=22, with_text=True)[2])),
+             ("vit", LoRA_ViT_timm(arch.VisionTransformerParams(depth=2), r=4, num_classes=768, lora_layer=[]), "image_encoder.", 13,
+              lambda sd: refcpu.vit_encoder(sd, synth.synth_batch(2, seed=23)[0]))]
+    for name, m, pre, seed, fn in cases:
+        sd = synth.synth_state_dict({pre + k: v for k, v in synth.shapes_of(m).items()}, seed=seed)
+        y0 = fn({k: v for k, v in sd.items()})
+        y, grads = _all_grads(sd, fn, synth.synth_tensor(f"{name}.cot.ft", y0.shape, seed=5))
+        check_summary(f"{name}.out.ft", y, g[name]["out"], 2e-5)
+        assert set(g[name]["grads"]) <= set(grads), sorted(set(g[name]["grads"]) - set(grads))[:5]
+        for k, gs in g[name]["grads"].items():
+            if k.endswith("attention.self.key.bias"):
+                # exactly zero in exact arithmetic (a key bias shifts every score of a query by the same amount, softmax does
+                # not see it): both sides hold rounding noise of 1e-10, there is nothing to compare
+                assert gs["norm"] < 1e-7 and grads[k].norm().item() < 1e-7
+                continue
+            check_summary(k, grads[k], gs, 1e-4, what=name + " ")
