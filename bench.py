@@ -42,13 +42,15 @@ class _Cfg:
         self.__dict__.update(kw)
 
 
-def build_model(with_text, device, seed=1234):
+def build_model(with_text, device, seed=1234, full_ft=False):
     from bioscanclip.model.simple_clip import load_clip_model
     torch.manual_seed(seed)
     mc = _Cfg(image=_Cfg(input_type="image", model="lora_vit"),
               dna=_Cfg(input_type="sequence", model="lora_barcode_bert"), output_dim=768)
     if with_text:
         mc.language = _Cfg(input_type="sequence", model="lora_bert")
+    if full_ft:
+        mc.disable_lora = True   # reference config/model_config/full_fine_tuning/**: every parameter trained
     args = _Cfg(model_config=mc, bioscan_bert_checkpoint=None, allow_random_init=True)
     model = load_clip_model(args, device=None)
     # LoRA-B is zero-initialised in the reference (image_encoder.py:102-106), which would make the LoRA branch a
@@ -209,6 +211,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="local (per-GPU) batch")
     ap.add_argument("--text", action="store_true", help="add the BERT-small text tower (BASELINE configs[2])")
     ap.add_argument("--fp8", action="store_true", help="fp8 e4m3 frozen-trunk GEMMs for ViT + BarcodeBERT (BASELINE configs[4])")
+    ap.add_argument("--full-ft", action="store_true", help="disable_lora: true -- train every parameter (SURVEY 8f-4; not a BASELINE config)")
+    ap.add_argument("--lr", type=float, default=None, help="AdamW lr (default 1e-3; 5e-5 with --full-ft, the reference's one-cycle max_lr)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -238,7 +242,7 @@ def main():
     from bioscanclip.hip.optim import FusedAdamW
     from bioscanclip.model.loss_func import ContrastiveLoss, GlobalBatchContrastiveLoss
 
-    model = build_model(a.text, device)
+    model = build_model(a.text, device, full_ft=a.full_ft)
     if a.fp8:
         from bioscanclip.hip.engine import set_precision
         set_precision(model, "fp8")
@@ -250,7 +254,7 @@ def main():
     image, dna, text = synthetic_batch(B, a.text, device, seed=1234 + rank)
     label = (torch.arange(B) + rank * B).to(device)
     crit = (GlobalBatchContrastiveLoss if world > 1 or force_dist else ContrastiveLoss)(torch.nn.CrossEntropyLoss(), 1 / 0.07)
-    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    opt = FusedAdamW(model.parameters(), lr=a.lr if a.lr is not None else (5e-5 if a.full_ft else 1e-3))
 
     # One process, one GPU: the whole step is captured once into a hipGraph and replayed (bioscanclip/hip/graph.py) -- the
     # host does three calls per step instead of ~1 500.  With a process group the step stays eager: the collectives are issued
@@ -310,6 +314,10 @@ def main():
         nmod = 3 if a.text else 2
         pairs = nmod * (nmod - 1) // 2
         per = GFLOP_PER_TRIPLE_IDT if a.text else GFLOP_PER_PAIR_ID
+        skipped = VIT_LAST_BLOCK_SKIPPED_GFLOP
+        if a.full_ft:   # fwd + dX + dW of every linear = 3 x F_fwd (58.79 G I+D, + 0.51 G text)
+            per = 3 * (58.79 + (0.51 if a.text else 0.0))
+            skipped += 196 * 768 * (768 + 2 * 3072) * 2 / 1e9      # the token-1..196 rows' dW of the last block's proj / MLP
         loss_gflop = pairs * 3 * 2.0 * N * N * 768 / 1e9  # fwd + 2x bwd on the distinct matrices
         step_tflop_per_gpu = (per * B + loss_gflop) / 1e3
         achieved = step_tflop_per_gpu / (ms * 1e-3)
@@ -318,9 +326,10 @@ def main():
             "value": round(N / (ms * 1e-3), 1), "unit": "paired samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": "configs[%d]: Image+DNA%s (LoRA ViT-B/16 + LoRA BarcodeBERT%s), local batch %d, "
+            "config": {"workload": "%s: Image+DNA%s (LoRA ViT-B/16 + LoRA BarcodeBERT%s), local batch %d, "
                                    "224x224 images + 133-token barcodes, %s InfoNCE, fused AdamW"
-                                   % (4 if a.fp8 else 2 if a.text else 1, "+Text" if a.text else "",
+                                   % ("full fine-tuning (disable_lora: true, every parameter trained; not a BASELINE config)"
+                                      if a.full_ft else "configs[%d]" % (4 if a.fp8 else 2 if a.text else 1), "+Text" if a.text else "",
                                       (" + BERT-small" if a.text else "") + (", fp8 e4m3 QKV/fc1/fc2 forward GEMMs with bf16 LoRA, "
                                                                              "attention, backward and loss" if a.fp8 else ""), B,
                                       "RCCL all-gather global-batch" if world > 1 else "local-batch"),
@@ -334,8 +343,8 @@ def main():
                               "algorithmic_tflop_per_gpu_step": round(step_tflop_per_gpu, 3),
                               # the reference's work (SURVEY 8d model).  The build skips what cannot reach the result: the last
                               # ViT block's proj / MLP / attention rows other than token 0, forward and backward
-                              "executed_tflop_per_gpu_step": round(step_tflop_per_gpu - VIT_LAST_BLOCK_SKIPPED_GFLOP * B / 1e3, 3),
-                              "executed_frac": round((step_tflop_per_gpu - VIT_LAST_BLOCK_SKIPPED_GFLOP * B / 1e3)
+                              "executed_tflop_per_gpu_step": round(step_tflop_per_gpu - skipped * B / 1e3, 3),
+                              "executed_frac": round((step_tflop_per_gpu - skipped * B / 1e3)
                                                      / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4)},
         }
         out["roofline"] = time_dominant_gemm(B, device)

@@ -96,8 +96,8 @@ def _load_vit(args):
 
 def load_clip_model(args, device=None):
     """Reference simple_clip.py:125-203, same config keys (``args.model_config.{image,dna,language,output_dim,
-    disable_lora}``, ``args.bioscan_bert_checkpoint``).  MLP / open_clip / full-fine-tuning variants are outside the
-    accelerated path and raise instead of silently running something else."""
+    disable_lora}``, ``args.bioscan_bert_checkpoint``).  ``disable_lora: true`` selects full fine-tuning (hip/engine_ft.py).
+    MLP / open_clip variants are outside the accelerated path and raise instead of silently running something else."""
     image_encoder = None
     dna_encoder = None
     language_encoder = None

