@@ -23,6 +23,7 @@ from .lib import EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_RESID_F32, KPAD
 
 class _FTMixin:
     full_ft = True
+    _partial = None
 
     # ------------------------------------------------------------------------------------------------ flat-buffer access
     def tp(self, name, shape=None, n=None, grad=False):
@@ -61,16 +62,33 @@ class _FTMixin:
             b = self._tbufs[key] = torch.zeros(rows, Mp, dtype=BF16, device=self.device)   # columns >= M stay zero
         return b
 
+    @staticmethod
+    def _split_plan(M, N, K):
+        """(splits, padded reduction length) for dW[N, K] reduced over M tokens: as many K ranges as bring the launch to about
+        two rounds of the 256 CUs, each at least four 64-wide K-tiles long."""
+        tiles = -(-N // 256) * (K // 256)
+        if K % 256 or tiles >= 192 or M < 512:
+            return 1, _pad64(M)
+        S = max(1, min(512 // tiles, M // 256))
+        unit = 64 * S
+        return S, -(-M // unit) * unit
+
     def _dw(self, dY, X, M, N, K, wname, bname, w_n=None):
         """grad(W[N,K]) += dY[:M,:N]^T X[:M,:K];  grad(b[N]) += column sums of dY."""
-        Mp = _pad64(M)
+        S, Mp = self._split_plan(M, N, K)
         tA, tB = self._tbuf("A", N, Mp), self._tbuf("B", K, Mp)
-        ops.transpose_bf16(dY, M, N, tA)
+        if bname is not None:   # the bias gradient falls out of the transpose's tiles
+            ops.transpose_colsum_bf16(dY, M, N, tA, self.tp(bname, n=N if w_n is not None else None, grad=True))
+        else:
+            ops.transpose_bf16(dY, M, N, tA)
         ops.transpose_bf16(X, M, K, tB)
         gW = self.tp(wname, (N, K), n=w_n, grad=True)
-        ops.gemm(tA, tB, gW, EPI_RESID_F32, resid=gW, K=Mp)
-        if bname is not None:
-            ops.colsum(dY, M, N, self.tp(bname, n=N if w_n is not None else None, grad=True))
+        if S > 1:
+            if self._partial is None:
+                self._partial = torch.empty(512 * 65536, dtype=F32, device=self.device)   # splits * tiles <= 512 slabs of 256 x 256
+            ops.gemm_splitk_f32(tA, tB, gW, S, self._partial, K=Mp)
+        else:
+            ops.gemm(tA, tB, gW, EPI_RESID_F32, resid=gW, K=Mp)
 
 
 # ============================================================================================================== ViT

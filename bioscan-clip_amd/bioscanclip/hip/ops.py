@@ -439,6 +439,24 @@ def transpose_bf16(src, R, C, dst):
     check(_l.load().bsclip_transpose_bf16(_p(src), _rowmajor(src, "src"), R, C, _p(dst), _rowmajor(dst, "dst"), _stream()))
 
 
+_TC_WS = {}
+
+
+def transpose_colsum_bf16(src, R, C, dst, colsum_out):
+    """dst[C, R] = src[R, C]^T and colsum_out[c] += sum_r src[r, c] in one pass over src (weight-gradient operand + bias gradient)."""
+    _req(src.dtype == BF16 and dst.dtype == BF16, "transpose_colsum_bf16 dtypes")
+    _req(src.shape[0] >= R and src.shape[1] >= C and dst.shape[0] >= C and dst.shape[1] >= R, "transpose_colsum_bf16 shapes")
+    _req(colsum_out.dtype == F32 and colsum_out.is_contiguous() and colsum_out.numel() >= C, "transpose_colsum_bf16: colsum f32 [C]")
+    lib = _l.load()
+    need = lib.bsclip_transpose_colsum_workspace_floats(R, C)
+    key = (str(src.device), torch.cuda.current_stream().cuda_stream)
+    ws = _TC_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _TC_WS[key] = torch.empty(need, dtype=F32, device=src.device)
+    check(lib.bsclip_transpose_colsum_bf16(_p(src), _rowmajor(src, "src"), R, C, _p(dst), _rowmajor(dst, "dst"), _p(colsum_out),
+                                           _p(ws), _stream()))
+
+
 def cast_f32_bf16(src, dst):
     _req(src.dtype == F32 and dst.dtype == BF16 and src.is_contiguous() and dst.is_contiguous()
          and dst.numel() >= src.numel(), "cast_f32_bf16")
@@ -536,6 +554,18 @@ def embed_grad(ids, type_ids, d_emb, d_word, d_pos, d_type, pad_id=0):
          and d_type.shape[0] >= 2, "embed_grad: gradient tables f32 [*,H]")
     check(_l.load().bsclip_embed_grad(_p(ids), _p(type_ids), B, S, H, d_word.shape[0], int(pad_id), _p(d_emb), _p(d_word),
                                       _p(d_pos), _p(d_type), _stream()))
+
+
+def gemm_splitk_f32(a, b, c, splits, partial, K=None):
+    """c[M, N] (f32) += a[M, K] . b[N, K]^T, reduction cut into ``splits`` K ranges (weight gradients of full fine-tuning)."""
+    M, N = c.shape
+    K = a.shape[1] if K is None else K
+    lda, ldb, ldc = _rowmajor(a, "a"), _rowmajor(b, "b"), _rowmajor(c, "c")
+    _req(a.dtype == BF16 and b.dtype == BF16 and c.dtype == F32 and partial.dtype == F32 and partial.is_contiguous(), "gemm_splitk_f32 dtypes")
+    _req(a.shape[0] >= M and b.shape[0] >= N and a.shape[1] >= K and b.shape[1] >= K, "gemm_splitk_f32: operand shapes")
+    _req(N % 256 == 0 and splits >= 1 and K % (64 * splits) == 0, "gemm_splitk_f32: N % 256 == 0, K % (64 * splits) == 0")
+    _req(partial.numel() >= splits * M * N, "gemm_splitk_f32: partial needs splits * M * N floats")
+    check(_l.load().bsclip_gemm_splitk_f32(_p(a), lda, _p(b), ldb, _p(c), ldc, M, N, K, int(splits), _p(partial), _stream()))
 
 
 def gather_cast_rows(src, rows_out, period_in, period_out, offset, dst):

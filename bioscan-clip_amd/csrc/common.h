@@ -189,6 +189,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// fullft.hip, internal: out0 / out1 [c] += sum_b partial[b][c] in a fixed order (columns < split go to out0, the rest to out1)
+void bsclip_launch_slab_reduce_add(const float* partial, int nblocks, int n, float* out0, float* out1, int split, hipStream_t s);
+
 // gemm.hip, internal: the fused InfoNCE products on the 256x256 ping-pong GEMM (see the EPI_LSE_PART / EPI_LOSS_W epilogues)
 int bsclip_gemm_infonce(int mode, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                         const int64_t* labels, const float* cnt, const float* lse_row, const float* lse_col, float* part,

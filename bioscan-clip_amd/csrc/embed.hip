@@ -79,6 +79,66 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     }
 }
 
+// The same transpose for 16-byte-aligned operands (ld % 8 == 0): every thread moves two 16-byte chunks in and two out, the
+// 64 x 64 tile sits in LDS with a 33-dword row stride (the 8 source rows a thread gathers for one output chunk land in 8
+// different banks).  COLSUM: the workgroup also emits the column sums of its 64 source rows, partial[blockIdx.y][c] (f32,
+// summed in row order) -- with dY as the source that is the bias gradient's slab, for free while the tile is in registers.
+template <bool COLSUM>
+__global__ __launch_bounds__(256) void transpose64_kernel(const bf16_t* __restrict__ in, int ld_in, int R, int C,
+                                                          bf16_t* __restrict__ out, int ld_out, float* __restrict__ partial) {
+    __shared__ unsigned tile[64][33];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int chunk = threadIdx.x + 256 * k, row = chunk >> 3, cc = chunk & 7;
+        const int r = r0 + row, c = c0 + cc * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r < R) {
+            if (c + 8 <= C) {
+                v = *reinterpret_cast<const u32x4*>(in + (size_t)r * ld_in + c);
+            } else {
+                for (int j = 0; j < 8; ++j)
+                    if (c + j < C) v[j >> 1] |= (unsigned)(*reinterpret_cast<const unsigned short*>(in + (size_t)r * ld_in + c + j)) << (16 * (j & 1));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[row][cc * 4 + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int chunk = threadIdx.x + 256 * k, orow = chunk >> 3, oc = chunk & 7;   // output row = source column c0 + orow
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned w = tile[oc * 8 + j][orow >> 1];
+            e[j] = (unsigned short)((orow & 1) ? (w >> 16) : (w & 0xffff));
+        }
+        const int c = c0 + orow, r = r0 + oc * 8;
+        if (c < C) {
+            if (r + 8 <= R) {
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (unsigned)e[2 * j] | ((unsigned)e[2 * j + 1] << 16);
+                *reinterpret_cast<u32x4*>(out + (size_t)c * ld_out + r) = o;
+            } else {
+                for (int j = 0; j < 8; ++j)
+                    if (r + j < R) *reinterpret_cast<unsigned short*>(out + (size_t)c * ld_out + r + j) = e[j];
+            }
+        }
+        if constexpr (COLSUM) {
+            float sum = 0.f;   // rows >= R were loaded as zeros
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += bf2f(e[j]);
+            // the 8 lanes oc = 0 .. 7 of one output row are consecutive: ordered sum of their 8-row pieces
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tot += __shfl(sum, (threadIdx.x & 56) + q, 64);
+            if (oc == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = tot;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, long n,
                                                              bf16_t* __restrict__ out) {
     const long n4 = n >> 2;
@@ -157,11 +217,35 @@ extern "C" int bsclip_bert_embed(const int64_t* ids, const int64_t* type_ids, in
     return BSCLIP_OK;
 }
 
+static bool transpose_aligned(const void* in, int ld_in, const void* out, int ld_out) {
+    return ld_in % 8 == 0 && ld_out % 8 == 0 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
+}
+
 extern "C" int bsclip_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream) {
     BSCLIP_REQUIRE(in && out && R > 0 && C > 0 && ld_in >= C && ld_out >= R, "bsclip_transpose_bf16: bad args");
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(C, 64), ceil_div(R, 64)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(in), ld_in, R, C,
-                       static_cast<bf16_t*>(out), ld_out);
+    const dim3 grid(ceil_div(C, 64), ceil_div(R, 64));
+    if (transpose_aligned(in, ld_in, out, ld_out))
+        hipLaunchKernelGGL((transpose64_kernel<false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const bf16_t*>(in), ld_in, R, C, static_cast<bf16_t*>(out), ld_out, nullptr);
+    else
+        hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const bf16_t*>(in), ld_in, R, C, static_cast<bf16_t*>(out), ld_out);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int64_t bsclip_transpose_colsum_workspace_floats(int R, int C) { return (int64_t)ceil_div(R, 64) * C; }
+
+extern "C" int bsclip_transpose_colsum_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum,
+                                            float* workspace, void* stream) {
+    BSCLIP_REQUIRE(in && out && colsum && workspace && R > 0 && C > 0 && ld_in >= C && ld_out >= R,
+                   "bsclip_transpose_colsum_bf16: bad args");
+    BSCLIP_REQUIRE(transpose_aligned(in, ld_in, out, ld_out), "bsclip_transpose_colsum_bf16: operands must be 16-byte aligned, ld %% 8 == 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int slabs = ceil_div(R, 64);
+    hipLaunchKernelGGL((transpose64_kernel<true>), dim3(ceil_div(C, 64), slabs), dim3(256), 0, s, static_cast<const bf16_t*>(in),
+                       ld_in, R, C, static_cast<bf16_t*>(out), ld_out, workspace);
+    bsclip_launch_slab_reduce_add(workspace, slabs, C, colsum, colsum, C, s);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

@@ -60,6 +60,9 @@ struct EpiArgs {
     float* part;                          // EPI_LSE_PART out: [M, tiles_n, 4] = (row max, sum exp, sum_j T_ij x_ij, -)
     float logit_scale, coef;              // x = logit_scale * cosine;  w = coef * (...)
     int n_valid, row_base;                // columns >= n_valid are padding; global row of local row 0
+    // split-K (bsclip_gemm_splitk_f32; EPI_F32 without bias only): workgroups with blockIdx.y = z reduce K columns
+    // [z K, (z + 1) K) of the operands into their own f32 slab C + z * split_stride
+    long split_stride;
 };
 constexpr int EPI_LSE_PART = 100;  // internal epilogues, not part of the public enum
 constexpr int EPI_LOSS_W = 101;
@@ -313,6 +316,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                                                           const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                           int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
     static_assert(OP == 0 || (SCHED == 0 && ABL == 0), "fp8 operands: production schedule only");
+    if constexpr (EPI == BSCLIP_EPI_F32 && !HAS_BIAS && OP == 0) {   // split-K slabs (gridDim.y == 1: no-op)
+        A += (size_t)blockIdx.y * K;
+        B += (size_t)blockIdx.y * K;
+        C = static_cast<float*>(C) + (size_t)blockIdx.y * e.split_stride;
+    }
     if constexpr (EPI == BSCLIP_EPI_RESID_F32) BSCLIP_DROP_RESOLVE(e.drop);
     constexpr int ESZ = OP == 0 ? 2 : 1;   // bytes per element of the main operands
     constexpr int SET = 65536, HALF = 16384, B_OFF = 32768;
@@ -1266,6 +1274,46 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
             break;
         default: BSCLIP_REQUIRE(false, "bsclip_gemm_bf16: unknown epilogue %d", epilogue);
     }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// split-K product with f32 accumulation into C: the weight-gradient GEMMs of full fine-tuning
+// ---------------------------------------------------------------------------------------------------------------
+// dW[N_out, K_in] = dY^T X has a small output (9 .. 36 tiles of 256 x 256) and a reduction over all tokens (50 432 for the ViT
+// at batch 256): one workgroup per output tile would use 4 .. 14 % of the chip.  The reduction is cut into `splits` equal
+// column ranges, every (tile, range) pair is one workgroup of the ping-pong kernel writing an f32 slab, and the slabs are
+// summed in the fixed order z = 0 .. splits - 1 and added to C (no atomics: the result does not depend on the schedule).
+__global__ __launch_bounds__(256) void splitk_reduce_add_kernel(const float* __restrict__ partial, int splits, int M, int N,
+                                                                float* __restrict__ C, int ldc) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t total = (size_t)M * N;
+    if (i >= total) return;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(partial + i);
+    for (int z = 1; z < splits; ++z) acc += *reinterpret_cast<const f32x4*>(partial + (size_t)z * total + i);
+    const size_t m = i / N, n = i - m * N;
+    f32x4* dst = reinterpret_cast<f32x4*>(C + m * ldc + n);
+    *dst = *dst + acc;
+}
+
+extern "C" int bsclip_gemm_splitk_f32(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                      int splits, float* partial, void* stream) {
+    BSCLIP_REQUIRE(A && B && C && partial, "bsclip_gemm_splitk_f32: null operand");
+    BSCLIP_REQUIRE(M > 0 && N > 0 && N % 256 == 0 && splits >= 1 && K > 0 && K % (64 * splits) == 0,
+                   "bsclip_gemm_splitk_f32: M=%d N=%d (multiple of 256) K=%d (multiple of 64 * splits=%d)", M, N, K, splits);
+    BSCLIP_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && ldc >= N && ldc % 4 == 0,
+                   "bsclip_gemm_splitk_f32: lda=%d ldb=%d ldc=%d", lda, ldb, ldc);
+    BSCLIP_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)partial) & 15) == 0, "bsclip_gemm_splitk_f32: 16-B alignment");
+    EpiArgs e{};
+    e.n_total = N;
+    e.drop = make_drop(0.f, 0);
+    e.split_stride = (long)M * N;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<BSCLIP_EPI_F32, false>), dim3(tiles_m * tiles_n, splits), dim3(512), 0, s,
+                       static_cast<const bf16_t*>(A), lda, static_cast<const bf16_t*>(B), ldb, partial, N, M, N, K / splits, tiles_n, e);
+    hipLaunchKernelGGL(splitk_reduce_add_kernel, dim3(ceil_div((int)((long)M * N / 4), 256)), dim3(256), 0, s, partial, splits, M, N, C, ldc);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

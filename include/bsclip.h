@@ -277,6 +277,12 @@ int bsclip_lora_grad_fp8(const void* dqkv, int ld_dqkv, const void* y_fp8, int l
                          void* stream);
 int bsclip_colsum(const void* g, int ld_g, int g_is_bf16, int M, int N, float* out, void* stream);
 int bsclip_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
+/* the same transpose, and colsum[c] += sum_r in[r, c] from the tiles while they are in registers (ordered sums): with in = dY
+ * this is the operand of the weight-gradient GEMM and the bias gradient of a Linear in one pass over dY (full fine-tuning,
+ * simple_clip.py:199-201).  workspace: bsclip_transpose_colsum_workspace_floats(R, C) floats; 16-byte aligned operands, ld % 8 == 0. */
+int64_t bsclip_transpose_colsum_workspace_floats(int R, int C);
+int bsclip_transpose_colsum_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum,
+                                 float* workspace, void* stream);
 int bsclip_cast_f32_bf16(const float* in, int64_t n, void* out, void* stream);
 /* W_aug[3H, H+KPAD] bf16: cols [H,H+4) of rows [0,H) = B_q, cols [H+4,H+8) of rows [2H,3H) = B_v (refreshed
  * every step from the f32 masters; the frozen [3H,H] block is written once at pack time). */
@@ -300,6 +306,12 @@ int bsclip_embed_grad(const int64_t* ids, const int64_t* type_ids, int B, int S,
                       const float* d_emb, float* d_word, float* d_pos, float* d_type, void* stream);
 int bsclip_gather_cast_rows(const float* src, int ld_src, int rows_out, int period_in, int period_out, int offset, int H,
                             void* dst_bf16, int ld_dst, void* stream);
+/* C[M, N] (f32) += A[M, K] . B[N, K]^T with the reduction cut into `splits` equal K ranges that run as separate workgroups
+ * (the weight gradient dW = dY^T X of a Linear, simple_clip.py:199-201: a 768 x 3072 output reduced over 50 432 tokens would
+ * otherwise occupy 36 of 256 CUs).  partial: f32 scratch of splits * M * N elements; the ranges are summed in a fixed order
+ * (no atomics).  N % 256 == 0, K % (64 * splits) == 0; operands bf16 row-major, 16-byte aligned. */
+int bsclip_gemm_splitk_f32(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, int splits,
+                           float* partial, void* stream);
 
 /* ---- optimiser: torch.optim.AdamW defaults (scripts/train_cl.py:158), one launch over a flat f32 buffer ---------- */
 int bsclip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -98,6 +98,52 @@ def test_gemm_layout_identity(ops):
     ops.set_gemm_tile(0)
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(512, 256, 64 * 21, 7), (768, 768, 64 * 40, 8), (300, 512, 64 * 6, 1), (256, 256, 64 * 6, 3)])
+def test_gemm_splitk_accumulates_in_fixed_order(ops, M, N, K, splits):
+    """bsclip_gemm_splitk_f32 (weight gradients of full fine-tuning): C += A B^T with the reduction cut into K ranges; same
+    values as the f32 product of the bf16 operands, added to what C held, and bitwise reproducible (ordered sum, no atomics)."""
+    a, b = dev(rnd(M, K + 64, seed=1)).bfloat16(), dev(rnd(N, K + 64, seed=2)).bfloat16()   # leading dimensions > K
+    c0 = dev(rnd(M, N, seed=3))
+    ref = c0.double() + a[:, :K].double() @ b[:, :K].double().t()
+    partial = torch.empty(splits * M * N, device="cuda")
+    outs = []
+    for _ in range(2):
+        c = c0.clone()
+        ops.gemm_splitk_f32(a, b, c, splits, partial, K=K)
+        outs.append(c)
+    assert rel_err(outs[0], ref) < TOL_F32
+    assert torch.equal(outs[0], outs[1])
+    with pytest.raises(Exception):
+        ops.gemm_splitk_f32(a, b, c0.clone(), 2, partial, K=64 * 3)     # three K-tiles do not split in two
+
+
+@pytest.mark.parametrize("R,C,ld_in", [(394, 768, 768), (1000, 832, 840), (64, 64, 64), (50432 // 8, 3072, 3072), (130, 200, 200)])
+def test_transpose_and_fused_column_sums(ops, R, C, ld_in):
+    """bsclip_transpose_bf16 (16-byte path and the element path for unaligned leading dimensions) and the fused
+    bsclip_transpose_colsum_bf16: exact transpose, column sums equal to the f64 sums to f32 accumulation, added to what the
+    output held, bitwise reproducible."""
+    src = dev(rnd(R, ld_in, seed=4)).bfloat16()[:, :C]
+    Rp = (R + 63) // 64 * 64
+    dst = torch.zeros(C, Rp, device="cuda", dtype=torch.bfloat16)
+    ops.transpose_bf16(src, R, C, dst)
+    assert torch.equal(dst[:, :R], src.t()) and (dst[:, R:] == 0).all()
+    odd = torch.zeros(C, R + 1, device="cuda", dtype=torch.bfloat16)      # ld_out % 8 != 0: element path
+    ops.transpose_bf16(src, R, C, odd)
+    assert torch.equal(odd[:, :R], src.t())
+    if ld_in % 8 == 0:
+        base = dev(rnd(C, seed=5))
+        outs = []
+        for _ in range(2):
+            dst2 = torch.zeros(C, Rp, device="cuda", dtype=torch.bfloat16)
+            cs = base.clone()
+            ops.transpose_colsum_bf16(src, R, C, dst2, cs)
+            assert torch.equal(dst2, dst)
+            outs.append(cs)
+        ref = base.double() + src.double().sum(0)
+        assert (outs[0].double() - ref).abs().max().item() < 2e-5 * max(1.0, src.float().abs().sum(0).max().item())
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_patch_epilogue(ops):
     from bioscanclip.hip.lib import EPI_PATCH_F32
     B = 3
