@@ -28,6 +28,18 @@ def _f32(w, dev):
     return w.detach().to(dev, F32).contiguous()
 
 
+def split_plan(M, N, K):
+    """(splits, padded reduction length) for a weight gradient dW[N, K] = dY^T X reduced over M rows (bsclip_gemm_splitk_f32): as
+    many K ranges as bring the launch to about two rounds of the 256 CUs, each at least four 64-wide K-tiles long.  The output
+    is 9 .. 36 tiles of 256 x 256; one workgroup per tile would leave most of the chip idle for the whole reduction."""
+    tiles = -(-N // 256) * (K // 256)
+    if K % 256 or tiles >= 192 or M < 512:
+        return 1, _pad64(M)
+    S = max(1, min(512 // tiles, M // 256))
+    unit = 64 * S
+    return S, -(-M // unit) * unit
+
+
 def _pad64(n):
     return (n + 63) // 64 * 64
 
@@ -474,7 +486,9 @@ class BertEngine(EncoderEngineBase):
         ws["dqkv"] = z(M, 3 * H)
         ws["dt"] = z(M, 8, dt=F32)
         if self.head == "mlm_softmax_mean":
-            Mp = _pad64(M)
+            ws["head_splits"], Mp = split_plan(M, self.out_dim, H)
+            if ws["head_splits"] > 1:
+                ws["head_partial"] = z(ws["head_splits"] * self.out_dim * H, dt=F32)
             ws["tz"] = z(M, H, dt=torch.uint8)   # gelu'(transform pre-activation), 8-bit codes
             ws["tg"] = z(M, H)            # gelu(transform)
             ws["tn"] = z(M, H)            # LN(gelu(.)) = decoder input
@@ -496,6 +510,17 @@ class BertEngine(EncoderEngineBase):
             ws["dyl"] = z(M, H, dt=F32)
         self.ws = ws
         return ws
+
+    def _decoder_grads(self, ws, gw, gb):
+        """dW_dec += dlogits^T tn (reduced over all B*S tokens: split-K, the [768, 768] output alone is 9 tiles) and db_dec += column
+        sums of dlogits, which fall out of the transpose that builds the GEMM operand."""
+        M, H = ws["M"], self.H
+        ops.transpose_colsum_bf16(ws["dlog"], M, self.out_dim, ws["dlog_t"], gb)
+        ops.transpose_bf16(ws["tn"], M, H, ws["tn_t"])
+        if ws["head_splits"] > 1:
+            ops.gemm_splitk_f32(ws["dlog_t"], ws["tn_t"], gw, ws["head_splits"], ws["head_partial"], K=ws["dlog_t"].shape[1])
+        else:
+            ops.gemm(ws["dlog_t"], ws["tn_t"], gw, EPI_RESID_F32, resid=gw)
 
     def _drop(self, ws, p, layer, site):
         """(p, seed) of one dropout site, or None when dropout is off (eval mode / p = 0).  The seed names the site; what
@@ -598,10 +623,7 @@ class BertEngine(EncoderEngineBase):
         ops.transpose_bf16(self.w_head_bf, self.out_dim, self.head_in, self.w_head_t)
         if self.head == "mlm_softmax_mean":
             ops.softmax_meanpool_bwd(ws["logits"], ws["sm"], dout, B, S, ws["dlog"])
-            ops.transpose_bf16(ws["dlog"], M, self.out_dim, ws["dlog_t"])
-            ops.transpose_bf16(ws["tn"], M, H, ws["tn_t"])
-            ops.gemm(ws["dlog_t"], ws["tn_t"], gw, EPI_RESID_F32, resid=gw)          # dW_dec += dlogits^T tn
-            ops.colsum(ws["dlog"], M, self.out_dim, gb)
+            self._decoder_grads(ws, gw, gb)
             ops.gemm(ws["dlog"], self.w_head_t, ws["dtn"], EPI_BF16)                   # d tn
             ops.layernorm_bwd(ws["tg"], ws["st_t"], self.ln_t[0], 0, g_gemm=ws["dtn"], dx_bf16=ws["dtg"])
             ops.dgelu_mul(ws["dtg"], ws["tz"], M, H, ws["dtg"])

@@ -17,7 +17,7 @@ it, so the fused [3H, H] operand and its gradient are plain views.
 import torch
 
 from . import ops
-from .engine import BF16, F32, BertEngine, ViTEngine, _pad64
+from .engine import BF16, F32, BertEngine, ViTEngine, split_plan
 from .lib import EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_RESID_F32, KPAD
 
 
@@ -62,20 +62,9 @@ class _FTMixin:
             b = self._tbufs[key] = torch.zeros(rows, Mp, dtype=BF16, device=self.device)   # columns >= M stay zero
         return b
 
-    @staticmethod
-    def _split_plan(M, N, K):
-        """(splits, padded reduction length) for dW[N, K] reduced over M tokens: as many K ranges as bring the launch to about
-        two rounds of the 256 CUs, each at least four 64-wide K-tiles long."""
-        tiles = -(-N // 256) * (K // 256)
-        if K % 256 or tiles >= 192 or M < 512:
-            return 1, _pad64(M)
-        S = max(1, min(512 // tiles, M // 256))
-        unit = 64 * S
-        return S, -(-M // unit) * unit
-
     def _dw(self, dY, X, M, N, K, wname, bname, w_n=None):
         """grad(W[N,K]) += dY[:M,:N]^T X[:M,:K];  grad(b[N]) += column sums of dY."""
-        S, Mp = self._split_plan(M, N, K)
+        S, Mp = split_plan(M, N, K)
         tA, tB = self._tbuf("A", N, Mp), self._tbuf("B", K, Mp)
         if bname is not None:   # the bias gradient falls out of the transpose's tiles
             ops.transpose_colsum_bf16(dY, M, N, tA, self.tp(bname, n=N if w_n is not None else None, grad=True))
@@ -278,12 +267,8 @@ class BertEngineFT(_FTMixin, BertEngine):
         gw, gb = self.extra(0, grad=True), self.extra(1, grad=True)
         ops.transpose_bf16(self.w_head_bf, self.out_dim, self.head_in, self.w_head_t)
         if self.head == "mlm_softmax_mean":
-            Mp = _pad64(M)
             ops.softmax_meanpool_bwd(ws["logits"], ws["sm"], dout, B, S, ws["dlog"])
-            ops.transpose_bf16(ws["dlog"], M, self.out_dim, ws["dlog_t"])
-            ops.transpose_bf16(ws["tn"], M, H, ws["tn_t"])
-            ops.gemm(ws["dlog_t"], ws["tn_t"], gw, EPI_RESID_F32, resid=gw)
-            ops.colsum(ws["dlog"], M, self.out_dim, gb)
+            self._decoder_grads(ws, gw, gb)
             ops.gemm(ws["dlog"], self.w_head_t, ws["dtn"], EPI_BF16)
             ops.ln_param_grad(ws["tg"], ws["st_t"], 0, self.tp("lnt.w", grad=True), self.tp("lnt.b", grad=True), g_gemm=ws["dtn"])
             ops.layernorm_bwd(ws["tg"], ws["st_t"], self.ln_t[0], 0, g_gemm=ws["dtn"], dx_bf16=ws["dtg"])
