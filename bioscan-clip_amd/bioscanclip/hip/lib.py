@@ -87,9 +87,10 @@ SIGNATURES = {
     "bsclip_waug_set_lora": (I, [P, I, I, P, P, P]),
     "bsclip_ln_param_grad_workspace_floats": (L, [I]),
     "bsclip_ln_param_grad": (I, [P, I, I, P, I, I, P, I, P, I, P, P, I, F, U, P, P, P, P]),
-    "bsclip_embed_grad": (I, [P, P, I, I, I, I, I, P, P, P, P, P]),
+    "bsclip_embed_grad_workspace_floats": (L, [I]),
+    "bsclip_embed_grad": (I, [P, P, I, I, I, I, I, P, P, P, P, P, P]),
     "bsclip_gather_cast_rows": (I, [P, I, I, I, I, I, I, P, I, P]),
-    "bsclip_transpose_colsum_workspace_floats": (ctypes.c_int64, [I, I]),
+    "bsclip_transpose_colsum_workspace_floats": (L, [I, I]),
     "bsclip_transpose_colsum_bf16": (I, [P, I, I, I, P, I, P, P, P]),
     "bsclip_gemm_splitk_f32": (I, [P, I, P, I, P, I, I, I, I, I, P, P]),
     "bsclip_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, F, P]),

@@ -552,8 +552,12 @@ def embed_grad(ids, type_ids, d_emb, d_word, d_pos, d_type, pad_id=0):
     _req(d_emb.dtype == F32 and d_emb.is_contiguous() and d_emb.shape[0] >= B * S and d_emb.shape[1] == H, "d_emb f32 [B*S,H]")
     _req(all(t.dtype == F32 and t.is_contiguous() and t.shape[1] == H for t in (d_word, d_pos, d_type)) and d_pos.shape[0] >= S
          and d_type.shape[0] >= 2, "embed_grad: gradient tables f32 [*,H]")
+    key = ("embed", H, str(d_emb.device), torch.cuda.current_stream().cuda_stream)
+    ws = _PG_WS.get(key)
+    if ws is None:
+        ws = _PG_WS[key] = torch.empty(_l.load().bsclip_embed_grad_workspace_floats(H), dtype=F32, device=d_emb.device)
     check(_l.load().bsclip_embed_grad(_p(ids), _p(type_ids), B, S, H, d_word.shape[0], int(pad_id), _p(d_emb), _p(d_word),
-                                      _p(d_pos), _p(d_type), _stream()))
+                                      _p(d_pos), _p(d_type), _p(ws), _stream()))
 
 
 def gemm_splitk_f32(a, b, c, splits, partial, K=None):

@@ -6,8 +6,8 @@
 //     d_beta[c] = sum_r dy[r,c], with dy assembled exactly as bsclip_layernorm_bwd assembles it;
 //   * BertEmbeddings gradients (word rows scattered by id, position rows summed over the batch, token-type rows);
 //   * a row gather + cast (f32 rows with a periodic row map -> bf16), which feeds the patch-embedding dW GEMM.
-// All HBM-bound; reductions are ordered (per-workgroup slabs summed in a fixed order) except the word / type embedding
-// scatter, which uses float atomics (rows are selected by data).
+// All HBM-bound; every reduction is ordered (per-workgroup slabs summed in a fixed order; embedding rows owned by one workgroup
+// each): no float atomics, a step is bitwise reproducible in this regime too.
 #include "common.h"
 
 namespace {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void slab_reduce_add_kernel(const float* __res
     }
 }
 
-// d_pos[s, :] += sum_b d[b, s, :]   (ordered);  word / type rows: float atomics
+// d_pos[s, :] += sum_b d[b, s, :]   (ordered)
 __global__ __launch_bounds__(256) void embed_grad_pos_kernel(const float* __restrict__ d, int B, int S, int H,
                                                              float* __restrict__ d_pos) {
     const int i = blockIdx.x * 256 + threadIdx.x;   // over S * H / 4
@@ -119,19 +119,52 @@ __global__ __launch_bounds__(256) void embed_grad_pos_kernel(const float* __rest
     f32x4* o = reinterpret_cast<f32x4*>(d_pos + (size_t)i * 4);
     *o = *o + s;
 }
-__global__ __launch_bounds__(256) void embed_grad_scatter_kernel(const int64_t* __restrict__ ids,
-                                                                 const int64_t* __restrict__ type_ids, int M, int H,
-                                                                 int vocab, int pad_id, const float* __restrict__ d,
-                                                                 float* __restrict__ d_word, float* __restrict__ d_type) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // over M * H
-    if (i >= (long)M * H) return;
-    const int row = (int)(i / H), c = (int)(i % H);
-    const float v = d[i];
-    long id = ids[row];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    if (id != pad_id) atomicAdd(d_word + id * H + c, v);   // nn.Embedding(padding_idx): that row gets no gradient
-    const long tt = type_ids ? (type_ids[row] != 0) : 0;
-    atomicAdd(d_type + tt * H + c, v);
+// Word rows: workgroup v owns vocabulary row v.  Every wave scans the ids 64 at a time (one per lane), `ballot` marks the tokens
+// that hold v, and their gradient rows are added in token order: a fixed order, no atomics.  The ids (a few hundred KB) come
+// out of L2 for all workgroups; the gradient rows are read once overall.  nn.Embedding(padding_idx): that row gets none.
+__global__ __launch_bounds__(256) void embed_grad_word_kernel(const int64_t* __restrict__ ids, int M, int H, int vocab, int pad_id,
+                                                              const float* __restrict__ d, float* __restrict__ d_word) {
+    const int v = blockIdx.x;
+    if (v == pad_id) return;
+    const int lane = threadIdx.x & 63, c = threadIdx.x * 4;
+    const bool active = c < H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+    for (int base = 0; base < M; base += 64) {
+        long id = -1;
+        if (base + lane < M) {
+            id = ids[base + lane];
+            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // the forward lookup clamps the same way
+        }
+        unsigned long long mask = __ballot(id == v);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            any = true;
+            if (active) acc += *reinterpret_cast<const f32x4*>(d + (size_t)(base + j) * H + c);
+        }
+    }
+    if (any && active) {
+        f32x4* o = reinterpret_cast<f32x4*>(d_word + (size_t)v * H + c);
+        *o = *o + acc;
+    }
+}
+
+// Token-type rows (two): per-workgroup slabs over contiguous row ranges, summed afterwards in slab order.
+__global__ __launch_bounds__(256) void embed_grad_type_kernel(const int64_t* __restrict__ type_ids, int M, int H, int rows_per_block,
+                                                              const float* __restrict__ d, float* __restrict__ partial) {
+    const int c = threadIdx.x * 4;
+    if (c >= H) return;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(d + (size_t)r * H + c);
+        if (type_ids && type_ids[r] != 0) a1 += v;
+        else a0 += v;
+    }
+    float* p = partial + (size_t)blockIdx.x * 2 * H;
+    *reinterpret_cast<f32x4*>(p + c) = a0;
+    *reinterpret_cast<f32x4*>(p + H + c) = a1;
 }
 
 // dst[r, :] = bf16(src[(r / p_out) * p_in + off + r % p_out, :])   (rows of H f32 -> bf16), 4 values per thread
@@ -183,15 +216,22 @@ extern "C" int bsclip_ln_param_grad(const void* x, int ld_x, int x_bf16, const f
     return BSCLIP_OK;
 }
 
+constexpr int EG_MAX_BLOCKS = 512;
+
+extern "C" int64_t bsclip_embed_grad_workspace_floats(int H) { return (int64_t)EG_MAX_BLOCKS * 2 * H; }
+
 extern "C" int bsclip_embed_grad(const int64_t* ids, const int64_t* type_ids, int B, int S, int H, int vocab, int pad_id,
-                                 const float* d_emb, float* d_word, float* d_pos, float* d_type, void* stream) {
-    BSCLIP_REQUIRE(ids && d_emb && d_word && d_pos && d_type && B > 0 && S > 0 && H % 4 == 0 && vocab > 0,
-                   "bsclip_embed_grad: null/empty input");
+                                 const float* d_emb, float* d_word, float* d_pos, float* d_type, float* workspace, void* stream) {
+    BSCLIP_REQUIRE(ids && d_emb && d_word && d_pos && d_type && workspace && B > 0 && S > 0 && H % 4 == 0 && H <= 1024 && vocab > 0,
+                   "bsclip_embed_grad: null/empty input or H=%d not in (0, 1024], H %% 4 == 0", H);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int M = B * S;
     hipLaunchKernelGGL(embed_grad_pos_kernel, dim3(ceil_div(S * H / 4, 256)), dim3(256), 0, s, d_emb, B, S, H, d_pos);
-    const long n = (long)B * S * H;
-    hipLaunchKernelGGL(embed_grad_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ids, type_ids, B * S, H,
-                       vocab, pad_id, d_emb, d_word, d_type);
+    hipLaunchKernelGGL(embed_grad_word_kernel, dim3(vocab), dim3(256), 0, s, ids, M, H, vocab, pad_id, d_emb, d_word);
+    const int rows_per_block = max(16, ceil_div(M, EG_MAX_BLOCKS));
+    const int blocks = ceil_div(M, rows_per_block);
+    hipLaunchKernelGGL(embed_grad_type_kernel, dim3(blocks), dim3(256), 0, s, type_ids, M, H, rows_per_block, d_emb, workspace);
+    bsclip_launch_slab_reduce_add(workspace, blocks, 2 * H, d_type, d_type, 2 * H, s);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

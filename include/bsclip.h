@@ -293,8 +293,9 @@ int bsclip_waug_set_lora(void* w_aug, int ld_w, int H, const float* lora_bq, con
  *   bsclip_layernorm_bwd does (g_gemm bf16 + dt.lora_a + (mode 1: g_resid)), optionally masked by the dropout the LN's
  *   OUTPUT was subjected to in forward (BertEmbeddings).  workspace: bsclip_ln_param_grad_workspace_floats(H) floats.
  * embed_grad: autograd of HF BertEmbeddings' three lookups from d_emb f32 [B*S, H] (gradient at the input of its LayerNorm):
- *   d_pos[s] += sum_b (ordered), d_word[id] / d_type[tt] += rows (float atomics: rows are selected by data); rows with id == pad_id get none
- *   (HF: nn.Embedding(padding_idx = config.pad_token_id = 0); pass -1 for "no padding row").
+ *   d_pos[s] += sum_b (ordered), d_word[id] += rows in token order (one workgroup per vocabulary row scans the ids), d_type[tt] +=
+ *   rows through ordered slabs -- no atomics; rows with id == pad_id get none (HF: nn.Embedding(padding_idx = config.pad_token_id
+ *   = 0); pass -1 for "no padding row").  workspace: bsclip_embed_grad_workspace_floats(H) floats.
  * gather_cast_rows: dst bf16 [rows_out, H], dst[r] = src[(r / period_out) * period_in + offset + r % period_out] (f32): e.g. the
  *   196 patch rows of each image out of the 197-row residual gradient -> operand of the patch-embedding dW GEMM. */
 int64_t bsclip_ln_param_grad_workspace_floats(int H);
@@ -302,8 +303,9 @@ int bsclip_ln_param_grad(const void* x, int ld_x, int x_bf16, const float* stats
                          int ld_gr, const void* g_gemm, int ld_g, const float* dt, const float* lora_a, int mode,
                          float in_dropout_p, uint32_t in_dropout_seed, float* d_gamma, float* d_beta, float* workspace,
                          void* stream);
+int64_t bsclip_embed_grad_workspace_floats(int H);
 int bsclip_embed_grad(const int64_t* ids, const int64_t* type_ids, int B, int S, int H, int vocab, int pad_id,
-                      const float* d_emb, float* d_word, float* d_pos, float* d_type, void* stream);
+                      const float* d_emb, float* d_word, float* d_pos, float* d_type, float* workspace, void* stream);
 int bsclip_gather_cast_rows(const float* src, int ld_src, int rows_out, int period_in, int period_out, int offset, int H,
                             void* dst_bf16, int ld_dst, void* stream);
 /* C[M, N] (f32) += A[M, K] . B[N, K]^T with the reduction cut into `splits` equal K ranges that run as separate workgroups

@@ -126,6 +126,30 @@ def test_all_parameter_gradients(name):
         check_summary(k, named[k[len(prefix):]].grad, gs, tol_grad, what=name + " ", first_slack=4.0, probe=not gain)
 
 
+@pytest.mark.parametrize("name", ["dna", "vit"])
+def test_gradients_are_bitwise_reproducible(name):
+    """No float atomics in this regime either: split-K slabs, embedding rows, bias and LayerNorm sums all add in a fixed order."""
+    build, prefix, seed, _, hip_in = _cases()[name]
+    m = build()
+    sd = synth.synth_state_dict({prefix + k: v for k, v in synth.shapes_of(m).items()}, seed=seed)
+    m.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    for p in m.parameters():
+        p.requires_grad = True
+    m.hip_full_ft = True
+    m.to("cuda").train()
+    x = hip_in()
+    x = torch.cat([x] * 4) if torch.is_tensor(x) else x          # 8 samples: M = 1 064 / 1 576 rows, the split-K path
+    runs = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        y = m(x)
+        (y * synth.synth_tensor(f"{name}.cot.rep", y.shape, seed=5).cuda()).sum().backward()
+        torch.cuda.synchronize()
+        runs.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert len(runs[0]) > 30 and all(torch.equal(runs[0][k], runs[1][k]) for k in runs[0])
+
+
 def test_weight_update_reaches_every_tensor():
     """Six FusedAdamW steps in the full fine-tuning regime (per-tensor launches: the optimizer is not attached to the engine):
     every tensor that has a gradient moves, the next forward uses the moved weights (the bf16 operand copies are re-packed

@@ -508,3 +508,59 @@ def test_infonce_fused_epilogues_vs_logits_slabs(ops, N, nmod):
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/infonce_timing.jsonl", "a") as f:
         f.write(json.dumps({"N": N, "nmod": nmod, "fused_ms": ms[0], "slab_ms": ms[1]}) + "\n")
+
+
+# ------------------------------------------------------------------------------- full fine-tuning kernels
+@pytest.mark.parametrize("H,vocab,B,S,types", [(768, 1027, 6, 133, False), (512, 30522, 5, 20, True)])
+def test_embed_grad_matches_autograd_and_is_ordered(ops, H, vocab, B, S, types):
+    """bsclip_embed_grad vs autograd of the three HF BertEmbeddings lookups (word with padding_idx = 0, position, token type);
+    added to what the tables held; bitwise reproducible (no atomics)."""
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, vocab, (B, S), generator=g)
+    ids[:, 0] = 0                                     # the padding row: no gradient
+    ids[1, 5:9] = ids[0, 5]                           # repeated ids across and within samples
+    tt = torch.randint(0, 2, (B, S), generator=g) if types else None
+    d = rnd(B * S, H, seed=4)
+    word = torch.zeros(vocab, H, requires_grad=True)
+    pos = torch.zeros(S + 3, H, requires_grad=True)
+    typ = torch.zeros(2, H, requires_grad=True)
+    e = torch.nn.functional.embedding(ids, word, padding_idx=0) + pos[:S][None] + \
+        torch.nn.functional.embedding(tt if types else torch.zeros_like(ids), typ)
+    (e.reshape(B * S, H) * d).sum().backward()
+    outs = []
+    for _ in range(2):
+        dw, dp, dty = (torch.full((vocab, H), 0.5, device="cuda"), torch.full((S + 3, H), 0.25, device="cuda"),
+                       torch.full((2, H), -1.0, device="cuda"))
+        ops.embed_grad(dev(ids), dev(tt) if types else None, dev(d), dw, dp, dty, pad_id=0)
+        outs.append((dw, dp, dty))
+    dw, dp, dty = outs[0]
+    assert rel_err(dw - 0.5, word.grad) < TOL_F32 and (dw[0] == 0.5).all()
+    assert rel_err(dp - 0.25, pos.grad) < TOL_F32 and rel_err(dty + 1.0, typ.grad) < TOL_F32
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+@pytest.mark.parametrize("H", [768, 512])
+def test_ln_param_grad(ops, H):
+    """d_gamma / d_beta of a LayerNorm whose upstream gradient is assembled like layernorm_bwd assembles it (bf16 GEMM output +
+    f32 residual gradient + the LoRA term dt . A)."""
+    M = 777
+    x = dev(rnd(M, H, seed=1) * 2 + 0.3)
+    gamma, beta = dev(rnd(H, seed=2) * 0.2 + 1), dev(rnd(H, seed=3) * 0.1)
+    y, stats = torch.empty(M, H + 64, device="cuda", dtype=torch.bfloat16), torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x, gamma, beta, 1e-6, y_bf16=y, stats=stats)
+    g_gemm = dev(rnd(M, H, seed=4)).bfloat16()
+    g_resid = dev(rnd(M, H, seed=5))
+    dt, la = dev(rnd(M, 8, seed=6)), dev(rnd(8, H, seed=7) * 0.1)
+    dy = g_gemm.float() + g_resid + dt @ la
+    xhat = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-6)
+    dg, db = dev(rnd(H, seed=8)), dev(rnd(H, seed=9))
+    dg0, db0 = dg.clone(), db.clone()
+    ops.ln_param_grad(x, stats, 1, dg, db, g_resid=g_resid, g_gemm=g_gemm, dt=dt, lora_a=la)
+    assert rel_err(dg - dg0, (dy * xhat).sum(0)) < 5e-5 and rel_err(db - db0, dy.sum(0)) < 5e-5
+
+
+def test_gather_cast_rows(ops):
+    src = dev(rnd(3 * 197, 768, seed=1))
+    dst = torch.empty(3 * 196, 768, device="cuda", dtype=torch.bfloat16)
+    ops.gather_cast_rows(src, 3 * 196, 197, 196, 1, dst)
+    assert torch.equal(dst, src.view(3, 197, 768)[:, 1:].reshape(-1, 768).bfloat16())
