@@ -236,7 +236,15 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __re
     const int e = second ? idx - SLAB : idx;
     const float* src = (second ? pb : pa) + e;
     float s = 0.f;
-    for (int b = p; b < nblocks; b += 8) s += src[(size_t)b * SLAB];
+    int b = p;
+    for (; b + 56 < nblocks; b += 64) {   // eight loads in flight; the adds keep the slab order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + 8 * u) * SLAB];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nblocks; b += 8) s += src[(size_t)b * SLAB];
     red[p][i] = s;
     __syncthreads();
     if (p != 0) return;
