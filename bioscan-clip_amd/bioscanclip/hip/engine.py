@@ -698,10 +698,15 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, engine, fwd_args, *params):
         ctx.engine = engine
         ctx.parent = _PARENT_STREAM[-1] if _PARENT_STREAM else None
+        ctx.generation = engine._fwd_generation
         return engine.forward(*fwd_args)
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.generation != ctx.engine._fwd_generation:
+            raise RuntimeError("backward through an encoder forward whose saved activations were overwritten by a later forward "
+                               "of the same encoder: the HIP engines hold one workspace per encoder -- run backward before the "
+                               "next training-mode forward (the reference loop does: train_epoch.py:28-42)")
         ctx.engine.backward(dout.contiguous())
         from .dist import start_allreduce
         start_allreduce(ctx.engine.flat)  # global-batch step: this tower's gradients are complete on this stream
@@ -764,6 +769,9 @@ def _engine_for(module, build):
 def run_encoder(module, build, fwd_args):
     eng = _engine_for(module, build)
     eng.training = module.training
+    # the engine keeps ONE set of saved activations (its workspace): any later forward of the same encoder, with or without
+    # autograd, overwrites them -- _EncoderFn.backward checks that it still owns them
+    eng._fwd_generation = getattr(eng, "_fwd_generation", 0) + 1
     if torch.is_grad_enabled() and any(p.requires_grad for p in eng.flat.params):
         return _EncoderFn.apply(eng, fwd_args, *eng.flat.params)
     return eng.forward(*fwd_args)

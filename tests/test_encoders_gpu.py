@@ -322,6 +322,28 @@ def test_training_on_a_fixed_batch_drives_the_loss_down():
     assert all(torch.isfinite(p).all() for p in model.parameters())
 
 
+def test_backward_after_a_later_forward_is_refused():
+    """An engine holds one workspace of saved activations per encoder.  forward(a), forward(b), backward(a) would silently
+    differentiate b's activations; it raises instead.  backward(b) still works, and so does the usual one-forward-one-backward."""
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2, **NODROP)), r=4, num_classes=768)
+    _load(m, "dna_encoder.", 11)
+    m.to("cuda").train()
+    a = synth.synth_batch(2, seed=21)[1].cuda()
+    b = synth.synth_batch(2, seed=22)[1].cuda()
+    ya = m(a)
+    yb = m(b)
+    with pytest.raises(RuntimeError, match="overwritten by a later forward"):
+        ya.sum().backward()
+    yb.sum().backward()
+    ya = m(a)
+    with torch.no_grad():
+        m(b)                                   # an evaluation pass in between overwrites the workspace just the same
+    with pytest.raises(RuntimeError, match="overwritten by a later forward"):
+        ya.sum().backward()
+
+
 def test_requires_gpu_inputs():
     from bioscanclip.model import arch
     from bioscanclip.model.image_encoder import LoRA_ViT_timm
