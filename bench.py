@@ -265,6 +265,7 @@ def main():
         graphed = GraphedStep(model, opt, crit, warmup=2)
 
     def step():
+        nonlocal graphed
         if graphed is not None:
             return graphed(image, dna, text, label)
         opt.zero_grad()
@@ -284,7 +285,18 @@ def main():
     if rank == 0:
         print(f"[bench] first step done, loss {loss.item():.5f}", file=sys.stderr, flush=True)
     hdist.broadcast_trainable(model)
-    for _ in range(max(a.warmup, 3 if graphed is not None else 0)):   # graph mode: 2 eager steps, then the capture
+    if graphed is not None:   # 1 more eager step, the capture, one replay -- all untimed; an eager fallback if the capture fails
+        try:
+            for _ in range(3):
+                loss = step()
+            torch.cuda.synchronize()
+        except Exception as exc:   # noqa: BLE001 - the measurement must not die with the launch path
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); continuing with the eager launch path",
+                  file=sys.stderr, flush=True)
+            graphed = None
+            opt.enable_device_hyper(False)
+            torch.cuda.synchronize()
+    for _ in range(a.warmup):
         loss = step()
 
     def fence():

@@ -1,7 +1,7 @@
 """The training step as ONE hipGraph ("HIP streams and graphs instead of a tracing compiler").
 
-Eagerly a step is ~1 500 ctypes launches: 25 ms of host wall time and a saturated core per rank.  ``GraphedStep`` runs the
-step's own Python once under stream capture -- zero_grad, the towers on their streams, loss, backward through autograd,
+Eagerly a step is ~560 ctypes launches: 8.6 ms of host time (measured at B=8, where the step IS the enqueue time; 2.7 ms for
+one graph replay).  ``GraphedStep`` runs the step's own Python once under stream capture -- zero_grad, the towers on their streams, loss, backward through autograd,
 fused AdamW -- and replays the resulting graph; per step the host then does three things: refresh the pinned (lr, step) pair
 the AdamW nodes read, launch the graph, and (if the caller wants it) read the loss.  What makes that legal:
   * no launch argument changes from step to step: dropout masks come from a per-engine device step word advanced by a node of
