@@ -7,6 +7,8 @@ Mirrored entry points (same names, argument meaning and return shapes as the ref
     top_k_macro_accuracy       :467-511
     inference_and_print_result :633-715   (accuracy table only; the csv / plotting side is control plane, out of scope)
     get_features_and_label     :734-784
+    main                       :786-871   (config -> load_clip_model -> checkpoint unless load_ckpt=false -> features -> table;
+                                           splits from the synthetic evaluation loaders, feature cache as .npz)
 """
 import os
 import sys
@@ -154,3 +156,53 @@ def inference_and_print_result(keys_dict, seen_dict, unseen_dict, args=None, sma
                 per_class_acc[q][kf][s] = per_class
     print_micro_and_macro_acc(acc_dict, k_list, args)
     return acc_dict, per_class_acc, pred_dict
+
+
+def main(argv=None):
+    """Reference entry (scripts/inference_and_eval.py:786-871): config -> ``load_clip_model`` -> checkpoint
+    (``model_config.ckpt_path`` unless ``model_config.load_ckpt`` is false, :839-843) -> features of the key / seen / unseen
+    splits -> accuracy table.  The HDF5 splits are not available here: the splits come from the synthetic
+    evaluation loaders; extracted features are cached as ``.npz`` (h5py is absent) under the reference's directory layout
+    (``extracted_embedding/<dataset>/<model_output_name>/``) and reused with ``load_inference=true`` (:797-833)."""
+    from bioscanclip.model.simple_clip import load_clip_model
+    from bioscanclip.util.config import load_config
+    from bioscanclip.util.synthetic import SyntheticEvalLoader
+    from bioscanclip.util.util import load_checked
+    here = os.path.dirname(os.path.abspath(__file__))
+    args = load_config(os.path.join(here, "..", "bioscanclip", "config"), list(sys.argv[1:] if argv is None else argv))
+    mc = args.model_config
+    if not torch.cuda.is_available():
+        raise RuntimeError("inference_and_eval needs a ROCm GPU: the encoders and the top-k search run in libbsclip_hip.so")
+    device = torch.device("cuda", 0)
+    ies = getattr(args, "inference_and_eval_setting", None)
+    k_list = list(getattr(ies, "k_list", [1, 3, 5])) if ies is not None else [1, 3, 5]
+    root = str(getattr(args, "project_root_path", "."))
+    folder = os.path.join(root, "extracted_embedding", str(getattr(mc, "dataset", "synthetic")), str(mc.model_output_name))
+    feats_path = os.path.join(folder, "extracted_feature_from_val_split.npz")
+    splits = None
+    if getattr(args, "load_inference", False) and os.path.exists(feats_path):
+        z = np.load(feats_path, allow_pickle=True)
+        splits = [z[k].item() for k in ("keys", "seen", "unseen")]
+    if splits is None:
+        print("Initialize model...")
+        model = load_clip_model(args, device)
+        if hasattr(mc, "load_ckpt") and mc.load_ckpt is False:
+            pass
+        else:
+            load_checked(model, torch.load(str(mc.ckpt_path), map_location="cpu"), f"checkpoint {mc.ckpt_path}")
+        model.eval()
+        with_text = hasattr(mc, "language")
+        bs, n = 24, int(getattr(args, "synthetic_eval_batches", 2))   # the reference evaluates at batch 24 (:846)
+        mk = lambda seed: SyntheticEvalLoader(bs, n, with_text=with_text, seed=seed)
+        splits = [get_features_and_label(mk(4321), model, device, for_key_set=True),
+                  get_features_and_label(mk(4322), model, device), get_features_and_label(mk(4323), model, device)]
+        if getattr(args, "save_inference", False):
+            os.makedirs(folder, exist_ok=True)
+            np.savez(feats_path, keys=np.array(splits[0], dtype=object), seen=np.array(splits[1], dtype=object),
+                     unseen=np.array(splits[2], dtype=object))
+    keys_dict, seen_dict, unseen_dict = splits
+    return inference_and_print_result(keys_dict, seen_dict, unseen_dict, args, small_species_list=None, k_list=k_list)
+
+
+if __name__ == "__main__":
+    main()

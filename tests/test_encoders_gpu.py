@@ -287,6 +287,33 @@ def test_train_cl_epoch_with_eval_phase(tmp_path, capsys):
     assert keys == {k for k in load_golden("state_dict_keys")["keys"] if not k.startswith("language_encoder.")}
 
 
+def test_inference_and_eval_script_loads_the_training_checkpoint(tmp_path, capsys):
+    """scripts/inference_and_eval.py as an entry point (reference :786-871): the checkpoint train_cl.py wrote is loaded (checked),
+    features of the three splits are extracted, the accuracy table is printed; ``save_inference`` / ``load_inference`` reuse the
+    cached features and give the same table; ``model_config.load_ckpt=false`` skips the checkpoint; a checkpoint of another
+    configuration is refused."""
+    import sys as _sys
+    scripts = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bioscan-clip_amd", "scripts")
+    _sys.path.insert(0, scripts)
+    import inference_and_eval
+    import train_cl
+    common = ["model_config=lora_vit_lora_barcode_bert_ssl", f"project_root_path={tmp_path}", "debug_flag=false"]
+    train_cl.main(common + ["model_config.batch_size=8", "model_config.epochs=1", "synthetic_steps_per_epoch=2", "save_ckpt=true"])
+    ck = [os.path.join(r, f) for r, _, fs in os.walk(str(tmp_path)) for f in fs if f.endswith("last.pth")][0]
+    capsys.readouterr()
+    acc, _, _ = inference_and_eval.main(common + [f"model_config.ckpt_path={ck}", "save_inference=true"])
+    out1 = capsys.readouterr().out
+    assert "Initialize model" in out1 and "micro_acc top-1" in out1 and "macro_acc top-5" in out1
+    a1 = acc["encoded_image_feature"]["encoded_dna_feature"]["seen"]["micro_acc"]
+    acc2, _, _ = inference_and_eval.main(common + [f"model_config.ckpt_path={ck}", "load_inference=true"])
+    out2 = capsys.readouterr().out
+    assert "Initialize model" not in out2                         # features came from the cache
+    assert acc2["encoded_image_feature"]["encoded_dna_feature"]["seen"]["micro_acc"] == a1
+    inference_and_eval.main(common + ["model_config.load_ckpt=false"])
+    with pytest.raises(RuntimeError, match="does not match the parameter tree"):
+        inference_and_eval.main(["model_config=lora_vit_lora_bert_ssl", f"project_root_path={tmp_path}", f"model_config.ckpt_path={ck}"])
+
+
 def test_train_cl_image_text_config(tmp_path, capsys):
     """The reference's two-tower Image+Text configuration (model_config/lora_vit_lora_bert_ssl.yaml): no DNA tower is built, the
     loss runs on the one pair, the checkpoint carries image and language keys only."""
