@@ -157,3 +157,20 @@ def test_checkpoint_helpers_and_roundtrip(tmp_path):
     torch.save(a.state_dict(), ck)
     b.load_state_dict(torch.load(ck))
     assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
+
+
+def test_split_plan_for_weight_gradient_gemms():
+    """hip/engine.py:split_plan -- the K-slice plan of bsclip_gemm_splitk_f32 (full fine-tuning dW GEMMs): equal slices of whole
+    64-wide K-tiles, about two rounds of the 256 CUs, no split where the output already fills the chip or the reduction is short."""
+    from bioscanclip.hip.engine import split_plan
+    for M, N, K in [(50432, 768, 3072), (50432, 3072, 768), (50432, 2304, 768), (50432, 768, 768), (34048, 768, 768),
+                    (5120, 512, 2048), (5120, 1536, 512), (1064, 768, 768)]:
+        S, Mp = split_plan(M, N, K)
+        tiles = -(-N // 256) * (K // 256)
+        assert S >= 1 and Mp >= M and Mp % (64 * S) == 0 and Mp - M < 64 * S
+        assert S * tiles <= 512 and Mp // S >= 256                      # at most two rounds; >= four K-tiles per slice
+        if M >= 16384:
+            assert S * tiles > 256                                       # more than one round of the chip
+    assert split_plan(394, 768, 3072) == (1, 448)                        # fixture-sized batches: one slice, padded to 64
+    assert split_plan(50432, 768, 1000)[0] == 1                          # K not a multiple of the 256-wide tile: the plain kernel
+    assert split_plan(50432, 4096, 4096)[0] == 1                         # 256 output tiles already fill the chip
