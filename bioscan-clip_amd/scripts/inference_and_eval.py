@@ -167,7 +167,7 @@ def main(argv=None):
     from bioscanclip.model.simple_clip import load_clip_model
     from bioscanclip.util.config import load_config
     from bioscanclip.util.synthetic import SyntheticEvalLoader
-    from bioscanclip.util.util import load_checked
+    from bioscanclip.util.util import load_checked, remove_extra_pre_fix
     here = os.path.dirname(os.path.abspath(__file__))
     args = load_config(os.path.join(here, "..", "bioscanclip", "config"), list(sys.argv[1:] if argv is None else argv))
     mc = args.model_config
@@ -189,7 +189,7 @@ def main(argv=None):
         if hasattr(mc, "load_ckpt") and mc.load_ckpt is False:
             pass
         else:
-            load_checked(model, torch.load(str(mc.ckpt_path), map_location="cpu"), f"checkpoint {mc.ckpt_path}")
+            load_checked(model, remove_extra_pre_fix(torch.load(str(mc.ckpt_path), map_location="cpu")), f"checkpoint {mc.ckpt_path}")
         model.eval()
         with_text = hasattr(mc, "language")
         bs, n = 24, int(getattr(args, "synthetic_eval_batches", 2))   # the reference evaluates at batch 24 (:846)
