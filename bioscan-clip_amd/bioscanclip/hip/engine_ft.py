@@ -55,17 +55,20 @@ class _FTMixin:
         super().refresh_lora_weights()
 
     # ------------------------------------------------------------------------------------------------ weight gradients
-    def _tbuf(self, tag, rows, Mp):
-        key = (tag, rows, Mp)
+    def _tbuf(self, tag, rows, M, Mp):
+        """Zero-padded transposed operand [rows, Mp] of a weight-gradient GEMM over M tokens.  Keyed by M as well: the columns
+        [M, Mp) must stay zero, and two GEMMs with different token counts (the ViT blocks' B * 197 and the patch embedding's
+        B * 196 round to the same Mp) would otherwise leave each other's last columns behind."""
+        key = (tag, rows, M, Mp)
         b = self._tbufs.get(key)
         if b is None:
-            b = self._tbufs[key] = torch.zeros(rows, Mp, dtype=BF16, device=self.device)   # columns >= M stay zero
+            b = self._tbufs[key] = torch.zeros(rows, Mp, dtype=BF16, device=self.device)
         return b
 
     def _dw(self, dY, X, M, N, K, wname, bname, w_n=None):
         """grad(W[N,K]) += dY[:M,:N]^T X[:M,:K];  grad(b[N]) += column sums of dY."""
         S, Mp = split_plan(M, N, K)
-        tA, tB = self._tbuf("A", N, Mp), self._tbuf("B", K, Mp)
+        tA, tB = self._tbuf("A", N, M, Mp), self._tbuf("B", K, M, Mp)
         if bname is not None:   # the bias gradient falls out of the transpose's tiles
             ops.transpose_colsum_bf16(dY, M, N, tA, self.tp(bname, n=N if w_n is not None else None, grad=True))
         else:
