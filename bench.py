@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--text", action="store_true", help="add the BERT-small text tower (BASELINE configs[2])")
     ap.add_argument("--fp8", action="store_true", help="fp8 e4m3 frozen-trunk GEMMs for ViT + BarcodeBERT (BASELINE configs[4])")
     ap.add_argument("--full-ft", action="store_true", help="disable_lora: true -- train every parameter (SURVEY 8f-4; not a BASELINE config)")
-    ap.add_argument("--lr", type=float, default=None, help="AdamW lr (default 1e-3; 5e-5 with --full-ft, the reference's one-cycle max_lr)")
+    ap.add_argument("--lr", type=float, default=None, help="AdamW lr (default 1e-3; 1e-6 with --full-ft, the reference's full fine-tuning base lr: random-init towers on noise images collapse under larger steps, tools/ft_dynamics_probe.py)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -254,7 +254,7 @@ def main():
     image, dna, text = synthetic_batch(B, a.text, device, seed=1234 + rank)
     label = (torch.arange(B) + rank * B).to(device)
     crit = (GlobalBatchContrastiveLoss if world > 1 or force_dist else ContrastiveLoss)(torch.nn.CrossEntropyLoss(), 1 / 0.07)
-    opt = FusedAdamW(model.parameters(), lr=a.lr if a.lr is not None else (5e-5 if a.full_ft else 1e-3))
+    opt = FusedAdamW(model.parameters(), lr=a.lr if a.lr is not None else (1e-6 if a.full_ft else 1e-3))
 
     # One process, one GPU: the whole step is captured once into a hipGraph and replayed (bioscanclip/hip/graph.py) -- the
     # host does three calls per step instead of ~1 500.  With a process group the step stays eager: the collectives are issued
