@@ -160,3 +160,59 @@ def test_engine_train_vs_eval_mode():
     (y2 * torch.randn_like(y2)).sum().backward()
     grads = [p.grad for p in m_drop.parameters() if p.requires_grad]
     assert all(torch.isfinite(g).all() and g.abs().sum() > 0 for g in grads)
+
+
+@pytest.mark.parametrize("full_ft", [False, True])
+def test_directional_derivative_with_the_masks_held_fixed(full_ft):
+    """End-to-end check of the backward pass WITH dropout: the masks are a function of (site seed, element, step word), so with
+    the engine's step word reset before every forward the encoder is a deterministic function of its parameters, and the
+    gradient the kernels produce must agree with a central finite difference of  L = sum(y * cot)  along a random direction over
+    all trainable tensors -- LoRA pairs + decoder, or every parameter under full fine-tuning (weight, bias, LayerNorm,
+    embedding gradients are then taken under the forward's masks, including the embedding LayerNorm's).  bf16 operands make L a
+    staircase in the parameters: the step is 3 % of each tensor's scale, the agreement asked for 10 %."""
+    from oracle import synth
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2)), r=4, num_classes=768,
+                          lora_layer=[] if full_ft else None)
+    sd = synth.synth_state_dict({"dna_encoder." + k: v for k, v in synth.shapes_of(m).items()}, 11)
+    m.load_state_dict({k[len("dna_encoder."):]: v for k, v in sd.items()})
+    if full_ft:
+        for p in m.parameters():
+            p.requires_grad = True
+        m.hip_full_ft = True
+    m.cuda().train()
+    x = synth.synth_batch(8, seed=21)[1].cuda()
+    cot = synth.synth_tensor("fd.cot", (8, 768), seed=5).cuda()
+    y = m(x)                                    # builds the engine
+
+    def L(grad):
+        m._engine._step_word.zero_()            # every forward below draws the masks of step 1
+        if grad:
+            for p in m.parameters():
+                p.grad = None
+            y = m(x)
+            (y * cot).sum().backward()
+            return (y.detach() * cot).sum().item()
+        with torch.no_grad():
+            return (m(x) * cot).sum().item()
+
+    base = L(True)
+    assert base == L(False), "masks are not held fixed"
+    params = [p for p in m.parameters() if p.requires_grad and p.grad is not None and p.grad.abs().max().item() > 0]
+    assert len(params) > (35 if full_ft else 8)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    d = [torch.randn(p.shape, device="cuda", generator=g) * p.detach().float().std().clamp_min(1e-3) for p in params]
+    analytic = sum((p.grad * di).sum().item() for p, di in zip(params, d))
+    eps = 0.03
+    vals = []
+    for sgn in (1.0, -1.0):
+        with torch.no_grad():
+            for p, di in zip(params, d):
+                p.add_(di, alpha=sgn * eps)
+        vals.append(L(False))
+        with torch.no_grad():
+            for p, di in zip(params, d):
+                p.sub_(di, alpha=sgn * eps)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - analytic) < 0.1 * abs(analytic), (fd, analytic, base, vals)
