@@ -108,24 +108,28 @@ def test_full_fine_tuning_large_batch_equals_small_batch_on_shared_rows():
     assert errs[worst] < 2e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:12]
 
 
-@pytest.mark.parametrize("full_ft", [False, True])
-def test_large_batch_gradients_equal_the_sum_over_chunks(full_ft):
+@pytest.mark.parametrize("full_ft,with_text", [(False, False), (True, False), (False, True), (True, True)])
+def test_large_batch_gradients_equal_the_sum_over_chunks(full_ft, with_text):
     """Every sample active: samples are independent, so the parameter gradients of a 128-sample batch (the large-grid kernels,
     split-K weight gradients under full fine-tuning) are the sum of the gradients of its sixteen 8-sample chunks (the fixture
-    shape).  Catches anything that leaks between rows, slices or shared buffers when no row's gradient is zero."""
+    shape).  Catches anything that leaks between rows, slices or shared buffers when no row's gradient is zero.  With the text
+    tower: ragged key masks and token-type ids per sample."""
     from bioscanclip.model.simple_clip import enable_full_fine_tuning
     B, n = 128, 8
-    model = _towers(False)
+    model = _towers(with_text)
     if full_ft:
         enable_full_fine_tuning(model)
-    fi, fd, _, _ = synth.synth_batch(32, seed=73)
+    fi, fd, ft, _ = synth.synth_batch(32, seed=73, with_text=with_text)
     image, dna = fi.repeat(B // 32, 1, 1, 1).cuda(), fd.repeat(B // 32, 1).cuda()
     image = image + 0.01 * torch.arange(B, device="cuda").view(B, 1, 1, 1) / B            # no two samples identical
-    cot = [synth.synth_tensor(f"chunk.cot.{i}", (B, 768), seed=6).cuda() for i in range(2)]
-    _, g_big = _run(model, image, dna, None, cot, B)
+    text = {k: v.repeat(B // 32, 1).cuda() for k, v in ft.items()} if with_text else None
+    nmod = 3 if with_text else 2
+    cot = [synth.synth_tensor(f"chunk.cot.{i}", (B, 768), seed=6).cuda() for i in range(nmod)]
+    _, g_big = _run(model, image, dna, text, cot, B)
     acc = {k: torch.zeros_like(v) for k, v in g_big.items()}
     for c in range(0, B, n):
-        _, g = _run(model, image[c:c + n], dna[c:c + n], None, [t[c:c + n] for t in cot], n)
+        tc = {k: v[c:c + n] for k, v in text.items()} if with_text else None
+        _, g = _run(model, image[c:c + n], dna[c:c + n], tc, [t[c:c + n] for t in cot], n)
         for k in acc:
             acc[k] += g[k]
     errs = {k: rel_err(g_big[k], acc[k]) for k in acc if acc[k].abs().max().item() > 0 and not k.endswith("attention.self.key.bias")}
