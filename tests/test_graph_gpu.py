@@ -10,23 +10,28 @@ from helpers import rel_err  # noqa: E402
 from oracle import synth  # noqa: E402
 
 
-def _build(seed, with_text):
+def _build(seed, with_text, full_ft=False):
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
     from bioscanclip.model.image_encoder import LoRA_ViT_timm
     from bioscanclip.model.language_encoder import LoRA_bert
     from bioscanclip.model.simple_clip import SimpleCLIP
     torch.manual_seed(seed)
-    model = SimpleCLIP(LoRA_ViT_timm(arch.VisionTransformerParams(depth=3), r=4, num_classes=768),
-                       LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=3)), r=4, num_classes=768),
-                       LoRA_bert(arch.BertModelParams(arch.bert_small_config(num_hidden_layers=2)), r=4, num_classes=768)
+    ll = [] if full_ft else None    # disable_lora: no LoRA in the BERTs, LoRA on every ViT block, everything trainable
+    model = SimpleCLIP(LoRA_ViT_timm(arch.VisionTransformerParams(depth=3), r=4, num_classes=768, lora_layer=ll),
+                       LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=3)), r=4, num_classes=768,
+                                         lora_layer=ll),
+                       LoRA_bert(arch.BertModelParams(arch.bert_small_config(num_hidden_layers=2)), r=4, num_classes=768, lora_layer=ll)
                        if with_text else None)
     model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=seed))
+    if full_ft:
+        from bioscanclip.model.simple_clip import enable_full_fine_tuning
+        enable_full_fine_tuning(model)
     return model.cuda().train()     # HF dropout 0.1 / 0.1 active
 
 
-@pytest.mark.parametrize("with_text", [False, True])
-def test_graph_replay_equals_eager_step(with_text):
+@pytest.mark.parametrize("with_text,full_ft", [(False, False), (True, False), (True, True)])
+def test_graph_replay_equals_eager_step(with_text, full_ft):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from bioscanclip.hip.graph import GraphedStep
@@ -37,10 +42,10 @@ def test_graph_replay_equals_eager_step(with_text):
     cuda = lambda t: None if t is None else ({k: v.cuda() for k, v in t.items()} if isinstance(t, dict) else t.cuda())
     runs = {}
     for mode in ("eager", "graph"):
-        model = _build(91, with_text)
-        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        model = _build(91, with_text, full_ft)
+        opt = FusedAdamW(model.parameters(), lr=1e-4 if full_ft else 1e-3)
         opt.enable_device_hyper(True)   # both modes on bsclip_adamw_step_dev (checked against the host-argument form below)
-        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-3, total_steps=steps, pct_start=0.3, anneal_strategy="cos",
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-4 if full_ft else 3e-3, total_steps=steps, pct_start=0.3, anneal_strategy="cos",
                                                     cycle_momentum=False)
         crit = ContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)
         g = GraphedStep(model, opt, crit, warmup=2) if mode == "graph" else None
