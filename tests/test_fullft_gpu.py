@@ -360,3 +360,31 @@ def test_full_fine_tuning_overfits_a_fixed_batch_with_dropout():
     _log({"test": "fullft fixed-batch training with dropout", "losses": losses})
     assert all(l == l for l in losses) and losses[-1] < 0.6 * losses[0], losses
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_shared_gradients_equal_the_lora_regime():
+    """The ViT carries LoRA on every block in both regimes (App. B-3): with the same weights and inputs the full fine-tuning engine
+    must produce the LoRA regime's embeddings and its LoRA / head gradients exactly -- same kernels on the shared part; the
+    regime only adds gradients (and keeps per-layer copies of two activations)."""
+    from bioscanclip.model import arch
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    x = synth.synth_batch(4, seed=23)[0].cuda()
+    outs = {}
+    for regime in ("lora", "full"):
+        m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=3), r=4, num_classes=768, lora_layer=[])
+        sd = synth.synth_state_dict({"image_encoder." + k: v for k, v in synth.shapes_of(m).items()}, seed=13)
+        m.load_state_dict({k[len("image_encoder."):]: v for k, v in sd.items()})
+        if regime == "full":
+            for p in m.parameters():
+                p.requires_grad = True
+            m.hip_full_ft = True
+        m.to("cuda").train()
+        y = m(x)
+        (y * synth.synth_tensor("vit.cot.shared", y.shape, seed=5).cuda()).sum().backward()
+        torch.cuda.synchronize()
+        outs[regime] = (y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    (yl, gl), (yf, gf) = outs["lora"], outs["full"]
+    assert torch.equal(yl, yf)
+    assert len(gl) == 3 * 4 + 2 and len(gf) > 40 and set(gl) <= set(gf)
+    for k in gl:
+        assert torch.equal(gl[k], gf[k]), k
