@@ -130,19 +130,31 @@ def test_large_batch_gradients_equal_the_sum_over_chunks_fp8():
     _chunk_sum_check(model, False, 100)
 
 
-def _chunk_sum_check(model, with_text, min_tensors):
-    B, n = 128, 8
+@pytest.mark.parametrize("full_ft", [False, True])
+def test_ragged_batch_gradients_equal_the_sum_over_chunks(full_ft):
+    """A batch size that fits no tile (B = 100: 19 700 ViT rows, 13 300 DNA rows, partial last GEMM tiles, zero-padded split-K
+    slices) against chunks of 8 and a last chunk of 4."""
+    from bioscanclip.model.simple_clip import enable_full_fine_tuning
+    model = _towers(False)
+    if full_ft:
+        enable_full_fine_tuning(model)
+    _chunk_sum_check(model, False, 350 if full_ft else 100, B=100)
+
+
+def _chunk_sum_check(model, with_text, min_tensors, B=128):
+    n = 8
     fi, fd, ft, _ = synth.synth_batch(32, seed=73, with_text=with_text)
-    image, dna = fi.repeat(B // 32, 1, 1, 1).cuda(), fd.repeat(B // 32, 1).cuda()
+    reps = -(-B // 32)
+    image, dna = fi.repeat(reps, 1, 1, 1)[:B].cuda(), fd.repeat(reps, 1)[:B].cuda()
     image = image + 0.01 * torch.arange(B, device="cuda").view(B, 1, 1, 1) / B            # no two samples identical
-    text = {k: v.repeat(B // 32, 1).cuda() for k, v in ft.items()} if with_text else None
+    text = {k: v.repeat(reps, 1)[:B].cuda() for k, v in ft.items()} if with_text else None
     nmod = 3 if with_text else 2
     cot = [synth.synth_tensor(f"chunk.cot.{i}", (B, 768), seed=6).cuda() for i in range(nmod)]
     _, g_big = _run(model, image, dna, text, cot, B)
     acc = {k: torch.zeros_like(v) for k, v in g_big.items()}
     for c in range(0, B, n):
         tc = {k: v[c:c + n] for k, v in text.items()} if with_text else None
-        _, g = _run(model, image[c:c + n], dna[c:c + n], tc, [t[c:c + n] for t in cot], n)
+        _, g = _run(model, image[c:c + n], dna[c:c + n], tc, [t[c:c + n] for t in cot], min(n, B - c))
         for k in acc:
             acc[k] += g[k]
     errs = {k: rel_err(g_big[k], acc[k]) for k in acc if acc[k].abs().max().item() > 0 and not k.endswith("attention.self.key.bias")}
