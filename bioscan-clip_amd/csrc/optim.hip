@@ -44,9 +44,31 @@ __device__ __forceinline__ float reduce8(float (&p)[8], int lane) {
 
 constexpr int LG_BLOCK = 256;
 
+// 4-way transpose-reduce: lane bits (5,4) end up owning index r
+__device__ __forceinline__ float reduce4(float (&p)[4], int lane) {
+    float q[2];
+    const bool hi5 = lane & 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float send = hi5 ? p[i] : p[i + 2];
+        const float keep = hi5 ? p[i + 2] : p[i];
+        q[i] = keep + __shfl_xor(send, 32, 64);
+    }
+    const bool hi4 = lane & 16;
+    float v = (hi4 ? q[1] : q[0]) + __shfl_xor(hi4 ? q[0] : q[1], 16, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
 // pass 1: dt[M,8] = [dq.B_q | dv.B_v];  dBq[H,4] += dq^T t_q;  dBv[H,4] += dv^T t_v
 // haug / ld_h: the bf16 block holding t -- the LN output row (t at column H, bf16 path) or the separate t_aug buffer
 // (t at column 0, fp8 path; the caller passes haug = t_aug - H)
+// The waves of a workgroup come in pairs: the even wave of a pair owns the q half of a row (dq, B_q, t_q), the odd wave the v
+// half.  With both halves in one wave the kernel held 2 x (B + accumulators) = 192 VGPRs plus the rows in flight and ran at two
+// waves per SIMD, HBM latency exposed (59 us for 155 MB); a half is 96 + rows, three waves per SIMD.
 template <int H>
 __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t* __restrict__ dqkv, int ld,
                                                                     const bf16_t* __restrict__ haug, int ld_h, int M,
@@ -56,76 +78,65 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t*
     constexpr int NV = H / 256;
     __shared__ float red[2 * NV * 16 * 64];
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * LG_BLOCK + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * LG_BLOCK) >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int is_v = wib & 1;
+    const int pair = blockIdx.x * (LG_BLOCK / 128) + (wib >> 1);
+    const int npairs = gridDim.x * (LG_BLOCK / 128);
     for (int i = threadIdx.x; i < 2 * NV * 16 * 64; i += LG_BLOCK) red[i] = 0.f;
 
-    f32x4 bq[NV][4], bv[NV][4];  // [chunk][column-in-chunk] -> 4 ranks
-    f32x4 aq[NV][4], av[NV][4];  // accumulators, same indexing
+    f32x4 bx[NV][4];  // [chunk][column-in-chunk] -> 4 ranks of this half's B
+    f32x4 ax[NV][4];  // accumulators, same indexing
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = j * 256 + lane * 4 + i;
-            bq[j][i] = *reinterpret_cast<const f32x4*>(lora_b + (size_t)c * 4);
-            bv[j][i] = *reinterpret_cast<const f32x4*>(lora_b + (size_t)(H + c) * 4);
-            aq[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            av[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bx[j][i] = *reinterpret_cast<const f32x4*>(lora_b + (size_t)(is_v * H + c) * 4);
+            ax[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-    // Rows are software-pipelined three deep: with one row per iteration every row paid a full HBM round trip (83 us for
-    // 155 MB); a wave now keeps the loads of its next PF rows (3 KiB each) in flight while it reduces the current one.
+    // Rows are software-pipelined three deep: a wave keeps the loads of its next PF half-rows in flight while it reduces one.
     constexpr int PF = 3;
-    uint2 rq[PF][NV], rv[PF][NV];
-    u32x4 rt[PF];
+    uint2 rx[PF][NV];
+    uint2 rt[PF];
     auto fetch = [&](int slot, int row) {
-        const bf16_t* g = dqkv + (size_t)row * ld;
+        const bf16_t* g = dqkv + (size_t)row * ld + is_v * 2 * H;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            rq[slot][j] = *reinterpret_cast<const uint2*>(g + j * 256 + lane * 4);
-            rv[slot][j] = *reinterpret_cast<const uint2*>(g + 2 * H + j * 256 + lane * 4);
-        }
-        rt[slot] = *reinterpret_cast<const u32x4*>(haug + (size_t)row * ld_h + H);  // t_q(4) t_v(4), broadcast
+        for (int j = 0; j < NV; ++j) rx[slot][j] = *reinterpret_cast<const uint2*>(g + j * 256 + lane * 4);
+        rt[slot] = *reinterpret_cast<const uint2*>(haug + (size_t)row * ld_h + H + 4 * is_v);  // this half's t (4), broadcast
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p)
-        if (wave + p * nwaves < M) fetch(p, wave + p * nwaves);
+        if (pair + p * npairs < M) fetch(p, pair + p * npairs);
     auto body = [&](int slot, int row) {
-        f32x4 dq[NV], dv[NV];
+        f32x4 dx[NV];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            dq[j] = f32x4{bf2f(rq[slot][j].x & 0xffff), bf2f(rq[slot][j].x >> 16), bf2f(rq[slot][j].y & 0xffff),
-                          bf2f(rq[slot][j].y >> 16)};
-            dv[j] = f32x4{bf2f(rv[slot][j].x & 0xffff), bf2f(rv[slot][j].x >> 16), bf2f(rv[slot][j].y & 0xffff),
-                          bf2f(rv[slot][j].y >> 16)};
-        }
-        const u32x4 tu = rt[slot];
-        if (row + PF * nwaves < M) fetch(slot, row + PF * nwaves);
-        const f32x4 tq = {bf2f(tu[0] & 0xffff), bf2f(tu[0] >> 16), bf2f(tu[1] & 0xffff), bf2f(tu[1] >> 16)};
-        const f32x4 tv = {bf2f(tu[2] & 0xffff), bf2f(tu[2] >> 16), bf2f(tu[3] & 0xffff), bf2f(tu[3] >> 16)};
-        f32x4 pq = {0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NV; ++j)
+            dx[j] = f32x4{bf2f(rx[slot][j].x & 0xffff), bf2f(rx[slot][j].x >> 16), bf2f(rx[slot][j].y & 0xffff),
+                          bf2f(rx[slot][j].y >> 16)};
+        const uint2 tu = rt[slot];
+        if (row + PF * npairs < M) fetch(slot, row + PF * npairs);
+        const f32x4 tx = {bf2f(tu.x & 0xffff), bf2f(tu.x >> 16), bf2f(tu.y & 0xffff), bf2f(tu.y >> 16)};
+        f32x4 px = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                pq += dq[j][i] * bq[j][i];
-                pv += dv[j][i] * bv[j][i];
-                aq[j][i] += dq[j][i] * tq;
-                av[j][i] += dv[j][i] * tv;
+                px += dx[j][i] * bx[j][i];
+                ax[j][i] += dx[j][i] * tx;
             }
-        float p[8] = {pq[0], pq[1], pq[2], pq[3], pv[0], pv[1], pv[2], pv[3]};
-        const float tot = reduce8(p, lane);
-        const int src = ((lane >> 2) & 1) * 32 + ((lane >> 1) & 1) * 16 + (lane & 1) * 8;
-        const float tl = __shfl(tot, src, 64);
-        if (lane < 8) dt[(size_t)row * 8 + lane] = tl;
+        float p[4] = {px[0], px[1], px[2], px[3]};
+        const float tot = reduce4(p, lane);
+        const float tl = __shfl(tot, ((lane >> 1) & 1) * 32 + (lane & 1) * 16, 64);
+        if (lane < 4) dt[(size_t)row * 8 + 4 * is_v + lane] = tl;
     };
-    for (int row = wave; row < M; row += PF * nwaves) {  // slots are compile-time indices: registers, not scratch
+    for (int row = pair; row < M; row += PF * npairs) {  // slots are compile-time indices: registers, not scratch
 #pragma unroll
         for (int p = 0; p < PF; ++p)
-            if (row + p * nwaves < M) body(p, row + p * nwaves);
+            if (row + p * npairs < M) body(p, row + p * npairs);
     }
-    // cross-wave sum in wave order (no LDS atomics: the order of float adds is fixed)
-    const int wib = threadIdx.x >> 6;
+    // cross-wave sum in wave order (no LDS atomics: the order of float adds is fixed): waves 0, 2 into the q region, 1, 3 into v
+    float* mine = red + is_v * (NV * 16 * 64);
     for (int w = 0; w < LG_BLOCK / 64; ++w) {
         __syncthreads();
         if (wib == w) {
@@ -134,10 +145,7 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t*
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        red[((j * 16 + i * 4 + r) * 64) + lane] += aq[j][i][r];
-                        red[((NV * 16 + j * 16 + i * 4 + r) * 64) + lane] += av[j][i][r];
-                    }
+                    for (int r = 0; r < 4; ++r) mine[((j * 16 + i * 4 + r) * 64) + lane] += ax[j][i][r];
         }
     }
     __syncthreads();
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
 
 }  // namespace
 
-constexpr int LG_MAX_BLOCKS = 512;
+constexpr int LG_MAX_BLOCKS = 768;   // three 4-wave workgroups per CU
 
 extern "C" int64_t bsclip_lora_grad_workspace_floats(int H) { return (int64_t)LG_MAX_BLOCKS * 16 * H; }
 
