@@ -80,16 +80,16 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
         g[j] = *reinterpret_cast<const f32x4*>(gamma + j * 256 + lane * 4);
         b[j] = *reinterpret_cast<const f32x4*>(beta + j * 256 + lane * 4);
     }
-    f32x4 a[LORA ? 8 : 1][NV];
+    // LoRA A [8, H] f32 lives in LDS (24 KiB per workgroup), read back as conflict-free 16-byte pieces for every row: in
+    // registers it cost 96 VGPRs and held the kernel at two waves per SIMD (177 VGPRs), HBM latency exposed.
+    __shared__ __attribute__((aligned(16))) float sA[LORA ? 8 * H : 4];
     if constexpr (LORA) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int j = 0; j < NV; ++j) a[r][j] = *reinterpret_cast<const f32x4*>(lora_a + r * H + j * 256 + lane * 4);
+        for (int i = threadIdx.x * 4; i < 8 * H; i += LN_BLOCK * 4)
+            *reinterpret_cast<f32x4*>(sA + i) = *reinterpret_cast<const f32x4*>(lora_a + i);
+        __syncthreads();
     }
 
-    // The wave's next row is loaded before the current one is reduced: the LoRA variant keeps A (96 VGPRs) resident, runs
-    // at 3 waves per SIMD and was latency-bound with one row in flight per wave (57 vs 41 us without LoRA).
+    // The wave's next row is loaded before the current one is reduced (one row in flight per wave was latency-bound).
     f32x4 nxt[NV];
     if (wave < M) load_row<H, X_BF16>(x, ld_x, wave, lane, nxt);
     for (int row = wave; row < M; row += nwaves) {
@@ -148,8 +148,10 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
                 for (int r = 0; r < 8; ++r) {
                     float d = 0.f;
 #pragma unroll
-                    for (int j = 0; j < NV; ++j)
-                        d += (v[j][0] * a[r][j][0] + v[j][1] * a[r][j][1]) + (v[j][2] * a[r][j][2] + v[j][3] * a[r][j][3]);
+                    for (int j = 0; j < NV; ++j) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(sA + r * H + j * 256 + lane * 4);
+                        d += (v[j][0] * a[0] + v[j][1] * a[1]) + (v[j][2] * a[2] + v[j][3] * a[3]);
+                    }
                     p[r] = d;
                 }
                 const float t = reduce8(p, lane);  // lane group (bits 5,4,3) owns r
@@ -184,15 +186,15 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
     f32x4 g[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) g[j] = *reinterpret_cast<const f32x4*>(gamma + j * 256 + lane * 4);
-    f32x4 a[LORA ? 8 : 1][NV];
+    __shared__ __attribute__((aligned(16))) float sA[LORA ? 8 * H : 4];   // LoRA A in LDS, as in the forward kernel
     if constexpr (LORA) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int j = 0; j < NV; ++j) a[r][j] = *reinterpret_cast<const f32x4*>(lora_a + r * H + j * 256 + lane * 4);
+        for (int i = threadIdx.x * 4; i < 8 * H; i += LN_BLOCK * 4)
+            *reinterpret_cast<f32x4*>(sA + i) = *reinterpret_cast<const f32x4*>(lora_a + i);
+        __syncthreads();
     }
 
     for (int row = wave; row < M; row += nwaves) {
+        if constexpr (LORA) asm volatile("" ::: "memory");   // sA is loop-invariant: keep its 24 reads out of the registers
         f32x4 v[NV], dy[NV], res[NV];
         load_row<H, X_BF16>(x, ld_x, row, lane, v);
         const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
@@ -220,8 +222,9 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
             const f32x4 d1 = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8 + 4);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                dy[j] += d0[0] * a[0][j] + d0[1] * a[1][j] + d0[2] * a[2][j] + d0[3] * a[3][j];
-                dy[j] += d1[0] * a[4][j] + d1[1] * a[5][j] + d1[2] * a[6][j] + d1[3] * a[7][j];
+                auto A = [&](int r) { return *reinterpret_cast<const f32x4*>(sA + r * H + j * 256 + lane * 4); };
+                dy[j] += d0[0] * A(0) + d0[1] * A(1) + d0[2] * A(2) + d0[3] * A(3);
+                dy[j] += d1[0] * A(4) + d1[1] * A(5) + d1[2] * A(6) + d1[3] * A(7);
             }
         }
         if (mode == 1) {
@@ -305,15 +308,16 @@ __global__ __launch_bounds__(LN_BLOCK) void l2norm_bwd_kernel(const float* __res
     }
 }
 
-int ln_grid(int M) {
+int ln_grid(int M, int resident_per_cu = 8) {
     const int blocks = ceil_div(M, LN_BLOCK / 64);
-    return blocks < 2048 ? blocks : 2048;  // grid-stride beyond 8 workgroups per CU
+    const int cap = 256 * resident_per_cu;   // grid-stride beyond what is resident at once (LoRA variants: 24 KiB of LDS each)
+    return blocks < cap ? blocks : cap;
 }
 
 }  // namespace
 
 #define LN_FWD_LAUNCH(HH, XB, LO)                                                                              \
-    hipLaunchKernelGGL((layernorm_fwd_kernel<HH, XB, LO>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, M, \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<HH, XB, LO>), dim3(ln_grid(M, LO ? 5 : 8)), dim3(LN_BLOCK), 0, s, x, ld_x, M, \
                        gamma, beta, eps, static_cast<bf16_t*>(y_bf16), ld_y, y_f32, lora_a, stats, drop)
 
 extern "C" int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma,
@@ -342,7 +346,7 @@ extern "C" int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, 
 }
 
 #define LN_FWD8_LAUNCH(HH, XB, LO)                                                                                   \
-    hipLaunchKernelGGL((layernorm_fwd_kernel<HH, XB, LO, true>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, M, gamma, \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<HH, XB, LO, true>), dim3(ln_grid(M, LO ? 5 : 8)), dim3(LN_BLOCK), 0, s, x, ld_x, M, gamma, \
                        beta, eps, static_cast<bf16_t*>(y_fp8), ld_y, y_f32, lora_a, stats, drop, static_cast<bf16_t*>(t_aug), ld_t)
 
 extern "C" int bsclip_layernorm_fwd_fp8(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma,
@@ -370,7 +374,7 @@ extern "C" int bsclip_layernorm_fwd_fp8(const void* x, int ld_x, int x_bf16, int
 }
 
 #define LN_BWD_LAUNCH(HH, XB, LO)                                                                                \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<HH, XB, LO>), dim3(ln_grid(M)), dim3(LN_BLOCK), 0, s, x, ld_x, stats, \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<HH, XB, LO>), dim3(ln_grid(M, LO ? 4 : 8)), dim3(LN_BLOCK), 0, s, x, ld_x, stats, \
                        gamma, M, g_resid, ld_gr, static_cast<const bf16_t*>(g_gemm), ld_g, dt, lora_a, mode, dx_f32, \
                        ld_dx, static_cast<bf16_t*>(dx_bf16), ld_dxb, drop, in_drop)
 

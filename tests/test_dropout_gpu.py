@@ -167,9 +167,9 @@ def test_directional_derivative_with_the_masks_held_fixed(full_ft):
     """End-to-end check of the backward pass WITH dropout: the masks are a function of (site seed, element, step word), so with
     the engine's step word reset before every forward the encoder is a deterministic function of its parameters, and the
     gradient the kernels produce must agree with a central finite difference of  L = sum(y * cot)  along a random direction over
-    all trainable tensors -- LoRA pairs + decoder, or every parameter under full fine-tuning (weight, bias, LayerNorm,
-    embedding gradients are then taken under the forward's masks, including the embedding LayerNorm's).  bf16 operands make L a
-    staircase in the parameters: the step is 3 % of each tensor's scale, the agreement asked for 10 %."""
+    all trainable tensors (the gradient direction, per tensor at the parameter's scale) -- LoRA pairs + decoder, or every parameter under full fine-tuning (weight, bias, LayerNorm,
+    embedding gradients are then taken under the forward's masks, including the embedding LayerNorm's).  Three step sizes; the
+    smallest must agree to 5 % (measured: 1.2 % in the LoRA regime, 1e-4 under full fine-tuning)."""
     from oracle import synth
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
@@ -181,6 +181,7 @@ def test_directional_derivative_with_the_masks_held_fixed(full_ft):
         for p in m.parameters():
             p.requires_grad = True
         m.hip_full_ft = True
+    torch.manual_seed(11)                       # the dropout site seeds derive from torch.initial_seed()
     m.cuda().train()
     x = synth.synth_batch(8, seed=21)[1].cuda()
     cot = synth.synth_tensor("fd.cot", (8, 768), seed=5).cuda()
@@ -201,18 +202,24 @@ def test_directional_derivative_with_the_masks_held_fixed(full_ft):
     assert base == L(False), "masks are not held fixed"
     params = [p for p in m.parameters() if p.requires_grad and p.grad is not None and p.grad.abs().max().item() > 0]
     assert len(params) > (35 if full_ft else 8)
-    g = torch.Generator(device="cuda").manual_seed(3)
-    d = [torch.randn(p.shape, device="cuda", generator=g) * p.detach().float().std().clamp_min(1e-3) for p in params]
+    # direction: the gradient itself, every tensor rescaled to its parameter's scale (a random direction makes the analytic
+    # value a cancellation remainder and the bf16 staircase of L dominates the comparison)
+    d = [p.grad / p.grad.pow(2).mean().sqrt().clamp_min(1e-30) * p.detach().float().std().clamp_min(1e-3) for p in params]
     analytic = sum((p.grad * di).sum().item() for p, di in zip(params, d))
-    eps = 0.03
-    vals = []
-    for sgn in (1.0, -1.0):
-        with torch.no_grad():
-            for p, di in zip(params, d):
-                p.add_(di, alpha=sgn * eps)
-        vals.append(L(False))
-        with torch.no_grad():
-            for p, di in zip(params, d):
-                p.sub_(di, alpha=sgn * eps)
-    fd = (vals[0] - vals[1]) / (2 * eps)
-    assert abs(fd - analytic) < 0.1 * abs(analytic), (fd, analytic, base, vals)
+    ratios = {}
+    for eps in (2e-3, 5e-4, 1.25e-4):
+        vals = []
+        for sgn in (1.0, -1.0):
+            with torch.no_grad():
+                for p, di in zip(params, d):
+                    p.add_(di, alpha=sgn * eps)
+            vals.append(L(False))
+            with torch.no_grad():
+                for p, di in zip(params, d):
+                    p.sub_(di, alpha=sgn * eps)
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        ratios[eps] = fd / analytic
+    # measured: LoRA regime 0.978 / 1.010 / 0.988, full fine-tuning 0.647 / 0.949 / 0.9999 -- the function is strongly curved along
+    # its own gradient (softmax-mean output), the finite difference converges onto the kernels' gradient as the step shrinks;
+    # far below one bf16 ulp per weight the staircase averages out over the 10^5 .. 10^8 perturbed weights
+    assert abs(ratios[1.25e-4] - 1.0) < 0.05 and abs(ratios[5e-4] - 1.0) < 0.12, ratios
