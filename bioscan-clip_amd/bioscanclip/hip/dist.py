@@ -62,6 +62,7 @@ def _comm_stream(device):
 
 _OVERLAP = {"on": False, "group": None}
 _PENDING_AR = []      # [(flat gradient buffer, work handle)] issued from _EncoderFn.backward, waited in allreduce_grads
+_ISSUED_AR = []       # the gradient buffers in the order their all-reduces were issued this step (must be rank-independent)
 _PENDING_LABELS = {}  # id(label tensor) -> (label tensor, gathered labels, work handle)
 
 
@@ -102,6 +103,9 @@ def start_label_gather(label):
 def start_allreduce(flat):
     """Called from an encoder's autograd node on that tower's stream once its whole backward is enqueued."""
     if overlap_active():
+        if not _PENDING_AR:
+            _ISSUED_AR.clear()
+        _ISSUED_AR.append(flat.grad)
         _PENDING_AR.append((flat.grad, dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=_OVERLAP["group"],
                                                        async_op=True)))
 
@@ -179,7 +183,9 @@ def frozen_checksum(model):
     equality check of the frozen trunk."""
     tensors = [t for t in list(model.parameters()) + list(model.buffers())
                if not getattr(t, "requires_grad", False) and t.is_floating_point()]
-    total = torch.zeros(1, dtype=torch.float64, device=tensors[0].device if tensors else "cpu")
+    if not tensors:          # full fine-tuning (disable_lora): nothing is frozen, nothing to compare
+        return None
+    total = torch.zeros(1, dtype=torch.float64, device=tensors[0].device)
     for t in tensors:
         total += t.detach().double().sum()
     return total
@@ -190,6 +196,8 @@ def assert_frozen_in_sync(model, group=None):
     if _inactive(group):
         return
     mine = frozen_checksum(model)
+    if mine is None:         # every rank takes this branch together: the set of frozen tensors is a property of the config
+        return
     allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
     dist.all_gather(allv, mine, group=group)
     vals = [v.item() for v in allv]

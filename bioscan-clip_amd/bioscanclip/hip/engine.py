@@ -11,6 +11,8 @@ Everything numerical happens in ``libbsclip_hip.so``; this file decides *which* 
     sub-layer, bf16 GEMM operands, attention LSE, LN statistics).
 Reference call shapes: SURVEY.md 2.3 (K1-K15), 3.2; semantics App. A.1-A.3.
 """
+import zlib
+
 import torch
 
 from . import ops
@@ -550,7 +552,8 @@ class BertEngine(EncoderEngineBase):
         # masks are functions of (seed, element index), regenerated in backward from the seeds kept here
         ws["train"] = bool(getattr(self, "training", False))
         # the rank is mixed in: ranks seeded alike (bench.py, train_cl.py) must not draw the same masks for their shards
-        ws["drop_base"] = (torch.initial_seed() * 0x2545F491 + _rank() * 0x632BE5AB) & 0xFFFFFFFF
+        # ... and the engine (its head kind): the DNA and text towers share layer / site numbers and step values
+        ws["drop_base"] = (torch.initial_seed() * 0x2545F491 + _rank() * 0x632BE5AB + zlib.crc32(self.head.encode())) & 0xFFFFFFFF
         self._begin_dropout(ws, advance=True)
         self.refresh_lora_weights()
         ops.cast_f32_bf16(self.extra(0), self.w_head_bf)

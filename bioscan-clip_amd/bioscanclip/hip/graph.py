@@ -2,8 +2,9 @@
 
 Eagerly a step is ~560 ctypes launches: 8.6 ms of host time (measured at B=8, where the step IS the enqueue time; 2.7 ms for
 one graph replay).  ``GraphedStep`` runs the step's own Python once under stream capture -- zero_grad, the towers on their streams, loss, backward through autograd,
-fused AdamW -- and replays the resulting graph; per step the host then does three things: refresh the pinned (lr, step) pair
-the AdamW nodes read, launch the graph, and (if the caller wants it) read the loss.  What makes that legal:
+fused AdamW -- and replays the resulting graph; per step the host then does three things: stage the learning rate (a fill
+kernel enqueued ahead of the replay; the step count lives on the device and is advanced by a node of the graph, so no
+in-flight node reads host memory the host could rewrite), launch the graph, and (if the caller wants it) read the loss.  What makes that legal:
   * no launch argument changes from step to step: dropout masks come from a per-engine device step word advanced by a node of
     the graph (``bsclip_set_dropout_step`` / ``bsclip_counter_add``), AdamW's lr and step from device memory
     (``bsclip_adamw_step_dev``), inputs from static buffers;
@@ -73,7 +74,9 @@ class GraphedStep:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = self._body()
-            # the capture ran the host half of the step once (step counts, pinned pairs) without executing anything
+            # the capture ran the host half of the step once (step counts) without executing anything; lr is delivered outside
+            # the graph, before the replay that consumes it
+            self.optimizer.stage_hyper()
             self.graph.replay()
             return self.loss
         self.optimizer.advance_host_state()

@@ -476,9 +476,11 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
 
 
 def adamw_step_dev(p, g, m, v, hyper, beta1, beta2, eps, weight_decay, grad_scale=1.0):
-    """AdamW with (lr, step) read from the device tensor ``hyper`` (f32 [2]) when the kernel runs: graph-capturable."""
+    """AdamW with (lr, step) read from the device pair ``hyper`` = [lr as f32, step as uint32] when the kernel runs:
+    graph-capturable (advance the step word with ``counter_add(hyper[1:2])``)."""
     _req(all(t.dtype == F32 and t.is_contiguous() and t.numel() == p.numel() for t in (p, g, m, v)), "adamw: flat f32 buffers")
-    _req(hyper.dtype == F32 and hyper.is_cuda and hyper.numel() >= 2, "adamw: hyper must be a device f32 [2] = (lr, step)")
+    _req(hyper.element_size() == 4 and hyper.is_cuda and hyper.is_contiguous() and hyper.numel() >= 2,
+         "adamw: hyper must be a device pair of 4-byte words (lr f32, step uint32)")
     check(_l.load().bsclip_adamw_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), float(beta1), float(beta2),
                                           float(eps), float(weight_decay), float(grad_scale), _stream()))
 

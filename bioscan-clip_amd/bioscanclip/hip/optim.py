@@ -20,19 +20,39 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def enable_device_hyper(self, on=True):
         """Read (lr, step) from device memory inside the kernel (``bsclip_adamw_step_dev``) instead of passing them as launch
-        arguments: required when the step is captured into a hipGraph (arguments freeze at capture).  Each flat buffer gets a
-        pinned host pair and a device pair; ``step()`` refreshes the host pair and enqueues the 8-byte copy (captured as a
-        memcpy node that reads the pinned pair at replay), ``advance_host_state()`` does the host half for a replay."""
+        arguments: required when the step is captured into a hipGraph (arguments freeze at capture).  Each flat buffer owns a
+        device pair ``[lr (f32), step (uint32)]``.  No in-flight node ever reads host memory: the step word is advanced on the
+        device (eagerly it is set by a fill kernel carrying the value as a launch argument; under capture a
+        ``bsclip_counter_add`` node advances it on every replay), and lr reaches the device through ``stage_hyper()`` -- a
+        stream-ordered fill issued at call time, OUTSIDE the graph, before the replay that consumes it."""
         self._dev_hyper = bool(on)
 
-    def advance_host_state(self):
-        """Host half of one optimizer step, for a graph replay: step counts += 1, pinned (lr, step) pairs refreshed."""
+    def _group_of(self, f):
+        for g in self.param_groups:
+            if any(p is f.params[0] for p in g["params"]):
+                return g
+        return self.param_groups[0]
+
+    def stage_hyper(self):
+        """Enqueue the current lr of every flat buffer's own param group into its device word (a fill kernel whose value is a
+        launch argument: stream-ordered behind the previous step, nothing for the host to overwrite while it is in flight).
+        Called by ``step()`` when it is not being captured and by ``GraphedStep`` before each replay."""
         for f in self._flats:
             st = self._flat_state.get(id(f))
-            if st is not None and "hyper_host" in st:
+            if st is not None and "hyper" in st:
+                lr = float(self._group_of(f)["lr"])
+                if st.get("lr_staged") != lr:
+                    st["hyper"].view(torch.float32)[0:1].fill_(lr)
+                    st["lr_staged"] = lr
+
+    def advance_host_state(self):
+        """Host half of one optimizer step, for a graph replay: the host's step counts follow the device words (which the
+        replayed graph advances itself) and the current lr is staged."""
+        for f in self._flats:
+            st = self._flat_state.get(id(f))
+            if st is not None and "hyper" in st:
                 st["step"] += 1
-                st["hyper_host"][0] = float(self.param_groups[0]["lr"])
-                st["hyper_host"][1] = float(st["step"])
+        self.stage_hyper()
 
     def _state_for(self, f):
         """Adam moments of one flat buffer.  Keyed by the PARAMETERS it holds (they outlive an engine rebuild: a checkpoint
@@ -104,7 +124,6 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         handled = set()
-        group0 = self.param_groups[0]
         in_opt = {id(p): g for g in self.param_groups for p in g["params"]}
         for f in self._flats:
             if not f.valid() or not all(id(p) in in_opt for p in f.params):
@@ -114,11 +133,19 @@ class FusedAdamW(torch.optim.Optimizer):
             f.bind_grads()
             st["step"] += 1
             if self._dev_hyper:
+                capturing = torch.cuda.is_current_stream_capturing()
                 if "hyper" not in st:
-                    st["hyper_host"] = torch.zeros(2, dtype=torch.float32).pin_memory()
-                    st["hyper"] = torch.zeros(2, dtype=torch.float32, device=f.data.device)
-                st["hyper_host"][0], st["hyper_host"][1] = float(g["lr"]), float(st["step"])
-                st["hyper"].copy_(st["hyper_host"], non_blocking=True)
+                    if capturing:
+                        raise RuntimeError("FusedAdamW: run one eager step with device-side (lr, step) before capturing")
+                    st["hyper"] = torch.zeros(2, dtype=torch.int32, device=f.data.device)   # [lr as f32 bits, step as uint32]
+                if capturing:
+                    ops.counter_add(st["hyper"][1:2], 1)          # a node of the graph: every replay advances the step word
+                else:
+                    st["hyper"][1:2].fill_(st["step"])             # value travels as a launch argument
+                    lr = float(g["lr"])
+                    if st.get("lr_staged") != lr:
+                        st["hyper"].view(torch.float32)[0:1].fill_(lr)
+                        st["lr_staged"] = lr
                 ops.adamw_step_dev(f.data, f.grad, st["m"], st["v"], st["hyper"], g["betas"][0], g["betas"][1], g["eps"],
                                    g["weight_decay"])
             else:

@@ -14,7 +14,7 @@ void bsclip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bsclip_last_error(void) { return g_err; }
-extern "C" int bsclip_abi_version(void) { return 4; }  // 4: layernorm_bwd in_dropout, fp8 / pipeline / comm / full-FT entry points, 8-bit gelu side band
+extern "C" int bsclip_abi_version(void) { return 5; }  // 5: adamw_step_dev step word is uint32 (device-advanced), dropout step passes through the mixer; 4: layernorm_bwd in_dropout, fp8 / pipeline / comm / full-FT entry points, 8-bit gelu side band
 
 // ---- dropout step word ------------------------------------------------------------------------------------------
 static thread_local const unsigned* g_drop_step = nullptr;

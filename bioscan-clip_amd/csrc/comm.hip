@@ -16,6 +16,8 @@
 // RCCL is bound at first use with dlopen, not at link time: libbsclip_hip.so loads on a box without RCCL, and a process that
 // already carries torch's bundled librccl keeps a single copy of its symbols.
 #include <dlfcn.h>
+
+#include <mutex>
 #include <string.h>
 #include <rccl/rccl.h>
 
@@ -34,17 +36,31 @@ struct Rccl {
 };
 Rccl g_rccl;
 
-const char* load_rccl() {
-    if (g_rccl.handle) return nullptr;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+// Resolution order: (1) an RCCL the process already carries (torch bundles one, SONAME librccl.so.1, found through torch's
+// RPATH): its symbols through RTLD_DEFAULT, or the loaded object itself through RTLD_NOLOAD -- never a second copy; (2) only
+// then a path search.  No RTLD_GLOBAL: the handle is private to this table.  Initialisation runs once (std::call_once):
+// collectives are issued from the host thread and from autograd's device thread.
+const char* load_rccl_once() {
     void* h = nullptr;
-    for (const char* n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+    const bool resident = dlsym(RTLD_DEFAULT, "ncclAllGather") != nullptr;
+    if (!resident) {
+        const char* loaded[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : loaded) {
+            h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (h) break;
+        }
+        if (!h) {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+            for (const char* n : names) {
+                h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (h) break;
+            }
+        }
+        if (!h) return "librccl.so not found (dlopen)";
     }
-    if (!h) return "librccl.so not found (dlopen)";
-#define BIND(field, sym)                                              \
-    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, sym)); \
+    void* from = resident ? RTLD_DEFAULT : h;
+#define BIND(field, sym)                                                       \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(from, sym)); \
     if (!g_rccl.field) return "RCCL symbol missing: " sym;
     BIND(GetUniqueId, "ncclGetUniqueId")
     BIND(CommInitRank, "ncclCommInitRank")
@@ -53,8 +69,15 @@ const char* load_rccl() {
     BIND(AllReduce, "ncclAllReduce")
     BIND(GetErrorString, "ncclGetErrorString")
 #undef BIND
-    g_rccl.handle = h;
+    g_rccl.handle = resident ? reinterpret_cast<void*>(1) : h;
     return nullptr;
+}
+
+std::once_flag g_rccl_once;
+const char* g_rccl_err = nullptr;
+const char* load_rccl() {
+    std::call_once(g_rccl_once, [] { g_rccl_err = load_rccl_once(); });
+    return g_rccl_err;
 }
 
 #define RCCL_READY()                                              \

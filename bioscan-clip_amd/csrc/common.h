@@ -59,10 +59,11 @@ struct DropCfg {
     const unsigned* step;  // device word mixed into the seed when the kernel RUNS (nullable): lets a captured hipGraph draw new
                            // masks on every replay -- kernel arguments are frozen at capture, device memory is not
 };
-// first statement of every kernel that takes a DropCfg by value
-#define BSCLIP_DROP_RESOLVE(d)                                        \
-    do {                                                              \
-        if ((d).thr16 && (d).step) (d).seed += *(d).step * 0x9E3779B9U; \
+// first statement of every kernel that takes a DropCfg by value.  The step goes through the mixer: added linearly with the
+// element multiplier (round 2) it made step s+1's mask the mask of step s slid by one element pair.
+#define BSCLIP_DROP_RESOLVE(d)                                                                    \
+    do {                                                                                          \
+        if ((d).thr16 && (d).step) (d).seed = hash32((d).seed ^ hash32(*(d).step + 0x85EBCA6BU)); \
     } while (0)
 __device__ __forceinline__ unsigned hash32(unsigned x) {  // "lowbias32" integer mixer
     x ^= x >> 16;

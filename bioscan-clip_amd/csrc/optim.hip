@@ -374,13 +374,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
-// lr and step come from device memory (hyper[0], hyper[1]); the bias corrections are formed in f64 like the host form does
+// lr and step come from device memory: hyper[0] = lr (f32), hyper[1] = step count (uint32 bits, advanced by a
+// bsclip_counter_add node of the captured step, so no in-flight node ever reads host memory); the bias corrections are
+// formed in f64 like the host form does
 __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, long n,
                                                          const float* __restrict__ hyper, float beta1, float beta2, float eps,
                                                          float wd, float grad_scale) {
     const float lr = hyper[0];
-    const double step = (double)hyper[1];
+    const double step = (double)reinterpret_cast<const unsigned*>(hyper)[1];
     const float inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, step)));
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, step)));
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {

@@ -318,8 +318,9 @@ int bsclip_gemm_splitk_f32(const void* A, int lda, const void* B, int ldb, float
 /* ---- optimiser: torch.optim.AdamW defaults (scripts/train_cl.py:158), one launch over a flat f32 buffer ---------- */
 int bsclip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int step, float grad_scale, void* stream);
-/* the same update with the two per-step quantities read from device memory when the kernel runs: hyper_dev[0] = lr,
- * hyper_dev[1] = step (as a float, exact below 2^24) -- the form a captured hipGraph replays with a moving LR schedule */
+/* the same update with the two per-step quantities read from device memory when the kernel runs: hyper_dev[0] = lr (f32),
+ * hyper_dev[1] = step count as a uint32 word (advance it with bsclip_counter_add, a capturable launch) -- the form a captured
+ * hipGraph replays with a moving LR schedule; neither word is ever read from host memory by an in-flight node */
 int bsclip_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, float beta1,
                           float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 

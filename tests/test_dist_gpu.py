@@ -17,20 +17,28 @@ from oracle import synth  # noqa: E402
 NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
 
 
-def _build(with_text=False):
+def _build(with_text=False, mode="lora"):
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
     from bioscanclip.model.image_encoder import LoRA_ViT_timm
     from bioscanclip.model.language_encoder import LoRA_bert
     from bioscanclip.model.simple_clip import SimpleCLIP
-    img = LoRA_ViT_timm(arch.VisionTransformerParams(depth=2), r=4, num_classes=768)
+    ll = [] if mode == "fullft" else None   # disable_lora (simple_clip.py:151-153): no LoRA in the BERTs, every parameter trained
+    img = LoRA_ViT_timm(arch.VisionTransformerParams(depth=2), r=4, num_classes=768, lora_layer=ll)
     dna = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2, **NODROP)), r=4,
-                            num_classes=768)
+                            num_classes=768, lora_layer=ll)
     txt = LoRA_bert(arch.BertModelParams(arch.bert_small_config(num_hidden_layers=2, **NODROP)), r=4,
-                    num_classes=768) if with_text else None
+                    num_classes=768, lora_layer=ll) if with_text else None
     model = SimpleCLIP(img, dna, txt)
     model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=51))
-    return model.cuda().train()
+    if mode == "fullft":
+        from bioscanclip.model.simple_clip import enable_full_fine_tuning
+        enable_full_fine_tuning(model)
+    model = model.cuda().train()
+    if mode == "fp8":
+        from bioscanclip.hip.engine import set_precision
+        set_precision(model, "fp8")
+    return model
 
 
 def _flat_grads(model):
@@ -41,14 +49,18 @@ def _cuda(text):
     return None if text is None else {k: v.cuda() for k, v in text.items()}
 
 
-def _worker(rank, world, port, B, tmp, with_text):
+def _worker(rank, world, port, B, tmp, with_text, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bioscanclip.hip import dist as hdist
     from bioscanclip.model.loss_func import GlobalBatchContrastiveLoss
-    model = _build(with_text)
+    model = _build(with_text, mode)
+    # scripts/train_cl.py:broadcast_model -- every parameter from rank 0 + the frozen-weights guard (with nothing frozen under
+    # full fine-tuning the guard has nothing to compare and must not touch a CPU tensor under a device backend: ADVICE r2)
+    hdist.broadcast_parameters(model, src=0)
+    hdist.assert_frozen_in_sync(model)
     image, dna, text, label = synth.synth_batch(world * B, seed=9, dup_labels=True, with_text=with_text)
     sl = slice(rank * B, (rank + 1) * B)
     crit = GlobalBatchContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)   # switches overlap mode on
@@ -60,16 +72,17 @@ def _worker(rank, world, port, B, tmp, with_text):
     loss = crit(io, do, to, local_label)
     loss.backward()
     assert len(hdist._PENDING_AR) == (3 if with_text else 2)                  # one all-reduce per encoder, from its node
+    order = [tuple(t.shape) for t in hdist._ISSUED_AR]                        # issue order: must not depend on the rank
     hdist.allreduce_grads(model)
     torch.cuda.synchronize()
-    torch.save({"loss": loss.detach().cpu(), "flat": _flat_grads(model)}, os.path.join(tmp, f"rank{rank}.pt"))
+    torch.save({"loss": loss.detach().cpu(), "flat": _flat_grads(model), "order": order}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("with_text", [False, True])
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path, with_text):
+@pytest.mark.parametrize("with_text,mode", [(False, "lora"), (True, "lora"), (True, "fullft"), (False, "fp8")])
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path, with_text, mode):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     world, B = 2, 4
@@ -77,9 +90,9 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, with_text):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(world, port, B, str(tmp_path), with_text), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, B, str(tmp_path), with_text, mode), nprocs=world, join=True)
     from bioscanclip.model.loss_func import ContrastiveLoss
-    model = _build(with_text)
+    model = _build(with_text, mode)
     image, dna, text, label = synth.synth_batch(world * B, seed=9, dup_labels=True, with_text=with_text)
     io, do, to = model(image.cuda(), dna.cuda(), _cuda(text))
     loss = ContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)(io, do, to, label.cuda())
@@ -90,7 +103,10 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, with_text):
     assert abs(r0["loss"].item() - loss.item()) < 1e-5 * abs(loss.item())
     assert abs(r1["loss"].item() - loss.item()) < 1e-5 * abs(loss.item())
     assert torch.equal(r0["flat"], r1["flat"])
-    assert rel_err(r0["flat"], flat) < 2e-3
+    assert r0["order"] == r1["order"] and len(r0["order"]) == (3 if with_text else 2)   # same collectives, same order, every rank
+    # full fine-tuning: the all-reduced buffers are the whole encoders (0.35 / 0.35 / 0.12 GB at full depth), every parameter's
+    # gradient is in `flat`; fp8 trunks: per-sample quantisation is batch-independent (scale 1 / per-row weight scales)
+    assert rel_err(r0["flat"], flat) < (5e-3 if mode == "fullft" else 2e-3)
 
 
 @pytest.mark.timeout(900)

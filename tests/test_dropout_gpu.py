@@ -61,6 +61,35 @@ def test_gemm_resid_dropout_and_layernorm_bwd_share_the_mask(ops):
     assert rel_err(dx16.float()[kept], (dx32 / (1 - P))[kept]) < 4e-3
 
 
+def test_masks_of_successive_steps_are_independent(ops):
+    """with the step added linearly to the seed, step s+1's mask was step s's mask slid by one element pair.  The
+    step word now goes through the mixer: masks of steps s and s+1 (and of two engines' seeds) agree at every small shift only
+    as often as independent masks do (p^2 + (1-p)^2 = 0.82 at p = 0.1; a shifted copy agrees everywhere)."""
+    from bioscanclip.hip.lib import EPI_RESID_F32
+    M, N, K = 512, 768, 64
+    a, w = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16), torch.zeros(N, K, device="cuda", dtype=torch.bfloat16)
+    bias, resid = torch.ones(N, device="cuda"), torch.zeros(M, N, device="cuda")
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    masks = []
+    try:
+        ops.set_dropout_step(word)
+        for s in range(4):
+            ops.counter_add(word, 1)
+            out = torch.empty(M, N, device="cuda")
+            ops.gemm(a, w, out, EPI_RESID_F32, bias=bias, resid=resid, dropout=(P, 4321))
+            masks.append((out != 0).flatten())
+    finally:
+        ops.set_dropout_step(None)
+    want = P * P + (1 - P) * (1 - P)
+    for s in range(3):
+        m0, m1 = masks[s], masks[s + 1]
+        assert abs(m1.float().mean().item() - (1 - P)) < 5e-3
+        for shift in range(-8, 9):
+            x, y = (m0[shift:], m1[:m1.numel() - shift]) if shift >= 0 else (m0[:shift], m1[-shift:])
+            agree = (x == y).float().mean().item()
+            assert abs(agree - want) < 1e-2, (s, shift, agree)
+
+
 def test_layernorm_fwd_dropout(ops):
     M, H = 2000, 768
     x = rnd(M, H, seed=1)

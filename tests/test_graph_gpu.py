@@ -82,14 +82,59 @@ def test_adamw_device_hyper_equals_host_arguments():
     p0 = torch.randn(n, generator=g).cuda()
     pa, pb = p0.clone(), p0.clone()
     ma, va, mb, vb = (torch.zeros(n, device="cuda") for _ in range(4))
-    hyper = torch.zeros(2, device="cuda")
+    hyper = torch.zeros(2, dtype=torch.int32, device="cuda")   # [lr as f32 bits, step as uint32]
     for step in range(1, 40):
         gr = torch.randn(n, generator=g).cuda()
         lr = 1e-3 * (1 + 0.1 * step)
         ops.adamw_step(pa, gr, ma, va, lr, 0.9, 0.999, 1e-8, 0.01, step)
-        hyper.copy_(torch.tensor([lr, float(step)]))
+        hyper.view(torch.float32)[0:1].fill_(lr)
+        ops.counter_add(hyper[1:2], 1)                          # the device advances its own step word
         ops.adamw_step_dev(pb, gr, mb, vb, hyper, 0.9, 0.999, 1e-8, 0.01)
+    assert int(hyper[1].item()) == 39
     assert rel_err(pb, pa) < 1e-7
+
+
+def test_graph_replays_without_per_step_sync_equal_eager():
+    """nothing a replay reads may live in host memory the host rewrites for the next step.  Replays are enqueued
+    back to back with a moving LR and NO synchronisation (the way bench.py's timed loop runs) and must end bit for bit where
+    the eager loop ends; the two param groups carry different learning rates (each flat buffer follows its own group)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bioscanclip.hip.graph import GraphedStep
+    from bioscanclip.hip.optim import FusedAdamW
+    from bioscanclip.model.loss_func import ContrastiveLoss
+    steps = 24
+    image, dna, text, label = synth.synth_batch(16, seed=311)
+    image, dna, label = image.cuda(), dna.cuda(), label.cuda()
+    finals = {}
+    for mode in ("eager", "graph"):
+        model = _build(92, False)
+        groups = [{"params": list(model.image_encoder.parameters()), "lr": 1e-3},
+                  {"params": list(model.dna_encoder.parameters()), "lr": 4e-4}]
+        opt = FusedAdamW(groups, lr=1e-3)
+        opt.enable_device_hyper(True)
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=[3e-3, 1.2e-3], total_steps=steps, pct_start=0.3,
+                                                    anneal_strategy="cos", cycle_momentum=False)
+        crit = ContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)
+        g = GraphedStep(model, opt, crit, warmup=2) if mode == "graph" else None
+        for s in range(steps):
+            if g is not None:
+                loss = g(image, dna, None, label)
+            else:
+                opt.zero_grad()
+                loss = crit(*model(image, dna, None), label)
+                loss.backward()
+                if opt.needs_attach():
+                    opt.attach(model)
+                opt.step()
+            sched.step()                                        # no loss.item(), no synchronize inside the loop
+        torch.cuda.synchronize()
+        finals[mode] = (float(loss), {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad},
+                        [int(st["step"]) for st in opt._flat_state.values()])
+    assert finals["eager"][2] == finals["graph"][2] == [steps, steps]
+    assert finals["eager"][0] == finals["graph"][0]
+    for k, v in finals["eager"][1].items():
+        assert torch.equal(v, finals["graph"][1][k]), k
 
 
 def test_optimizer_state_survives_rebuild_and_state_dict_roundtrip():
