@@ -42,7 +42,8 @@ def _build(with_text=False, mode="lora"):
 
 
 def _flat_grads(model):
-    return torch.cat([p.grad.reshape(-1) for _, p in sorted(model.named_parameters()) if p.requires_grad]).cpu()
+    # full fine-tuning: a few parameters sit off the path (BERT pooler, the dangling MLM bias) and never receive a gradient
+    return torch.cat([p.grad.reshape(-1) for _, p in sorted(model.named_parameters()) if p.requires_grad and p.grad is not None]).cpu()
 
 
 def _cuda(text):

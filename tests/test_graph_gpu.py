@@ -129,7 +129,7 @@ def test_graph_replays_without_per_step_sync_equal_eager():
                 opt.step()
             sched.step()                                        # no loss.item(), no synchronize inside the loop
         torch.cuda.synchronize()
-        finals[mode] = (float(loss), {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad},
+        finals[mode] = (float(loss.detach()), {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad},
                         [int(st["step"]) for st in opt._flat_state.values()])
     assert finals["eager"][2] == finals["graph"][2] == [steps, steps]
     assert finals["eager"][0] == finals["graph"][0]
