@@ -11,6 +11,7 @@ Everything numerical happens in ``libbsclip_hip.so``; this file decides *which* 
     sub-layer, bf16 GEMM operands, attention LSE, LN statistics).
 Reference call shapes: SURVEY.md 2.3 (K1-K15), 3.2; semantics App. A.1-A.3.
 """
+import os
 import zlib
 
 import torch
@@ -20,6 +21,11 @@ from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_GELU_FP8
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+# Residual-GRADIENT stream dtype of the LoRA-regime backward (the gradient that flows down the skip connections, read and
+# written by every LayerNorm backward): "bf16" halves its bytes (LN backward is HBM-bound: 16 -> 10-12 bytes per element);
+# the forward and the parameter gradients' f32 accumulation are unchanged.  "f32" restores round 2's behaviour.  Full
+# fine-tuning keeps f32 (its LayerNorm parameter gradients read the same stream).
+GRAD_STREAM_BF16 = os.environ.get("BSCLIP_GRAD_STREAM", "bf16").lower() != "f32"
 
 
 def _bf16(w, dev):
@@ -247,7 +253,8 @@ class ViTEngine(EncoderEngineBase):
         ws["clsn"] = z(B, H)
         ws["st_f"] = z(B, 2, dt=F32)
         # backward temporaries
-        ws["dx"] = torch.zeros(M, H, dtype=F32, device=dev)
+        ws["grad_bf16"] = GRAD_STREAM_BF16 and not self.full_ft
+        ws["dx"] = None if ws["grad_bf16"] else torch.zeros(M, H, dtype=F32, device=dev)
         ws["dxb"] = torch.zeros(M, H, dtype=BF16, device=dev)
         ws["dz"] = z(M, FF)
         ws["dh"] = z(M, H)
@@ -336,10 +343,15 @@ class ViTEngine(EncoderEngineBase):
         ops.transpose_bf16(self.w_head_bf, self.out_dim, H, self.w_head_t)
         ops.gemm(ws["dout_bf"], self.w_head_t, ws["dclsn"], EPI_BF16)
         # final norm on token-0 rows only: every other row of the residual gradient is zero
-        dx.zero_()
+        # bf16 gradient stream (no dropout in the ViT): the bf16 operand buffer IS the residual gradient, read and rewritten
+        # in place by each LayerNorm backward (same lane, same elements); the f32 copy does not exist
+        gb = ws["grad_bf16"]
+        R = dxb if gb else dx          # the residual-gradient stream
+        if not gb:
+            dx.zero_()
         dxb.zero_()
         ops.layernorm_bwd(x[-1].view(B, S * H)[:, :H], ws["st_f"], self.ln_f[0], 0, g_gemm=ws["dclsn"],
-                          dx_f32=dx.view(B, S * H)[:, :H], dx_bf16=dxb.view(B, S * H)[:, :H])
+                          dx_f32=None if gb else dx.view(B, S * H)[:, :H], dx_bf16=dxb.view(B, S * H)[:, :H])
         L = len(self.layers)
         for l in range(L - 1, -1, -1):
             lay = self.layers[l]
@@ -351,16 +363,16 @@ class ViTEngine(EncoderEngineBase):
                 dxb_c = dxb.view(B, S * H)[:, :H]
                 ops.gemm(dxb_c, lay.w_fc2_t, ws["dz_c"], EPI_DGELU_BF16, aux=ws["z_c"])
                 ops.gemm(ws["dz_c"], lay.w_fc1_t, ws["dh_c"], EPI_BF16)
-                dx_c = dx.view(B, S * H)[:, :H]
+                dx_c = R.view(B, S * H)[:, :H]
                 ops.layernorm_bwd(x[2 * l + 1].view(B, S * H)[:, :H], ws["st_c"], lay.ln2[0], 0, g_resid=dx_c,
-                                  g_gemm=ws["dh_c"], dx_f32=dx_c, dx_bf16=dxb_c)
+                                  g_gemm=ws["dh_c"], dx_f32=None if gb else dx_c, dx_bf16=dxb_c)
                 ws["dctx"].zero_()
                 ops.gemm(dxb_c, lay.w_proj_t, ws["dctx"].view(B, S * H)[:, :H], EPI_BF16)
             else:
                 ops.gemm(dxb, lay.w_fc2_t, ws["dz"], EPI_DGELU_BF16, aux=ws["z"][l])
                 ops.gemm(ws["dz"], lay.w_fc1_t, ws["dh"], EPI_BF16)
-                ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh"], dx_f32=dx,
-                                  dx_bf16=dxb)
+                ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=R, g_gemm=ws["dh"],
+                                  dx_f32=None if gb else dx, dx_bf16=dxb)
                 ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
             ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
                          q_rows=1 if l == L - 1 else 0)
@@ -374,9 +386,9 @@ class ViTEngine(EncoderEngineBase):
                     ops.lora_grad(ws["dqkv"], ws["h1"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gb[0], gb[1])
             if l > 0:  # nothing trainable sits below block 0 (patch-embed, cls, pos are frozen)
                 ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
-                ops.layernorm_bwd(x[2 * l], ws["st1"][l], lay.ln1[0], 0, g_resid=dx, g_gemm=ws["dh"],
+                ops.layernorm_bwd(x[2 * l], ws["st1"][l], lay.ln1[0], 0, g_resid=R, g_gemm=ws["dh"],
                                   dt=ws["dt"] if lb is not None else None,
-                                  lora_a=self.lora_a(l) if lb is not None else None, dx_f32=dx, dx_bf16=dxb)
+                                  lora_a=self.lora_a(l) if lb is not None else None, dx_f32=None if gb else dx, dx_bf16=dxb)
 
 
 # ======================================================================================================= BERT
@@ -479,9 +491,11 @@ class BertEngine(EncoderEngineBase):
         ws["key_bias"] = None
         ws["kb_buf"] = z(B, S, dt=F32)
         # backward temporaries
-        ws["ds"] = z(M, H, dt=F32)
+        ws["grad_bf16"] = GRAD_STREAM_BF16 and not self.full_ft
+        gdt = BF16 if ws["grad_bf16"] else F32       # residual-gradient stream (see GRAD_STREAM_BF16)
+        ws["ds"] = z(M, H, dt=gdt)
         ws["dsb"] = z(M, H)
-        ws["ds1"] = z(M, H, dt=F32)
+        ws["ds1"] = z(M, H, dt=gdt)
         ws["dz"] = z(M, FF)
         ws["dh"] = z(M, H)
         ws["dctx"] = z(M, H)
@@ -642,16 +656,19 @@ class BertEngine(EncoderEngineBase):
             ops.meanpool_tokens_bwd(ws["dmp"], B, S, ws["dyl"])
             g_resid, g_gemm = ws["dyl"], None
         dt_in, a_in = None, None
+        gb = ws["grad_bf16"]
         for l in range(L - 1, -1, -1):
             lay = self.layers[l]
-            # dsb is the operand of fc2's dX GEMM: it carries the mask fc2's forward output was dropped with
+            # dsb is the operand of fc2's dX GEMM: it carries the mask fc2's forward output was dropped with.  With the bf16
+            # gradient stream and no dropout the operand IS the residual gradient: one output, rewritten in place next time
+            drop_b, drop_a = self._drop(ws, self.p_hidden, l, 3), self._drop(ws, self.p_hidden, l, 2)
+            one_b, one_a = gb and drop_b is None, gb and drop_a is None
             ops.layernorm_bwd(ws["s2"][l], ws["stb"][l], lay.ln_b[0], 1, g_resid=g_resid, g_gemm=g_gemm, dt=dt_in,
-                              lora_a=a_in, dx_f32=ws["ds"], dx_bf16=ws["dsb"],
-                              dropout=self._drop(ws, self.p_hidden, l, 3))
+                              lora_a=a_in, dx_f32=None if one_b else ws["ds"], dx_bf16=ws["dsb"], dropout=drop_b)
             ops.gemm(ws["dsb"], lay.w_fc2_t, ws["dz"], EPI_DGELU_BF16, aux=ws["z"][l])
             ops.gemm(ws["dz"], lay.w_fc1_t, ws["dh"], EPI_BF16)
-            ops.layernorm_bwd(ws["s1"][l], ws["sta"][l], lay.ln_a[0], 1, g_resid=ws["ds"], g_gemm=ws["dh"],
-                              dx_f32=ws["ds1"], dx_bf16=ws["dsb"], dropout=self._drop(ws, self.p_hidden, l, 2))
+            ops.layernorm_bwd(ws["s1"][l], ws["sta"][l], lay.ln_a[0], 1, g_resid=ws["dsb"] if one_b else ws["ds"], g_gemm=ws["dh"],
+                              dx_f32=None if one_a else ws["ds1"], dx_bf16=ws["dsb"], dropout=drop_a)
             ops.gemm(ws["dsb"], lay.w_o_t, ws["dctx"], EPI_BF16)
             ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
                          key_bias=ws["key_bias"], dropout=self._drop(ws, self.p_attn, l, 1))
@@ -665,7 +682,7 @@ class BertEngine(EncoderEngineBase):
                     ops.lora_grad(ws["dqkv"], ws["yb"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gbb[0], gbb[1])
             if l > 0:  # embeddings are frozen: nothing to do below layer 0
                 ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
-                g_resid, g_gemm = ws["ds1"], ws["dh"]
+                g_resid, g_gemm = (ws["dsb"] if one_a else ws["ds1"]), ws["dh"]
                 dt_in, a_in = (ws["dt"], self.lora_a(l)) if lb is not None else (None, None)
         ops.set_dropout_step(None)
 

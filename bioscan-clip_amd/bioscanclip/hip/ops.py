@@ -200,6 +200,8 @@ def layernorm_fwd_fp8(x, gamma, beta, eps, y_fp8, t_aug=None, y_f32=None, lora_a
 
 def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lora_a=None, dx_f32=None, dx_bf16=None,
                   M=None, dropout=None, in_dropout=None):
+    """``g_resid`` / ``dx_f32`` are the residual-gradient stream in / out: f32, or bf16 (half the bytes; the dtype of each
+    tensor is passed on as ``resid_flags``).  ``dx_bf16`` is the next dX GEMM's operand (carries ``dropout``'s mask)."""
     ld_x = _rowmajor(x, "x")
     H = gamma.numel()
     M = x.shape[0] if M is None else M
@@ -208,7 +210,7 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
     ld_g = ld_dxb = ld_gr = ld_dx = 0
     if g_resid is not None:
         ld_gr = _rowmajor(g_resid, "g_resid")
-        _req(g_resid.dtype == F32 and g_resid.shape[0] >= M and g_resid.shape[1] >= H, "g_resid must be f32 [M,>=H]")
+        _req(g_resid.dtype in (F32, BF16) and g_resid.shape[0] >= M and g_resid.shape[1] >= H, "g_resid must be f32 / bf16 [M,>=H]")
     if g_gemm is not None:
         ld_g = _rowmajor(g_gemm, "g_gemm")
         _req(g_gemm.dtype == BF16 and g_gemm.shape[0] >= M and g_gemm.shape[1] >= H, "g_gemm must be bf16 [M,>=H]")
@@ -218,7 +220,7 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
              "lora_a must be f32 [8,H]")
     if dx_f32 is not None:
         ld_dx = _rowmajor(dx_f32, "dx_f32")
-        _req(dx_f32.dtype == F32 and dx_f32.shape[0] >= M and dx_f32.shape[1] >= H, "dx_f32 must be f32 [M,>=H]")
+        _req(dx_f32.dtype in (F32, BF16) and dx_f32.shape[0] >= M and dx_f32.shape[1] >= H, "dx_f32 must be f32 / bf16 [M,>=H]")
     if dx_bf16 is not None:
         ld_dxb = _rowmajor(dx_bf16, "dx_bf16")
         _req(dx_bf16.dtype == BF16 and dx_bf16.shape[0] >= M and dx_bf16.shape[1] >= H, "dx_bf16 too small")
@@ -228,7 +230,9 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
                                          0.0 if dropout is None else float(dropout[0]),
                                          0 if dropout is None else int(dropout[1]) & 0xFFFFFFFF,
                                          0.0 if in_dropout is None else float(in_dropout[0]),
-                                         0 if in_dropout is None else int(in_dropout[1]) & 0xFFFFFFFF, _stream()))
+                                         0 if in_dropout is None else int(in_dropout[1]) & 0xFFFFFFFF,
+                                         (1 if g_resid is not None and g_resid.dtype == BF16 else 0)
+                                         | (2 if dx_f32 is not None and dx_f32.dtype == BF16 else 0), _stream()))
 
 
 def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, q_rows=0):

@@ -171,11 +171,15 @@ __device__ __forceinline__ float fp8_to_f32(unsigned w, int byte) {  // byte is 
 // size of the bf16 rounding of a value near 1 (2^-9 .. 2^-8) -- at half the bytes of the bf16 band it replaces
 // (fc1 wrote 12 KB per row, now 9 KB; dfc2 read 6 KB of side band per row, now 3 KB).
 constexpr float DG8_OFF = 0.13f, DG8_SCALE = 255.0f / 1.26f, DG8_STEP = 1.26f / 255.0f;
-__device__ __forceinline__ unsigned dg8_code(float g) {
-    return (unsigned)(int)__builtin_amdgcn_fmed3f(fmaf(g, DG8_SCALE, DG8_OFF * DG8_SCALE + 0.5f), 0.0f, 255.0f);
-}
+// v_cvt_pk_u8_f32 converts (round to nearest even, saturating to [0, 255]: tools/probe/cvt_pk_u8_probe.hip) AND inserts the byte
+// into a dword: one instruction per value where clamp + convert + shift/or took four (the GELU epilogue is VALU-bound).
 __device__ __forceinline__ unsigned dg8_pack4(float a, float b, float c, float d) {
-    return dg8_code(a) | (dg8_code(b) << 8) | (dg8_code(c) << 16) | (dg8_code(d) << 24);
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(a, DG8_SCALE, DG8_OFF * DG8_SCALE), 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(b, DG8_SCALE, DG8_OFF * DG8_SCALE), 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(c, DG8_SCALE, DG8_OFF * DG8_SCALE), 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, DG8_SCALE, DG8_OFF * DG8_SCALE), 3, w);
+    return w;
 }
 __device__ __forceinline__ f32x4 dg8_unpack4(unsigned w) {
     return f32x4{fmaf((float)(w & 0xff), DG8_STEP, -DG8_OFF), fmaf((float)((w >> 8) & 0xff), DG8_STEP, -DG8_OFF),

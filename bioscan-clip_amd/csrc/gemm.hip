@@ -552,12 +552,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             readA(base, 0);
             readB(base, 0);
             PP_BARRIER();
-            mma(0, 0);
+            mma(0, 0, std::true_type{});
             PP_BARRIER();
             // ---- phase 1 ----
             readA(base, 1);
             PP_BARRIER();
-            mma(1, 0);
+            mma(1, 0, std::true_type{});
             PP_BARRIER();
             // ---- phase 2 ----
             readB(base, 1);
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 dmaA(set, 0, k2);
                 dmaA(set, 1, k2);
             }
-            mma(1, 1);
+            mma(1, 1, std::true_type{});
             PP_BARRIER();
             // ---- phase 3 ----
             if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile t+1 complete; A of tile t+2 may fly
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 dmaB(set, 0, k2);
                 dmaB(set, 1, k2);
             }
-            mma(0, 1);
+            mma(0, 1, std::true_type{});
             PP_BARRIER();
         }
     } else if constexpr (SCHED == 2) {
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             readA(base, 0);
             readB(base, 0);
             BAR_G0();
-            mma(0, 0);
+            mma(0, 0, std::true_type{});
             // ---- phase 1 ----
             BAR_G1();
             if (has1) {
@@ -638,13 +638,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             }
             readA(base, 1);
             BAR_G0();
-            mma(1, 0);
+            mma(1, 0, std::true_type{});
             // ---- phase 2 ----
             BAR_G1();
             if (has1 && g == 0) dmaB(set ^ 1, 1, k1);
             readB(base, 1);
             BAR_G0();
-            mma(1, 1);
+            mma(1, 1, std::true_type{});
             // ---- phase 3 ----
             if (g == 0) {
                 if (has2) {
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 dmaA(set, 0, k2);
                 dmaA(set, 1, k2);
             }
-            mma(0, 1);
+            mma(0, 1, std::true_type{});
         }
 #undef BAR_G0
 #undef BAR_G1
@@ -1071,6 +1071,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     stamp(3);
 }
 
+#include "gemm_duo.h"
+
 int g_tile_override = 0;
 [[maybe_unused]] int g_diag_ablate = 0;  // tools/gemm_ablate.py: which parts of the K loop the diagnostic EPI_BF16 build leaves out
 
@@ -1112,6 +1114,7 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
     if ((tile == 3 || tile == 4 || tile == 6 || tile == 7) && N % 256 != 0) tile = 2;
     switch (tile) {
         case 4: launch_pp<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
+        case 5: launch_duo<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
 #ifdef BSCLIP_DIAG
         case 6: launch_pp<EPI, HB, 1>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // two-tiles-ahead DMA (comparison)
         case 7: launch_pp<EPI, HB, 2>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // four barriers per K-tile (experimental)
@@ -1191,6 +1194,45 @@ extern "C" int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, 
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }
+
+// The duo kernel with per-workgroup stamps: diag[grid * 8] = {start, tile 0 landed, K loop done, end, HW_ID, XCC_ID, -, -}.
+// tools/gemm_duo_phases.py reads co-residency (two workgroups with overlapping lifetimes on one CU) and section times from it.
+extern "C" int bsclip_gemm_duo_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                    int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream) {
+    BSCLIP_REQUIRE(A && B && C && diag && args, "bsclip_gemm_duo_diag: null pointer");
+    BSCLIP_REQUIRE(K % 64 == 0 && N % 128 == 0, "bsclip_gemm_duo_diag: K %% 64, N %% 128");
+    EpiArgs e{};
+    e.bias = args->bias;
+    e.resid = args->resid;
+    e.ld_resid = args->ld_resid;
+    e.aux = static_cast<unsigned char*>(args->aux);
+    e.ld_aux = args->ld_aux;
+    e.drop = make_drop(0.f, 0);
+    e.n_total = N;
+    e.diag = diag;
+    const int tiles_m = ceil_div(M, 256), tiles_n = N / 128;
+    const dim3 grid(tiles_m * tiles_n), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16_t* a = static_cast<const bf16_t*>(A);
+    const bf16_t* b = static_cast<const bf16_t*>(B);
+    switch (epilogue) {
+        case BSCLIP_EPI_BF16:
+            hipLaunchKernelGGL((gemm_nt_duo_kernel<BSCLIP_EPI_BF16, false, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
+            break;
+        case BSCLIP_EPI_GELU_BF16:
+            hipLaunchKernelGGL((gemm_nt_duo_kernel<BSCLIP_EPI_GELU_BF16, true, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
+            break;
+        case BSCLIP_EPI_RESID_F32:
+            hipLaunchKernelGGL((gemm_nt_duo_kernel<BSCLIP_EPI_RESID_F32, true, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
+            break;
+        case BSCLIP_EPI_DGELU_BF16:
+            hipLaunchKernelGGL((gemm_nt_duo_kernel<BSCLIP_EPI_DGELU_BF16, false, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, e);
+            break;
+        default: BSCLIP_REQUIRE(false, "bsclip_gemm_duo_diag: epilogue %d has no diagnostic build", epilogue);
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
 #endif  // BSCLIP_DIAG
 
 // Fills the device-side GELU table.  Stream-ordered; the GEMM entry point also does this lazily on its own stream, so a
@@ -1205,9 +1247,9 @@ extern "C" int bsclip_init_tables(void* stream) {
 
 extern "C" int bsclip_gemm_set_tile(int tile) {
 #ifdef BSCLIP_DIAG
-    BSCLIP_REQUIRE(tile >= 0 && tile <= 7 && tile != 5, "bsclip_gemm_set_tile: tile %d not in {0,1,2,3,4,6,7}", tile);
+    BSCLIP_REQUIRE(tile >= 0 && tile <= 7, "bsclip_gemm_set_tile: tile %d not in 0..7", tile);
 #else
-    BSCLIP_REQUIRE(tile >= 0 && tile <= 4, "bsclip_gemm_set_tile: tile %d not in {0,1,2,3,4}", tile);
+    BSCLIP_REQUIRE(tile >= 0 && tile <= 5, "bsclip_gemm_set_tile: tile %d not in 0..5", tile);
 #endif
     g_tile_override = tile;
     return BSCLIP_OK;

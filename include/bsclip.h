@@ -103,7 +103,8 @@ int bsclip_lora_baug_set(void* b_aug, int ld_b, int H, const float* lora_bq, con
 /* one-time device tables (GELU Phi/phi table of the 256x256 kernel's epilogue).  bsclip_gemm_bf16 fills them lazily on
  * its own stream; call this once (and synchronise) before launching GEMMs from several streams. */
 int bsclip_init_tables(void* stream);
-/* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x256 ping-pong; the diagnostic
+/* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x256 ping-pong,
+ * 5 = the 256x128 kernel that runs two workgroups per CU (csrc/gemm_duo.h); the diagnostic
  * library (-DBSCLIP_DIAG, `make diag`) adds 6 = ping-pong with the LDS-DMA two K-tiles ahead (slower) and 7 = four instead of
  * eight barriers per K-tile (equal), kept for comparison only */
 int bsclip_gemm_set_tile(int tile);
@@ -116,6 +117,10 @@ int bsclip_gemm_set_tile(int tile);
 int bsclip_gemm_diag_ablate(int mask);
 int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream);
+/* the 256x128 two-workgroups-per-CU kernel (bsclip_gemm_set_tile(5)) with per-workgroup stamps, diag[grid * 8] = {start, tile 0
+ * landed, K loop done, end, HW_ID, XCC_ID, -, -}: section times and co-residency; tools/gemm_duo_phases.py */
+int bsclip_gemm_duo_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                         int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream);
 /* the attention backward kernel (S = 197 or 133, no mask, no dropout) with per-wave section stamps in 100 MHz ticks,
  * diag[B*heads*4*8]; tools/attn_phases.py */
 int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
@@ -147,10 +152,13 @@ int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, cons
 int bsclip_layernorm_fwd_fp8(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma, const float* beta,
                              float eps, void* y_fp8, int ld_y, void* t_aug, int ld_t, float* y_f32, const float* lora_a,
                              float* stats, float dropout_p, uint32_t dropout_seed, void* stream);
+/* resid_flags: the residual-gradient stream (g_resid in, dx_f32 out) may be kept in bf16 -- bit 0: g_resid is bf16 [M, ld_gr],
+ *   bit 1: dx_f32 points to a bf16 [M, ld_dx] buffer (the undropped gradient, rounded once); 0 = both f32. */
 int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M, int H,
-                         const float* g_resid, int ld_gr, const void* g_gemm, int ld_g, const float* dt,
-                         const float* lora_a, int mode, float* dx_f32, int ld_dx, void* dx_bf16, int ld_dxb,
-                         float dropout_p, uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, void* stream);
+                         const void* g_resid, int ld_gr, const void* g_gemm, int ld_g, const float* dt,
+                         const float* lora_a, int mode, void* dx_f32, int ld_dx, void* dx_bf16, int ld_dxb,
+                         float dropout_p, uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed,
+                         int resid_flags, void* stream);
 
 /* ---- self-attention (timm Attention.forward; HF BertSelfAttention) ---------------------------------------------
  * qkv bf16 [B*S, ld_qkv] with columns [q | k | v], each heads*64 wide; ctx bf16 [B*S, ld_ctx];

@@ -32,13 +32,13 @@ def test_gemm_resid_dropout_and_layernorm_bwd_share_the_mask(ops):
     bias, resid = rnd(N, seed=3), rnd(M, N, seed=4)
     ref = a.float() @ w.float().t() + bias
     outs = {}
-    for tile in (1, 4):
+    for tile in (1, 4, 5):
         ops.set_gemm_tile(tile)
         out = torch.empty(M, N, device="cuda")
         ops.gemm(a, w, out, EPI_RESID_F32, bias=bias, resid=resid, dropout=(P, 1234))
         outs[tile] = out - resid
     ops.set_gemm_tile(0)
-    assert torch.equal(outs[1] == 0, outs[4] == 0), "mask must not depend on the kernel/tile layout"
+    assert torch.equal(outs[1] == 0, outs[4] == 0) and torch.equal(outs[5] == 0, outs[4] == 0), "mask must not depend on the kernel/tile layout"
     d = outs[4]
     kept = d != 0
     assert abs(kept.float().mean().item() - (1 - P)) < 5e-3

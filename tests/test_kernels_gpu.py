@@ -40,7 +40,7 @@ def dgelu(x):
 
 
 # ------------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 64), (300, 256, 128), (1000, 768, 832), (2500, 512, 576), (197 * 8, 2304, 832),
                                    (5120, 768, 3072)])
 def test_gemm_epilogues(ops, tile, M, N, K):
@@ -90,7 +90,7 @@ def test_gemm_layout_identity(ops):
     a = torch.eye(K, device="cuda", dtype=torch.bfloat16)
     b = (torch.arange(N, device="cuda")[:, None] * 2 + torch.arange(K, device="cuda")[None, :] % 7).float()
     b = b.bfloat16()
-    for tile in (1, 2, 3, 4):
+    for tile in (1, 2, 3, 4, 5):
         ops.set_gemm_tile(tile)
         out = torch.empty(K, N, device="cuda")
         ops.gemm(a, b, out, EPI_F32)

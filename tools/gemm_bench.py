@@ -10,6 +10,7 @@ from bioscanclip.hip import ops  # noqa: E402
 from bioscanclip.hip.lib import EPI_BF16, EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32  # noqa: E402
 
 B = int(os.environ.get("B", "256"))
+TILES = tuple(int(t) for t in os.environ.get("TILES", "1,2,3,4,5").split(","))
 SHAPES = []
 for name, M in (("vit", B * 197), ("dna", B * 133)):
     SHAPES += [(f"{name}.qkv", M, 2304, 832, EPI_BF16), (f"{name}.proj", M, 768, 768, EPI_RESID_F32),
@@ -31,7 +32,7 @@ def run(M, N, K, epi, iters):
         kw["aux"] = torch.randint(0, 256, (M, N), device="cuda", dtype=torch.uint8)
     res = {}
     for rnd in range(3):
-        for tile in (1, 2, 3, 4):
+        for tile in TILES:
             ops.set_gemm_tile(tile)
             ops.gemm(a, w, out, epi, bias=bias, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -59,14 +60,14 @@ def run(M, N, K, epi, iters):
     return {t: min(v) for t, v in res.items()}
 
 
-tot = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0, "best": 0.0, "lib": 0.0}
+tot = {**{t: 0.0 for t in TILES}, "best": 0.0, "lib": 0.0}
 for name, M, N, K, epi in SHAPES:
     r = run(M, N, K, epi, 10)
     fl = 2.0 * M * N * K
     best = min((t for t in r if t != 'lib'), key=r.get)
     print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}  " + "  ".join(
-        f"t{t}: {r[t]*1e3:7.1f}us {fl/r[t]/1e9:7.1f}TF" for t in (1, 2, 3, 4, "lib")) + f"   best=t{best}", flush=True)
-    for t in (1, 2, 3, 4, "lib"):
+        f"t{t}: {r[t]*1e3:7.1f}us {fl/r[t]/1e9:7.1f}TF" for t in TILES + ("lib",)) + f"   best=t{best}", flush=True)
+    for t in TILES + ("lib",):
         tot[t] += r[t]
     tot["best"] += r[best]
 print("sum per layer (ms):", {k: round(v, 3) for k, v in tot.items()})
