@@ -17,7 +17,8 @@ import zlib
 import torch
 
 from . import ops
-from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_GELU_FP8, EPI_PATCH_F32, EPI_RESID_F32, KPAD)
+from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_GELU_FP8, EPI_PATCH_BF16, EPI_PATCH_F32, EPI_RESID_BF16,
+                  EPI_RESID_F32, KPAD)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -26,6 +27,13 @@ F32 = torch.float32
 # the forward and the parameter gradients' f32 accumulation are unchanged.  "f32" restores round 2's behaviour.  Full
 # fine-tuning keeps f32 (its LayerNorm parameter gradients read the same stream).
 GRAD_STREAM_BF16 = os.environ.get("BSCLIP_GRAD_STREAM", "bf16").lower() != "f32"
+# Residual stream dtype of the FORWARD (the tensor every sub-layer adds its output to; saved per sub-layer as the LayerNorm
+# backward's input).  "bf16": each sum is formed in f32 in the GEMM epilogue and rounded once on the way to HBM; the
+# out-projection / fc2 epilogues move 4 instead of 8 bytes per element, LayerNorm forward reads 2 instead of 4 (BERT: writes no
+# f32 copy either), LayerNorm backward reads 2 instead of 4, and the saved stream halves (3.9 -> 2.0 GB for the ViT at B = 256).
+# Cost, measured on the CPU oracle at depth 12: the distance to the f32 reference grows by ~10 % (2.5e-2 -> 2.8e-2),
+# the gradients' not at all.  "f32" restores round 2's stream.  Full fine-tuning and fp8 trunks keep f32.
+RESID_STREAM_BF16 = os.environ.get("BSCLIP_RESID_STREAM", "bf16").lower() != "f32"
 
 
 def _bf16(w, dev):
@@ -233,7 +241,8 @@ class ViTEngine(EncoderEngineBase):
         z = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
         ws = {"B": B, "M": M}
         ws["cols"] = z(B * 196, H)
-        ws["x"] = [z(M, H, dt=F32) for _ in range(2 * L + 1)]         # residual stream after every sub-layer
+        rb = ws["resid_bf16"] = RESID_STREAM_BF16 and not self.full_ft and not self.fp8
+        ws["x"] = [z(M, H, dt=BF16 if rb else F32) for _ in range(2 * L + 1)]   # residual stream after every sub-layer
         ws["h1"] = [z(M, H + KPAD) for _ in range(L)]                 # LN1 output + LoRA t (QKV operand)
         ws["st1"] = [z(M, 2, dt=F32) for _ in range(L)]
         ws["st2"] = [z(M, 2, dt=F32) for _ in range(L)]
@@ -280,8 +289,9 @@ class ViTEngine(EncoderEngineBase):
         self.refresh_lora_weights()
         ops.cast_f32_bf16(self.extra(0), self.w_head_bf)
         x = ws["x"]
+        EPI_R, EPI_P = (EPI_RESID_BF16, EPI_PATCH_BF16) if ws["resid_bf16"] else (EPI_RESID_F32, EPI_PATCH_F32)
         ops.im2col_patch16(image, ws["cols"])
-        ops.gemm(ws["cols"], self.w_patch, x[0], EPI_PATCH_F32, bias=self.b_patch, resid=self.pos)
+        ops.gemm(ws["cols"], self.w_patch, x[0], EPI_P, bias=self.b_patch, resid=self.pos)
         ops.vit_cls_rows(x[0], self.cls, self.pos, B, S, H)
         L = len(self.layers)
         for l, lay in enumerate(self.layers):
@@ -300,16 +310,16 @@ class ViTEngine(EncoderEngineBase):
                 # the B token-0 rows (row stride S*H) instead of all B*197.  Same values, 1/197 of the GEMM work.
                 tok0 = lambda t, w: t.view(B, S * w)[:, :w]
                 ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], q_rows=1)
-                ops.gemm(tok0(ws["ctx"][l], H), lay.w_proj, tok0(x[2 * l + 1], H), EPI_RESID_F32, bias=lay.b_proj,
+                ops.gemm(tok0(ws["ctx"][l], H), lay.w_proj, tok0(x[2 * l + 1], H), EPI_R, bias=lay.b_proj,
                          resid=tok0(x[2 * l], H))
                 ops.layernorm_fwd(tok0(x[2 * l + 1], H), lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2_c"],
                                   stats=ws["st_c"])
                 ops.gemm(ws["h2_c"], lay.w_fc1, ws["act_c"], EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z_c"])
-                ops.gemm(ws["act_c"], lay.w_fc2, tok0(x[2 * l + 2], H), EPI_RESID_F32, bias=lay.b_fc2,
+                ops.gemm(ws["act_c"], lay.w_fc2, tok0(x[2 * l + 2], H), EPI_R, bias=lay.b_fc2,
                          resid=tok0(x[2 * l + 1], H))
                 continue
             ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l])
-            ops.gemm(ws["ctx"][l], lay.w_proj, x[2 * l + 1], EPI_RESID_F32, bias=lay.b_proj, resid=x[2 * l])
+            ops.gemm(ws["ctx"][l], lay.w_proj, x[2 * l + 1], EPI_R, bias=lay.b_proj, resid=x[2 * l])
             if self.fp8:
                 ops.layernorm_fwd_fp8(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, ws["h2_8"], stats=ws["st2"][l])
                 ops.gemm_fp8(ws["h2_8"], lay.w_fc1_8, ws["act8"], lay.s_fc1, lay.b_fc1, EPI_GELU_FP8, aux=ws["z"][l])
@@ -318,7 +328,7 @@ class ViTEngine(EncoderEngineBase):
             h2, act = (ws["h2s"][l], ws["acts"][l]) if self.full_ft else (ws["h2"], ws["act"])   # dW needs them per layer
             ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=h2, stats=ws["st2"][l])
             ops.gemm(h2, lay.w_fc1, act, EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
-            ops.gemm(act, lay.w_fc2, x[2 * l + 2], EPI_RESID_F32, bias=lay.b_fc2, resid=x[2 * l + 1])
+            ops.gemm(act, lay.w_fc2, x[2 * l + 2], EPI_R, bias=lay.b_fc2, resid=x[2 * l + 1])
         x_cls = x[-1].view(B, S * H)[:, :H]  # token 0 of every image (row stride S*H)
         ops.layernorm_fwd(x_cls, self.ln_f[0], self.ln_f[1], 1e-6, y_bf16=ws["clsn"], stats=ws["st_f"])
         out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
@@ -345,13 +355,13 @@ class ViTEngine(EncoderEngineBase):
         # final norm on token-0 rows only: every other row of the residual gradient is zero
         # bf16 gradient stream (no dropout in the ViT): the bf16 operand buffer IS the residual gradient, read and rewritten
         # in place by each LayerNorm backward (same lane, same elements); the f32 copy does not exist
-        gb = ws["grad_bf16"]
-        R = dxb if gb else dx          # the residual-gradient stream
-        if not gb:
+        g16 = ws["grad_bf16"]
+        R = dxb if g16 else dx          # the residual-gradient stream
+        if not g16:
             dx.zero_()
         dxb.zero_()
         ops.layernorm_bwd(x[-1].view(B, S * H)[:, :H], ws["st_f"], self.ln_f[0], 0, g_gemm=ws["dclsn"],
-                          dx_f32=None if gb else dx.view(B, S * H)[:, :H], dx_bf16=dxb.view(B, S * H)[:, :H])
+                          dx_f32=None if g16 else dx.view(B, S * H)[:, :H], dx_bf16=dxb.view(B, S * H)[:, :H])
         L = len(self.layers)
         for l in range(L - 1, -1, -1):
             lay = self.layers[l]
@@ -365,14 +375,14 @@ class ViTEngine(EncoderEngineBase):
                 ops.gemm(ws["dz_c"], lay.w_fc1_t, ws["dh_c"], EPI_BF16)
                 dx_c = R.view(B, S * H)[:, :H]
                 ops.layernorm_bwd(x[2 * l + 1].view(B, S * H)[:, :H], ws["st_c"], lay.ln2[0], 0, g_resid=dx_c,
-                                  g_gemm=ws["dh_c"], dx_f32=None if gb else dx_c, dx_bf16=dxb_c)
+                                  g_gemm=ws["dh_c"], dx_f32=None if g16 else dx_c, dx_bf16=dxb_c)
                 ws["dctx"].zero_()
                 ops.gemm(dxb_c, lay.w_proj_t, ws["dctx"].view(B, S * H)[:, :H], EPI_BF16)
             else:
                 ops.gemm(dxb, lay.w_fc2_t, ws["dz"], EPI_DGELU_BF16, aux=ws["z"][l])
                 ops.gemm(ws["dz"], lay.w_fc1_t, ws["dh"], EPI_BF16)
                 ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=R, g_gemm=ws["dh"],
-                                  dx_f32=None if gb else dx, dx_bf16=dxb)
+                                  dx_f32=None if g16 else dx, dx_bf16=dxb)
                 ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
             ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
                          q_rows=1 if l == L - 1 else 0)
@@ -388,7 +398,7 @@ class ViTEngine(EncoderEngineBase):
                 ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
                 ops.layernorm_bwd(x[2 * l], ws["st1"][l], lay.ln1[0], 0, g_resid=R, g_gemm=ws["dh"],
                                   dt=ws["dt"] if lb is not None else None,
-                                  lora_a=self.lora_a(l) if lb is not None else None, dx_f32=None if gb else dx, dx_bf16=dxb)
+                                  lora_a=self.lora_a(l) if lb is not None else None, dx_f32=None if g16 else dx, dx_bf16=dxb)
 
 
 # ======================================================================================================= BERT
@@ -468,14 +478,16 @@ class BertEngine(EncoderEngineBase):
         ws = {"B": B, "S": S, "M": M}
         ws["emb"] = z(M, H, dt=F32)
         ws["yb"] = [z(M, H + KPAD) for _ in range(L + 1)]   # LN outputs feeding each layer's QKV GEMM (+ LoRA t)
-        ws["y"] = z(M, H, dt=F32)                           # f32 copy of the current layer input (residual)
-        ws["ym"] = z(M, H, dt=F32)
+        rb = ws["resid_bf16"] = RESID_STREAM_BF16 and not self.full_ft and not self.fp8
+        sdt = BF16 if rb else F32
+        ws["y"] = z(M, H, dt=F32)                           # f32 copy of the current layer input (residual; bf16 stream: head input only)
+        ws["ym"] = None if rb else z(M, H, dt=F32)
         ws["ymb"] = z(M, H)
         ws["qkv"] = [z(M, 3 * H) for _ in range(L)]
         ws["ctx"] = [z(M, H) for _ in range(L)]
         ws["lse"] = [z(B, self.heads, S, dt=F32) for _ in range(L)]
-        ws["s1"] = [z(M, H, dt=F32) for _ in range(L)]      # pre-LN sums (LN backward inputs)
-        ws["s2"] = [z(M, H, dt=F32) for _ in range(L)]
+        ws["s1"] = [z(M, H, dt=sdt) for _ in range(L)]      # pre-LN sums (LN backward inputs)
+        ws["s2"] = [z(M, H, dt=sdt) for _ in range(L)]
         ws["sta"] = [z(M, 2, dt=F32) for _ in range(L)]
         ws["stb"] = [z(M, 2, dt=F32) for _ in range(L)]
         ws["z"] = [z(M, FF, dt=torch.uint8) for _ in range(L)]       # gelu'(intermediate pre-activation), 8-bit codes
@@ -580,11 +592,13 @@ class BertEngine(EncoderEngineBase):
         ops.bert_embed(input_ids.contiguous(), None if token_type_ids is None else token_type_ids.contiguous(),
                        self.word, self.posw, self.typew, ws["emb"])
         f8 = self.fp8
+        rb = ws["resid_bf16"]   # bf16 residual stream: the LN's bf16 operand IS the residual, no f32 copy is written
+        EPI_R = EPI_RESID_BF16 if rb else EPI_RESID_F32
         if f8:
             ops.layernorm_fwd_fp8(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, ws["yb8"][0], t_aug=ws["t"][0], y_f32=ws["y"],
                                   lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0))
         else:
-            ops.layernorm_fwd(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, y_bf16=ws["yb"][0], y_f32=ws["y"],
+            ops.layernorm_fwd(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, y_bf16=ws["yb"][0], y_f32=None if rb else ws["y"],
                               lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0),
                               stats=ws["st_e"] if self.full_ft else None)
         ws["ids"], ws["type_ids"] = input_ids, token_type_ids
@@ -596,7 +610,7 @@ class BertEngine(EncoderEngineBase):
                 ops.gemm(ws["yb"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
             ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], key_bias=key_bias,
                          dropout=self._drop(ws, self.p_attn, l, 1))
-            ops.gemm(ws["ctx"][l], lay.w_o, ws["s1"][l], EPI_RESID_F32, bias=lay.b_o, resid=ws["y"],
+            ops.gemm(ws["ctx"][l], lay.w_o, ws["s1"][l], EPI_R, bias=lay.b_o, resid=ws["yb"][l] if rb else ws["y"],
                      dropout=self._drop(ws, self.p_hidden, l, 2))
             if f8:
                 ops.layernorm_fwd_fp8(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, ws["ymb8"], y_f32=ws["ym"],
@@ -609,14 +623,16 @@ class BertEngine(EncoderEngineBase):
                 ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ymb, y_f32=ws["ym"],
                                   stats=ws["sta"][l])
                 ops.gemm(ymb, lay.w_fc1, act, EPI_GELU_BF16, bias=lay.b_fc1, aux=ws["z"][l])
-                ops.gemm(act, lay.w_fc2, ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"],
+                ops.gemm(act, lay.w_fc2, ws["s2"][l], EPI_R, bias=lay.b_fc2, resid=ymb if rb else ws["ym"],
                          dropout=self._drop(ws, self.p_hidden, l, 3))
             nxt = self.lora_a(l + 1) if l + 1 < L else self._zero_a
             if f8 and l + 1 < L:
                 ops.layernorm_fwd_fp8(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, ws["yb8"][l + 1], t_aug=ws["t"][l + 1],
                                       y_f32=ws["y"], lora_a=nxt, stats=ws["stb"][l])
             else:
-                ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1], y_f32=ws["y"],
+                # (bf16 stream: the f32 copy is written for the last layer only, where the mean-pool head reads it)
+                ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1],
+                                  y_f32=None if rb and not (l + 1 == L and self.head != "mlm_softmax_mean") else ws["y"],
                                   lora_a=nxt, stats=ws["stb"][l])
         out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
         if self.head == "mlm_softmax_mean":
@@ -656,13 +672,13 @@ class BertEngine(EncoderEngineBase):
             ops.meanpool_tokens_bwd(ws["dmp"], B, S, ws["dyl"])
             g_resid, g_gemm = ws["dyl"], None
         dt_in, a_in = None, None
-        gb = ws["grad_bf16"]
+        g16 = ws["grad_bf16"]
         for l in range(L - 1, -1, -1):
             lay = self.layers[l]
             # dsb is the operand of fc2's dX GEMM: it carries the mask fc2's forward output was dropped with.  With the bf16
             # gradient stream and no dropout the operand IS the residual gradient: one output, rewritten in place next time
             drop_b, drop_a = self._drop(ws, self.p_hidden, l, 3), self._drop(ws, self.p_hidden, l, 2)
-            one_b, one_a = gb and drop_b is None, gb and drop_a is None
+            one_b, one_a = g16 and drop_b is None, g16 and drop_a is None
             ops.layernorm_bwd(ws["s2"][l], ws["stb"][l], lay.ln_b[0], 1, g_resid=g_resid, g_gemm=g_gemm, dt=dt_in,
                               lora_a=a_in, dx_f32=None if one_b else ws["ds"], dx_bf16=ws["dsb"], dropout=drop_b)
             ops.gemm(ws["dsb"], lay.w_fc2_t, ws["dz"], EPI_DGELU_BF16, aux=ws["z"][l])

@@ -10,7 +10,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libbsclip_hip.so")
 
-EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, EPI_DGELU_BF16, EPI_PATCH_F32, EPI_GELU_FP8 = range(7)
+(EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, EPI_DGELU_BF16, EPI_PATCH_F32, EPI_GELU_FP8, EPI_RESID_BF16,
+ EPI_PATCH_BF16) = range(9)
 KPAD = 64
 LORA_COLS = 8
 
@@ -55,7 +56,7 @@ SIGNATURES = {
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, P]),
     "bsclip_mask_to_bias": (I, [P, I, P, P]),
-    "bsclip_vit_cls_rows": (I, [P, P, P, I, I, I, P]),
+    "bsclip_vit_cls_rows": (I, [P, I, P, P, I, I, I, P]),
     "bsclip_bert_embed": (I, [P, P, I, I, I, P, I, P, P, P, P]),
     "bsclip_softmax_meanpool_fwd": (I, [P, I, I, I, P, P, P]),
     "bsclip_softmax_meanpool_bwd": (I, [P, P, P, I, I, I, P, I, P]),

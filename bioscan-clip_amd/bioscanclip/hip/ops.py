@@ -9,7 +9,8 @@ import ctypes
 import torch
 
 from . import lib as _l
-from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_GELU_FP8, EPI_PATCH_F32, EPI_RESID_F32, KPAD,  # noqa: F401
+from .lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_GELU_FP8, EPI_PATCH_BF16, EPI_PATCH_F32,  # noqa: F401
+                  EPI_RESID_BF16, EPI_RESID_F32, KPAD,
                   EpiArgs, Fp8Args, check)
 
 BF16 = torch.bfloat16
@@ -49,7 +50,7 @@ def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, 
     want = F32 if epilogue in (EPI_F32, EPI_RESID_F32, EPI_PATCH_F32) else BF16
     if out.dtype != want:
         raise ValueError(f"gemm: out dtype {out.dtype} != {want}")
-    if epilogue == EPI_PATCH_F32:
+    if epilogue in (EPI_PATCH_F32, EPI_PATCH_BF16):
         _req(M % 196 == 0 and out.shape[0] >= M // 196 * 197 and out.shape[1] >= N, "gemm(PATCH): out too small")
     else:
         _req(out.shape[0] >= M and out.shape[1] >= N, "gemm: out too small")
@@ -58,8 +59,8 @@ def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, 
         _req(bias.dtype == F32 and bias.numel() >= N and bias.is_contiguous(), "gemm: bias must be f32 [N]")
         args.bias = bias.data_ptr()
     if resid is not None:
-        _req(resid.dtype == F32, "gemm: resid must be f32")
-        need = 197 if epilogue == EPI_PATCH_F32 else M
+        _req(resid.dtype == (BF16 if epilogue == EPI_RESID_BF16 else F32), "gemm: resid must be f32 (bf16 for EPI_RESID_BF16)")
+        need = 197 if epilogue in (EPI_PATCH_F32, EPI_PATCH_BF16) else M
         _req(resid.shape[0] >= need and resid.shape[1] >= N, "gemm: resid too small")
         args.resid = resid.data_ptr()
         args.ld_resid = _rowmajor(resid, "resid")
@@ -68,7 +69,7 @@ def gemm(a, b, out, epilogue=EPI_BF16, bias=None, resid=None, aux=None, M=None, 
         args.aux = aux.data_ptr()
         args.ld_aux = _rowmajor(aux, "aux")
     if dropout is not None:  # (p, seed): C = dropout(acc + bias) + resid
-        _req(epilogue == EPI_RESID_F32, "gemm: dropout is only defined for EPI_RESID_F32")
+        _req(epilogue in (EPI_RESID_F32, EPI_RESID_BF16), "gemm: dropout is only defined for EPI_RESID_F32 / _BF16")
         args.dropout_p, args.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF
     check(_l.load().bsclip_gemm_bf16(_p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, epilogue, ctypes.byref(args),
                                      _stream()))
@@ -274,9 +275,9 @@ def mask_to_bias(mask, bias):
 
 
 def vit_cls_rows(x, cls_token, pos_embed, B, S, H):
-    _req(x.dtype == F32 and x.is_contiguous() and x.numel() >= B * S * H, "x f32 [B*S,H]")
+    _req(x.dtype in (F32, BF16) and x.is_contiguous() and x.numel() >= B * S * H, "x f32 / bf16 [B*S,H]")
     _req(cls_token.numel() == H and pos_embed.numel() >= H and cls_token.dtype == F32 and pos_embed.dtype == F32, "cls/pos")
-    check(_l.load().bsclip_vit_cls_rows(_p(x), _p(cls_token), _p(pos_embed), B, S, H, _stream()))
+    check(_l.load().bsclip_vit_cls_rows(_p(x), int(x.dtype == BF16), _p(cls_token), _p(pos_embed), B, S, H, _stream()))
 
 
 def bert_embed(ids, type_ids, word, pos, typ, out):

@@ -31,12 +31,14 @@ __global__ __launch_bounds__(256) void im2col_patch16_kernel(const float* __rest
     }
 }
 
-__global__ void vit_cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls,
+template <bool X_BF16>
+__global__ void vit_cls_rows_kernel(void* __restrict__ x, const float* __restrict__ cls,
                                     const float* __restrict__ pos, int B, int S, int H) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, c = i % H;
-    x[(size_t)b * S * H + c] = cls[c] + pos[c];
+    if constexpr (X_BF16) static_cast<bf16_t*>(x)[(size_t)b * S * H + c] = f2bf(cls[c] + pos[c]);
+    else static_cast<float*>(x)[(size_t)b * S * H + c] = cls[c] + pos[c];
 }
 
 // one wave per token row
@@ -197,11 +199,15 @@ extern "C" int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16,
     return BSCLIP_OK;
 }
 
-extern "C" int bsclip_vit_cls_rows(float* x, const float* cls_token, const float* pos_embed, int B, int S, int H,
+extern "C" int bsclip_vit_cls_rows(void* x, int x_bf16, const float* cls_token, const float* pos_embed, int B, int S, int H,
                                    void* stream) {
     BSCLIP_REQUIRE(x && cls_token && pos_embed && B > 0, "bsclip_vit_cls_rows: bad args");
-    hipLaunchKernelGGL(vit_cls_rows_kernel, dim3(ceil_div(B * H, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       x, cls_token, pos_embed, B, S, H);
+    if (x_bf16)
+        hipLaunchKernelGGL((vit_cls_rows_kernel<true>), dim3(ceil_div(B * H, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           x, cls_token, pos_embed, B, S, H);
+    else
+        hipLaunchKernelGGL((vit_cls_rows_kernel<false>), dim3(ceil_div(B * H, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           x, cls_token, pos_embed, B, S, H);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

@@ -40,7 +40,7 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 
 struct EpiArgs {
     const float* bias;
-    const float* resid;
+    const float* resid;   // RESID_BF16: bf16 data behind the same pointer
     int ld_resid;
     unsigned char* aux;  // gelu' side band, 8-bit codes (common.h dg8_*)
     int ld_aux;
@@ -115,6 +115,16 @@ __device__ __forceinline__ void gelu_lut2(const char* lut, f32x2 x, f32x2& gl, f
     dg = x * pdf + cdf;
 }
 
+__device__ __forceinline__ f32x4 bf4_to_f32(uint2 u) {
+    return f32x4{bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
+}
+__device__ __forceinline__ uint2 f32_to_bf4(f32x4 v) { return uint2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}; }
+constexpr bool epi_is_resid(int epi) { return epi == BSCLIP_EPI_RESID_F32 || epi == BSCLIP_EPI_RESID_BF16; }
+constexpr bool epi_is_patch(int epi) { return epi == BSCLIP_EPI_PATCH_F32 || epi == BSCLIP_EPI_PATCH_BF16; }
+constexpr bool epi_out_bf16_from_f32_slab(int epi) {
+    return epi == BSCLIP_EPI_DGELU_BF16 || epi == BSCLIP_EPI_RESID_BF16 || epi == BSCLIP_EPI_PATCH_BF16;
+}
+
 // v already holds acc (+ bias).  No data-dependent branch guards a load.
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, int ldc, const EpiArgs& e) {
@@ -154,6 +164,16 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, i
         const f32x4 pos = *reinterpret_cast<const f32x4*>(e.resid + (size_t)(1 + p) * e.ld_resid + n);
         v += pos;
         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = v;
+    } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
+        const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(e.resid) + (size_t)m * e.ld_resid + n);
+        if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
+        v += bf4_to_f32(r);
+        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = f32_to_bf4(v);
+    } else if constexpr (EPI == BSCLIP_EPI_PATCH_BF16) {
+        const int b = m / 196, p = m - b * 196;
+        const f32x4 pos = *reinterpret_cast<const f32x4*>(e.resid + (size_t)(1 + p) * e.ld_resid + n);
+        v += pos;
+        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = f32_to_bf4(v);
     }
 }
 
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const bf
                                                                          int K, int tiles_n, EpiArgs e) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // per-wave output tile
-    if constexpr (EPI == BSCLIP_EPI_RESID_F32) BSCLIP_DROP_RESOLVE(e.drop);
+    if constexpr (epi_is_resid(EPI)) BSCLIP_DROP_RESOLVE(e.drop);
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         B += (size_t)blockIdx.y * K;
         C = static_cast<float*>(C) + (size_t)blockIdx.y * e.split_stride;
     }
-    if constexpr (EPI == BSCLIP_EPI_RESID_F32) BSCLIP_DROP_RESOLVE(e.drop);
+    if constexpr (epi_is_resid(EPI)) BSCLIP_DROP_RESOLVE(e.drop);
     constexpr int ESZ = OP == 0 ? 2 : 1;   // bytes per element of the main operands
     constexpr int SET = 65536, HALF = 16384, B_OFF = 32768;
     // main loop 128 KiB; epilogue slabs 2x64x1040 (f32) or 4x64x528 (bf16 x2) = 132 KiB, + 16 KiB GELU table
@@ -1017,9 +1037,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 const int n = n0 + lane * 4;
                 if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
                     R[it] = *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
+                } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
+                    R[it] = bf4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(e.resid) + (size_t)m * e.ld_resid + n));
                 } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
                     R[it] = dg8_unpack4(*reinterpret_cast<const unsigned*>(e.aux + (size_t)m * e.ld_aux + n));
-                } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
+                } else if constexpr (epi_is_patch(EPI)) {
                     R[it] = *reinterpret_cast<const f32x4*>(e.resid + (size_t)(1 + m % 196) * e.ld_resid + n);
                 } else {
                     R[it] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1050,6 +1072,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                         const int b = m / 196, p = m - b * 196;
                         v += R[it];
                         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = v;
+                    } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
+                        if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
+                        v += R[it];
+                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = f32_to_bf4(v);
+                    } else if constexpr (EPI == BSCLIP_EPI_PATCH_BF16) {
+                        const int b = m / 196, p = m - b * 196;
+                        v += R[it];
+                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = f32_to_bf4(v);
                     }
                 }
             }
@@ -1155,7 +1185,7 @@ extern "C" int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, 
     BSCLIP_REQUIRE(K % 64 == 0 && N % 256 == 0, "bsclip_gemm_diag: K %% 64, N %% 256");
     EpiArgs e{};
     e.bias = args->bias;
-    e.resid = args->resid;
+    e.resid = static_cast<const float*>(args->resid);
     e.ld_resid = args->ld_resid;
     e.aux = static_cast<unsigned char*>(args->aux);
     e.ld_aux = args->ld_aux;
@@ -1203,7 +1233,7 @@ extern "C" int bsclip_gemm_duo_diag(const void* A, int lda, const void* B, int l
     BSCLIP_REQUIRE(K % 64 == 0 && N % 128 == 0, "bsclip_gemm_duo_diag: K %% 64, N %% 128");
     EpiArgs e{};
     e.bias = args->bias;
-    e.resid = args->resid;
+    e.resid = static_cast<const float*>(args->resid);
     e.ld_resid = args->ld_resid;
     e.aux = static_cast<unsigned char*>(args->aux);
     e.ld_aux = args->ld_aux;
@@ -1281,7 +1311,7 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
                        "bsclip_gemm_bf16: args->struct_size=%u, this library's bsclip_epi_args is %zu bytes (binding out of date?)",
                        args->struct_size, sizeof(bsclip_epi_args));
         e.bias = args->bias;
-        e.resid = args->resid;
+        e.resid = static_cast<const float*>(args->resid);
         e.ld_resid = args->ld_resid;
         e.aux = static_cast<unsigned char*>(args->aux);
         e.ld_aux = args->ld_aux;
@@ -1289,8 +1319,8 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
                        "bsclip_gemm_bf16: aux (8-bit gelu' band) needs ld_aux >= N, ld_aux %% 16 == 0, 16-B alignment (ld_aux=%d)",
                        args->ld_aux);
         BSCLIP_REQUIRE(args->dropout_p >= 0.f && args->dropout_p < 1.f, "bsclip_gemm_bf16: dropout_p=%f", args->dropout_p);
-        BSCLIP_REQUIRE(args->dropout_p == 0.f || epilogue == BSCLIP_EPI_RESID_F32,
-                       "bsclip_gemm_bf16: dropout is only defined for BSCLIP_EPI_RESID_F32");
+        BSCLIP_REQUIRE(args->dropout_p == 0.f || epilogue == BSCLIP_EPI_RESID_F32 || epilogue == BSCLIP_EPI_RESID_BF16,
+                       "bsclip_gemm_bf16: dropout is only defined for BSCLIP_EPI_RESID_F32 / _BF16");
         e.drop = make_drop(args->dropout_p, args->dropout_seed);
     }
     e.n_total = N;
@@ -1313,6 +1343,15 @@ extern "C" int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, 
         case BSCLIP_EPI_PATCH_F32:
             BSCLIP_REQUIRE(e.resid && e.ld_resid >= N && M % 196 == 0, "bsclip_gemm_bf16: PATCH needs pos, M%%196==0");
             launch_bias<BSCLIP_EPI_PATCH_F32>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
+            break;
+        case BSCLIP_EPI_RESID_BF16:
+            BSCLIP_REQUIRE(e.resid && e.ld_resid >= N && e.ld_resid % 4 == 0 && (((uintptr_t)e.resid) & 7) == 0,
+                           "bsclip_gemm_bf16: RESID_BF16 needs resid (bf16, 8-byte aligned rows) / ld_resid");
+            launch_bias<BSCLIP_EPI_RESID_BF16>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
+            break;
+        case BSCLIP_EPI_PATCH_BF16:
+            BSCLIP_REQUIRE(e.resid && e.ld_resid >= N && M % 196 == 0, "bsclip_gemm_bf16: PATCH needs pos, M%%196==0");
+            launch_bias<BSCLIP_EPI_PATCH_BF16>(a, lda, b, ldb, C, ldc, M, N, K, e, s);
             break;
         default: BSCLIP_REQUIRE(false, "bsclip_gemm_bf16: unknown epilogue %d", epilogue);
     }
@@ -1420,7 +1459,7 @@ extern "C" int bsclip_gemm_fp8(const void* A8, int lda, const void* B8, int ldb,
     BSCLIP_REQUIRE(f8->form == 1 || f8->form == 2, "bsclip_gemm_fp8: form %d (1 or 2)", f8->form);
     EpiArgs e{};
     e.bias = args->bias;
-    e.resid = args->resid;
+    e.resid = static_cast<const float*>(args->resid);
     e.ld_resid = args->ld_resid;
     e.aux = static_cast<unsigned char*>(args->aux);
     e.ld_aux = args->ld_aux;

@@ -28,7 +28,7 @@ template <int EPI, bool HAS_BIAS, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __restrict__ A, int lda,
                                                              const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                              int ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
-    if constexpr (EPI == BSCLIP_EPI_RESID_F32) BSCLIP_DROP_RESOLVE(e.drop);
+    if constexpr (epi_is_resid(EPI)) BSCLIP_DROP_RESOLVE(e.drop);
     constexpr int PIECE = 16384, NSLOT = 5;
     __shared__ __attribute__((aligned(16))) char smem[NSLOT * PIECE];
 
@@ -246,9 +246,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __res
                 const int n = n0 + (tid & 31) * 4;
                 if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
                     R[it] = *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
+                } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
+                    R[it] = bf4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(e.resid) + (size_t)m * e.ld_resid + n));
                 } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
                     R[it] = dg8_unpack4(*reinterpret_cast<const unsigned*>(e.aux + (size_t)m * e.ld_aux + n));
-                } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
+                } else if constexpr (epi_is_patch(EPI)) {
                     R[it] = *reinterpret_cast<const f32x4*>(e.resid + (size_t)(1 + m % 196) * e.ld_resid + n);
                 } else {
                     R[it] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -289,6 +291,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __res
                         const int b = m / 196, p = m - b * 196;
                         v += pre[mi][it];
                         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = v;
+                    } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
+                        if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
+                        v += pre[mi][it];
+                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = f32_to_bf4(v);
+                    } else if constexpr (EPI == BSCLIP_EPI_PATCH_BF16) {
+                        const int b = m / 196, p = m - b * 196;
+                        v += pre[mi][it];
+                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = f32_to_bf4(v);
                     }
                 }
             }

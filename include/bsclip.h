@@ -54,17 +54,20 @@ enum bsclip_epilogue {
     BSCLIP_EPI_RESID_F32 = 3,  /* C f32  = acc + bias + resid                                       */
     BSCLIP_EPI_DGELU_BF16 = 4, /* C bf16 = acc * aux          (aux = gelu' codes saved by the forward) */
     BSCLIP_EPI_PATCH_F32 = 5,  /* C f32 row (b*197+1+p) = acc + bias + pos[1+p], input row b*196+p  */
-    BSCLIP_EPI_GELU_FP8 = 6    /* bsclip_gemm_fp8 only: C fp8 e4m3 = gelu(..) (the next GEMM's operand); aux as GELU_BF16 */
+    BSCLIP_EPI_GELU_FP8 = 6,   /* bsclip_gemm_fp8 only: C fp8 e4m3 = gelu(..) (the next GEMM's operand); aux as GELU_BF16 */
+    /* the residual stream stored as bf16 (the sum is formed in f32 and rounded once): 4 instead of 8 bytes per element moved */
+    BSCLIP_EPI_RESID_BF16 = 7, /* C bf16 = acc + bias + resid, resid bf16 [M, ld_resid] (+ dropout as RESID_F32)  */
+    BSCLIP_EPI_PATCH_BF16 = 8  /* as PATCH_F32 with a bf16 C (pos_embed stays f32)                         */
 };
 typedef struct bsclip_epi_args {
     uint32_t struct_size; /* = sizeof(bsclip_epi_args) = bsclip_epi_args_size(); a mismatch is rejected (ABI drift guard) */
     const float* bias;    /* [N] or NULL */
-    const float* resid; /* RESID: f32 [M, ld_resid]; PATCH: pos_embed f32 [197, N] */
+    const void* resid;  /* RESID_F32: f32 [M, ld_resid]; RESID_BF16: bf16 [M, ld_resid]; PATCH_*: pos_embed f32 [197, N] */
     int ld_resid;
     void* aux; /* gelu' side band, uint8 [M, ld_aux]: code = round((gelu' + 0.13) * 255 / 1.26); GELU: out (nullable), DGELU: in;
                 * ld_aux % 16 == 0, 16-byte aligned */
     int ld_aux;
-    float dropout_p;        /* RESID only: C = dropout(acc + bias) + resid (HF hidden_dropout_prob); 0 = off */
+    float dropout_p;        /* RESID_* only: C = dropout(acc + bias) + resid (HF hidden_dropout_prob); 0 = off */
     uint32_t dropout_seed;  /* decision of element (m,n) = f(seed, m*N + n): see bsclip_layernorm_bwd */
 } bsclip_epi_args;
 int bsclip_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -183,7 +186,8 @@ int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, c
 int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16, void* stream);
 /* HF extended attention mask (BertModel, language_encoder.py:89): bias[i] = mask[i] ? 0 : finfo(f32).min */
 int bsclip_mask_to_bias(const int64_t* mask, int n, float* bias, void* stream);
-int bsclip_vit_cls_rows(float* x, const float* cls_token, const float* pos_embed, int B, int S, int H, void* stream);
+/* x[b*S, :] = cls_token + pos_embed[0] (x f32, or bf16 when x_bf16 != 0: the bf16 residual stream) */
+int bsclip_vit_cls_rows(void* x, int x_bf16, const float* cls_token, const float* pos_embed, int B, int S, int H, void* stream);
 int bsclip_bert_embed(const int64_t* ids, const int64_t* type_ids, int B, int S, int H, const float* word,
                       int vocab, const float* pos, const float* type, float* out, void* stream);
 

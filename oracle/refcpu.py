@@ -29,6 +29,17 @@ def _q(x, emulate_bf16):
     return x + (x.detach().to(torch.bfloat16).to(x.dtype) - x.detach())
 
 
+# The HIP engines keep the residual stream in bf16 by default (hip/engine.py RESID_STREAM_BF16): every sub-layer's sum is formed
+# in f32 and rounded once when stored.  The rounding-aware evaluation (emulate_bf16=True) restates that rounding point too; set
+# to False to emulate the f32 stream (BSCLIP_RESID_STREAM=f32).  The plain f32 evaluation never rounds anything.
+EMULATE_RESID_BF16 = True
+
+
+def _rq(x, emulate_bf16):
+    """bf16 rounding of a stored residual-stream tensor (only under emulate_bf16)."""
+    return _q(x, emulate_bf16 and EMULATE_RESID_BF16)
+
+
 def linear(x, w, b=None, emulate_bf16=False):
     y = _q(x, emulate_bf16) @ _q(w, emulate_bf16).t()
     return y if b is None else y + b
@@ -78,7 +89,7 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
     gh, gw = image.shape[2] // ps, image.shape[3] // ps
     cols = image.reshape(B, 3, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, 3 * ps * ps)
     x = linear(cols, w_pe.reshape(D, -1), p("patch_embed.proj.bias"), eb)
-    x = torch.cat([p("cls_token").expand(B, -1, -1), x], dim=1) + p("pos_embed")
+    x = _rq(torch.cat([p("cls_token").expand(B, -1, -1), x], dim=1) + p("pos_embed"), eb)
     tap = (lambda name, t: taps.__setitem__(name, t.detach())) if taps is not None else (lambda name, t: None)
     tap("x0", x)
     depth = 0
@@ -106,11 +117,11 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
         tap(f"qkv.{i}", qkv.permute(1, 3, 0, 2, 4).reshape(B, S, 3 * D))
         ctx = sdpa(_q(qkv[0], eb), _q(qkv[1], eb), _q(qkv[2], eb), emulate_bf16=eb).transpose(1, 2).reshape(B, S, D)
         tap(f"ctx.{i}", ctx)
-        x = x + linear(ctx, p(b + "attn.proj.weight"), p(b + "attn.proj.bias"), eb)
+        x = _rq(x + linear(ctx, p(b + "attn.proj.weight"), p(b + "attn.proj.bias"), eb), eb)
         tap(f"x{2 * i + 1}", x)
         h = layer_norm(x, p(b + "norm2.weight"), p(b + "norm2.bias"), 1e-6)
         h = gelu_erf(linear(h, p(b + "mlp.fc1.weight"), p(b + "mlp.fc1.bias"), eb))
-        x = x + linear(h, p(b + "mlp.fc2.weight"), p(b + "mlp.fc2.bias"), eb)
+        x = _rq(x + linear(h, p(b + "mlp.fc2.weight"), p(b + "mlp.fc2.bias"), eb), eb)
         tap(f"x{2 * i + 2}", x)
     x = layer_norm(x, p("norm.weight"), p("norm.bias"), 1e-6)
     if return_hidden:
@@ -165,11 +176,12 @@ def bert_encoder(sd, prefix, input_ids, token_type_ids=None, attention_mask=None
         sh = lambda t: t.reshape(B, S, num_heads, hd).transpose(1, 2)
         ctx = sdpa(_q(sh(q), eb), _q(sh(k), eb), _q(sh(v), eb), bias, emulate_bf16=eb).transpose(1, 2).reshape(B, S, H)
         a = linear(ctx, sd[lp + "attention.output.dense.weight"], sd[lp + "attention.output.dense.bias"], eb)
-        h = layer_norm(h + a, sd[lp + "attention.output.LayerNorm.weight"],
+        # (bf16 stream: the LayerNorm's bf16 GEMM operand IS the residual branch, and the sum is stored rounded)
+        h = layer_norm(_rq(_rq(h, eb) + a, eb), sd[lp + "attention.output.LayerNorm.weight"],
                        sd[lp + "attention.output.LayerNorm.bias"], eps)
         m = gelu_erf(linear(h, sd[lp + "intermediate.dense.weight"], sd[lp + "intermediate.dense.bias"], eb))
         m = linear(m, sd[lp + "output.dense.weight"], sd[lp + "output.dense.bias"], eb)
-        h = layer_norm(h + m, sd[lp + "output.LayerNorm.weight"], sd[lp + "output.LayerNorm.bias"], eps)
+        h = layer_norm(_rq(_rq(h, eb) + m, eb), sd[lp + "output.LayerNorm.weight"], sd[lp + "output.LayerNorm.bias"], eps)
     return h
 
 

@@ -39,6 +39,10 @@ def test_gemm_resid_dropout_and_layernorm_bwd_share_the_mask(ops):
         outs[tile] = out - resid
     ops.set_gemm_tile(0)
     assert torch.equal(outs[1] == 0, outs[4] == 0) and torch.equal(outs[5] == 0, outs[4] == 0), "mask must not depend on the kernel/tile layout"
+    from bioscanclip.hip.lib import EPI_RESID_BF16
+    outb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, w, outb, EPI_RESID_BF16, bias=bias, resid=torch.zeros(M, N, device="cuda", dtype=torch.bfloat16), dropout=(P, 1234))
+    assert torch.equal(outb == 0, outs[4] == 0), "the bf16-stream epilogue draws the same mask"
     d = outs[4]
     kept = d != 0
     assert abs(kept.float().mean().item() - (1 - P)) < 5e-3

@@ -44,7 +44,7 @@ def dgelu(x):
 @pytest.mark.parametrize("M,N,K", [(300, 256, 64), (300, 256, 128), (1000, 768, 832), (2500, 512, 576), (197 * 8, 2304, 832),
                                    (5120, 768, 3072)])
 def test_gemm_epilogues(ops, tile, M, N, K):
-    from bioscanclip.hip.lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32)
+    from bioscanclip.hip.lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_BF16, EPI_RESID_F32)
     ops.set_gemm_tile(tile)
     try:
         a = dev(rnd(M, K + 16, seed=1).bfloat16())[:, :K]      # row stride > K on purpose
@@ -71,6 +71,15 @@ def test_gemm_epilogues(ops, tile, M, N, K):
         r = dev(rnd(M, N, seed=4))
         ops.gemm(a, b, out32, EPI_RESID_F32, bias=bias, resid=r, M=M)
         assert rel_err(out32[:M], ref + r) < TOL_F32
+        # bf16 residual stream: the sum is formed in f32 and rounded once (resid bf16 with a row stride > N, as the BERT engine
+        # passes the LayerNorm's K-augmented operand)
+        rb = torch.zeros(M, N + 64, device="cuda", dtype=torch.bfloat16)
+        rb[:, :N] = r.bfloat16()
+        out16r = torch.full((M + 3, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, b, out16r, EPI_RESID_BF16, bias=bias, resid=rb, M=M)
+        assert torch.equal(out16r[:M], (out32[:M] - r + rb[:, :N].float()).bfloat16()) or \
+            rel_err(out16r[:M].float(), ref + rb[:, :N].float()) < 2.5e-3     # = one bf16 rounding of the f32 sum
+        assert torch.isnan(out16r[M:]).all(), "rows beyond M were written"
         # in-place residual (C aliases resid): used by the loss gradient accumulation
         acc = r.clone()
         ops.gemm(a, b, acc, EPI_RESID_F32, resid=acc)
@@ -156,6 +165,13 @@ def test_gemm_patch_epilogue(ops):
     got = out.reshape(B, 197, 768)
     assert rel_err(got[:, 1:], ref) < TOL_F32
     assert (got[:, 0] == 0).all()
+    from bioscanclip.hip.lib import EPI_PATCH_BF16
+    for tile in (1, 4, 5):
+        ops.set_gemm_tile(tile)
+        out16 = torch.zeros(B * 197, 768, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, w, out16, EPI_PATCH_BF16, bias=bias, resid=pos)
+        ops.set_gemm_tile(0)
+        assert torch.equal(out16, out.bfloat16()), f"tile {tile}"      # the f32 result rounded once; row 0 of each image untouched
 
 
 def test_gemm_rejects_bad_shapes(ops):
