@@ -34,7 +34,13 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md chip table)
 GFLOP_PER_PAIR_ID = 118.3   # fwd 58.8 + LoRA-regime bwd
 GFLOP_PER_TRIPLE_IDT = 119.3
-FC1_TRAFFIC_BYTES_B256 = 765.8e6  # (11 x 953.3 + 12 x 644.9 + 154.5) / 24 MB: per-shape PMC figures (profiles/r02_c_fc1_pmc.txt), this build's launch mix
+# HBM-side bytes per launch of the dominant kernel: NOT measured by this run (PMC passes need rocprofv3 around the process).
+# Offline figure: (11 x 953.3 + 12 x 644.9 + 154.5) / 24 MB from the per-shape FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE
+# passes of profiles/r03_b_fc1_pmc.txt (tools/scripts/r03_pmc.sh; the kernel's loop and stores are unchanged since
+# profiles/r02_c_fc1_pmc.txt, which gave the same numbers).
+FC1_TRAFFIC_BYTES_B256 = 765.8e6
+FC1_TRAFFIC_SOURCE = "offline rocprofv3 --pmc passes (profiles/r03_b_fc1_pmc.txt, tools/scripts/r03_pmc.sh), not collected by this run"
+METRIC = "paired samples/sec/node (I+D+T, global batch) + step MFMA-roofline % at 1/2/4/8 GPU"   # BASELINE.json:metric, verbatim
 
 
 class _Cfg:
@@ -125,7 +131,7 @@ def time_dominant_gemm(B, device, reps=4):
             # bytes per launch at the L2's memory side, FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, averaged over the
             # same launch mix; collected offline with rocprofv3 --pmc (profiles/r02_c_fc1_pmc.txt), valid for B=256
             "traffic": FC1_TRAFFIC_BYTES_B256 if B == 256 else None,
-            "traffic_note": "rocprofv3 PMC, profiles/r02_c_fc1_pmc.txt; algorithmic bytes per launch: "
+            "traffic_note": FC1_TRAFFIC_SOURCE + "; algorithmic bytes per launch: "
                             "%.1f MB (A + W bf16, gelu bf16, gelu' 8-bit)" % (sum(((M * K + N * K) * 2.0 + 3.0 * M * N) * c for M, N, K, c in shapes)
                                                                              / launches / 1e6),
             "kernel": "gemm_nt_pp_kernel<2 = EPI_GELU_BF16, true> (fc1 + bias + GELU; 24 launches per step)",
@@ -197,6 +203,37 @@ def cpu_baseline(seconds_budget=20.0):
                       f"{t_total:.1f} s, torch CPU threads={cores}, {cpu}"}
 
 
+def side_measurement(device, with_text, fp8, B, steps=8):
+    """ms/step of another BASELINE configuration's per-GPU shape on this one GPU (same step, same launch path: captured
+    hipGraph), reported as extra keys of the line so that they are driver-run numbers too: configs[2]'s I+D+T at local batch 256
+    and configs[4]'s fp8 trunks at its own local batch 512."""
+    from bioscanclip.hip.graph import GraphedStep
+    from bioscanclip.hip.optim import FusedAdamW
+    from bioscanclip.model.loss_func import ContrastiveLoss
+    model = build_model(with_text, device)
+    if fp8:
+        from bioscanclip.hip.engine import set_precision
+        set_precision(model, "fp8")
+    model.train()
+    image, dna, text = synthetic_batch(B, with_text, device, seed=4321)
+    label = torch.arange(B, device=device)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    g = GraphedStep(model, opt, ContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07), warmup=2)
+    for _ in range(5):      # two eager steps, the capture (+ its replay), two more replays
+        loss = g(image, dna, text, label)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = g(image, dna, text, label)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    out = {"ms_per_step": round(ms, 3), "paired_samples_per_s": round(B / (ms * 1e-3), 1), "local_batch": B, "steps": steps,
+           "final_loss": round(loss.item(), 5)}
+    del g, opt, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     # stdout carries exactly one line, the JSON result.  Native libraries print there too (RCCL writes a version banner to
     # fd 1 when the first communicator is created), so fd 1 is pointed at stderr for the duration of the run and the result
@@ -215,6 +252,8 @@ def main():
     ap.add_argument("--lr", type=float, default=None, help="AdamW lr (default 1e-3; 1e-6 with --full-ft, the reference's full fine-tuning base lr: random-init towers on noise images collapse under larger steps, tools/ft_dynamics_probe.py)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (I+D+T at B=256, fp8 trunks at B=512) the "
+                    "default single-GPU line carries as extra keys")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -334,7 +373,9 @@ def main():
         step_tflop_per_gpu = (per * B + loss_gflop) / 1e3
         achieved = step_tflop_per_gpu / (ms * 1e-3)
         out = {
-            "metric": "paired samples/sec/node (I+D%s, global batch)" % ("+T" if a.text else ""),
+            # BASELINE.json's metric string; which towers THIS line ran is in config.workload (configs[1] = I+D is the
+            # single-GPU configuration the metric is quoted on; --text runs configs[2]'s I+D+T)
+            "metric": METRIC,
             "value": round(N / (ms * 1e-3), 1), "unit": "paired samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
@@ -360,6 +401,16 @@ def main():
                                                      / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4)},
         }
         out["roofline"] = time_dominant_gemm(B, device)
+        if world == 1 and not force_dist and not (a.no_extras or a.text or a.fp8 or a.full_ft or nodrop or B != 256):
+            # the other single-GPU-measurable BASELINE shapes, so that they are driver-run numbers
+            graphed = None
+            del opt, model
+            torch.cuda.empty_cache()
+            try:
+                out["extra"] = {"configs[2] per-GPU shape (I+D+T, bf16, local batch 256)": side_measurement(device, True, False, 256),
+                                "configs[4] per-GPU shape (fp8 trunks, I+D, local batch 512)": side_measurement(device, False, True, 512)}
+            except Exception as exc:   # noqa: BLE001 - the headline line must not die with a side measurement
+                out["extra"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(f"[bench] gpu: {ms:.2f} ms/step, {out['value']} pairs/s; host enqueue wall {t_enq / a.steps * 1e3:.2f} ms/step, "
               f"host cpu {host_cpu_s / a.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:

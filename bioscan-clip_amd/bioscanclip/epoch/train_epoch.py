@@ -5,7 +5,15 @@ Per batch, in the reference's order: inputs to the device, ``optimizer.zero_grad
 autograd anomaly mode stays off, the loss is read back once per step (the reference synchronises three times), tqdm / wandb
 are optional, and under a process group of more than one rank the flat trainable gradients are all-reduced (SUM) before the
 optimizer step.  Returns the mean loss of the epoch.
+
+Launch path (round 3): on one rank the step runs as ONE replayed hipGraph (``bioscanclip.hip.graph.GraphedStep``: the same
+Python body captured once -- bitwise the eager step, tests/test_graph_gpu.py) and the loss is read one step late, so the host
+never waits for the step it has just enqueued: what ``bench.py`` measures is what ``scripts/train_cl.py`` runs.  A batch whose
+shape differs from the captured one (a last, smaller batch) is enqueued eagerly.  ``BSCLIP_GRAPH=0`` forces the eager loop; with
+more than one rank the step stays eager (the collectives are issued from Python).
 """
+import os
+
 import torch
 
 try:  # neither ships in this image (SURVEY 5)
@@ -30,6 +38,23 @@ def _to_device(batch, device):
     return image, dna, text, label.to(device)
 
 
+def _graphed_step(model, optimizer, criterion, device):
+    """The captured step for this (model, optimizer, criterion), created on first use and kept on the model; None when the
+    step has to stay eager: BSCLIP_GRAPH=0, a CPU device, an optimizer other than FusedAdamW, more than one rank."""
+    from bioscanclip.hip import dist as hdist
+    if os.environ.get("BSCLIP_GRAPH", "1") == "0" or torch.device(device).type != "cuda":
+        return None
+    if not hasattr(optimizer, "enable_device_hyper") or not hdist._inactive(None) or hasattr(criterion, "prefetch_labels"):
+        return None
+    from bioscanclip.hip.graph import GraphedStep
+    key = (id(optimizer), id(criterion))
+    g = getattr(model, "_bsclip_graphed", None)
+    if g is None or g[0] != key:
+        g = (key, GraphedStep(model, optimizer, criterion, warmup=2))
+        model._bsclip_graphed = g
+    return g[1]
+
+
 def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimizer, criterion, device, scheduler=None,
                 for_open_clip=False, rank=None, check_cuda_memory=False):
     from bioscanclip.hip import dist as hdist
@@ -41,8 +66,31 @@ def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimize
     running = 0.0
 
     model.train()
+    graphed = _graphed_step(model, optimizer, criterion, device)
+    ring = torch.zeros(4, dtype=torch.float32, device=device) if graphed is not None else None
+    pending = None   # (step, lr) whose loss sits in ring[step % 4] and has not been read yet
+
+    def report(step, value, lr):
+        if show:
+            mem = f" || Allocated: {torch.cuda.memory_allocated() / 2 ** 30:.2f} GB" if check_cuda_memory else ""
+            steps.set_description(f"Epoch: {epoch}||Step: {step}/{n_steps}||Loss: {value}{mem} || Current LR: {lr}")
+        if activate_wandb and wandb is not None:
+            wandb.log({"loss": value, "step": step + epoch * n_steps, "learning_rate": lr})
+
     for step, batch in steps:
         image, dna, text, label = _to_device(batch, device)
+        if graphed is not None and graphed.accepts(image, dna, text, label):
+            loss = graphed(image, dna, text, label)              # device scalar, overwritten by the next replay ...
+            ring[step % 4].copy_(loss.detach())                  # ... so it is parked in this step's slot
+            lr = optimizer.param_groups[0]["lr"]
+            if scheduler is not None:
+                scheduler.step()
+            if pending is not None:                              # read the PREVIOUS step's loss: the host stays one step ahead
+                value = ring[pending[0] % 4].item()
+                running += value
+                report(pending[0], value, pending[1])
+            pending = (step, lr)
+            continue
         optimizer.zero_grad()
         if hasattr(criterion, "prefetch_labels"):
             criterion.prefetch_labels(label)  # global-batch loss: the label all-gather starts before the encoders
@@ -52,17 +100,21 @@ def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimize
         if hasattr(optimizer, "needs_attach") and optimizer.needs_attach():
             optimizer.attach(model)  # FusedAdamW: adopt the engines' flat buffers once they exist (or were rebuilt)
         optimizer.step()
+        lr = optimizer.param_groups[0]["lr"]
         if scheduler is not None:
             scheduler.step()
-
-        value = loss.item()  # the step's only host synchronisation
+        if pending is not None:
+            value = ring[pending[0] % 4].item()
+            running += value
+            report(pending[0], value, pending[1])
+            pending = None
+        value = loss.item()  # the eager step's only host synchronisation
         running += value
-        lr = optimizer.param_groups[0]["lr"]
-        if show:
-            mem = f" || Allocated: {torch.cuda.memory_allocated() / 2 ** 30:.2f} GB" if check_cuda_memory else ""
-            steps.set_description(f"Epoch: {epoch}||Step: {step}/{n_steps}||Loss: {value}{mem} || Current LR: {lr}")
-        if activate_wandb and wandb is not None:
-            wandb.log({"loss": value, "step": step + epoch * n_steps, "learning_rate": lr})
+        report(step, value, lr)
+    if pending is not None:
+        value = ring[pending[0] % 4].item()
+        running += value
+        report(pending[0], value, pending[1])
 
     mean_loss = running / max(n_steps, 1)
     print(f"Epoch [{epoch}/{total_epochs}], Loss: {mean_loss}")

@@ -11,6 +11,7 @@ Everything numerical happens in ``libbsclip_hip.so``; this file decides *which* 
     sub-layer, bf16 GEMM operands, attention LSE, LN statistics).
 Reference call shapes: SURVEY.md 2.3 (K1-K15), 3.2; semantics App. A.1-A.3.
 """
+import itertools
 import os
 import zlib
 
@@ -34,6 +35,9 @@ GRAD_STREAM_BF16 = os.environ.get("BSCLIP_GRAD_STREAM", "bf16").lower() != "f32"
 # Cost, measured on the CPU oracle at depth 12: the distance to the f32 reference grows by ~10 % (2.5e-2 -> 2.8e-2),
 # the gradients' not at all.  "f32" restores round 2's stream.  Full fine-tuning and fp8 trunks keep f32.
 RESID_STREAM_BF16 = os.environ.get("BSCLIP_RESID_STREAM", "bf16").lower() != "f32"
+
+
+_WS_GEN = itertools.count(1)   # every workspace gets a unique, never reused number (hip/graph.py keys captured graphs on it)
 
 
 def _bf16(w, dev):
@@ -239,7 +243,7 @@ class ViTEngine(EncoderEngineBase):
         dev, H, S, L, FF = self.device, self.H, self.S, len(self.layers), self.FF
         M = B * S
         z = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
-        ws = {"B": B, "M": M}
+        ws = {"B": B, "M": M, "gen": next(_WS_GEN)}
         ws["cols"] = z(B * 196, H)
         rb = ws["resid_bf16"] = RESID_STREAM_BF16 and not self.full_ft and not self.fp8
         ws["x"] = [z(M, H, dt=BF16 if rb else F32) for _ in range(2 * L + 1)]   # residual stream after every sub-layer
@@ -475,7 +479,7 @@ class BertEngine(EncoderEngineBase):
         dev, H, L, FF = self.device, self.H, len(self.layers), self.FF
         M = B * S
         z = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
-        ws = {"B": B, "S": S, "M": M}
+        ws = {"B": B, "S": S, "M": M, "gen": next(_WS_GEN)}
         ws["emb"] = z(M, H, dt=F32)
         ws["yb"] = [z(M, H + KPAD) for _ in range(L + 1)]   # LN outputs feeding each layer's QKV GEMM (+ LoRA t)
         rb = ws["resid_bf16"] = RESID_STREAM_BF16 and not self.full_ft and not self.fp8

@@ -24,6 +24,7 @@ class GraphedStep:
         self.static = None
         self.loss = None
         self.loss_buf = None
+        self.captured_for = None
         if not hasattr(optimizer, "enable_device_hyper"):
             raise TypeError("GraphedStep needs FusedAdamW (device-side lr / step)")
         optimizer.enable_device_hyper(True)
@@ -62,6 +63,36 @@ class GraphedStep:
                     raise ValueError(f"GraphedStep was captured for batch shape {tuple(dst.shape)}, got {tuple(src.shape)}")
                 dst.copy_(src, non_blocking=True)
 
+    def _signature(self):
+        """What the captured graph holds raw pointers into: each engine, its workspace (replaced when a forward of another
+        batch size runs in between -- the evaluation phase -- and then freed), its flat parameter buffer (replaced when a
+        checkpoint is loaded mid-run).  A replay after any of them changed would write into freed memory."""
+        sig = []
+        for m in self.model.modules():
+            eng = getattr(m, "_engine", None)
+            if eng is not None:
+                flat = getattr(eng, "flat", None)
+                ws = getattr(eng, "ws", None)
+                sig.append((id(eng), None if ws is None else ws["gen"], 0 if flat is None else flat.data.data_ptr()))
+        return tuple(sig)
+
+    def accepts(self, image, dna, text, label):
+        """False for a batch the captured graph cannot take (another shape / another set of modalities than the static
+        buffers hold): the caller enqueues that step eagerly."""
+        if self.static is None:
+            return True
+        for dst, src in zip(self.static, (image, dna, text, label)):
+            if (dst is None) != (src is None):
+                return False
+            if dst is None:
+                continue
+            if isinstance(dst, dict):
+                if set(dst) != set(src) or any(dst[k].shape != src[k].shape for k in dst):
+                    return False
+            elif dst.shape != src.shape or dst.dtype != src.dtype:
+                return False
+        return True
+
     def __call__(self, image, dna, text, label):
         """One optimisation step; returns the loss as a device scalar (no host synchronisation)."""
         self._stage(image, dna, text, label)
@@ -69,8 +100,13 @@ class GraphedStep:
             self.warmup_left -= 1
             self.loss = self._body()
             return self.loss
+        if self.graph is not None and self._signature() != self.captured_for:
+            self.graph = None                 # an engine / workspace / flat buffer was replaced: one eager step, then re-capture
+            self.loss = self._body()
+            return self.loss
         if self.graph is None:
             torch.cuda.synchronize()
+            self.captured_for = self._signature()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = self._body()

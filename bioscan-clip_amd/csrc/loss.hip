@@ -194,7 +194,11 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
     contrib[i] = cnt[i] * l - dot;
 }
 
-int g_infonce_impl = 0;  // 0 = fused epilogues (default), 1 = f32 logits slabs + separate reduce kernels
+// 0 = by size (default): below 2 048 padded rows a product is <= 8 x 8 tiles of the 256 x 256 GEMM -- at the bench's N = 256 ONE
+// tile per directed pair, 255 CUs idle -- and the slab form on 128 x 128 tiles is faster (0.18 vs 0.28 ms at N = 256, 1.35 vs
+// 1.27 at N = 2 048, 8.3 vs 4.5 at N = 8 192: profiles/r02_e_infonce_fused_vs_slab.log); 1 = f32 logits slabs + separate reduce
+// kernels; 2 = fused epilogues
+int g_infonce_impl = 0;
 
 inline int64_t align4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
@@ -260,7 +264,7 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
     float* cnt = ws + L.cnt;
     float* dacc = ws + L.dacc;
     float* part = ws + L.part;
-    const bool fused = g_infonce_impl == 0;
+    const bool fused = g_infonce_impl == 2 || (g_infonce_impl == 0 && Np >= 2048);
     const size_t opA = (size_t)Np * 3 * D;  // elements per modality in PA / PB
     const size_t opT = (size_t)D * 3 * Np;  // elements per modality in PBt
 
@@ -351,7 +355,7 @@ extern "C" int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int
 }
 
 extern "C" int bsclip_infonce_set_impl(int impl) {
-    BSCLIP_REQUIRE(impl == 0 || impl == 1, "bsclip_infonce_set_impl: %d (0 = fused epilogues, 1 = logits slabs)", impl);
+    BSCLIP_REQUIRE(impl >= 0 && impl <= 2, "bsclip_infonce_set_impl: %d (0 = by size, 1 = logits slabs, 2 = fused epilogues)", impl);
     g_infonce_impl = impl;
     return BSCLIP_OK;
 }

@@ -217,9 +217,10 @@ int bsclip_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, in
  * all-gathered batch); pass row0 = 0, n_local = N for the local-batch loss.
  * workspace: f32, at least bsclip_infonce_workspace_floats(N, nmod) elements. */
 int64_t bsclip_infonce_workspace_floats(int N, int nmod);
-/* implementation switch for benchmarking / cross-checking: 0 (default) = fused -- the logits tile stays in the MFMA
+/* implementation switch for benchmarking / cross-checking: 2 = fused -- the logits tile stays in the MFMA
  * accumulators, row max / log-sum-exp reduced with wave shuffles in the GEMM epilogue, pass 2 emits dL/dG from the
- * accumulators; 1 = logits formed in f32 row slabs in the workspace and reduced by separate kernels (round 1) */
+ * accumulators; 1 = logits formed in f32 row slabs in the workspace and reduced by separate kernels (round 1);
+ * 0 (default) = by size: fused from 2 048 (padded) rows up, slabs below, where a product is too few 256 x 256 tiles to fill the chip */
 int bsclip_infonce_set_impl(int impl);
 int bsclip_infonce_fwd_bwd(const float* const* z, int nmod, const int64_t* labels, int N, int D, float scale,
                            int row0, int n_local, float* loss_out, float* const* dz, float* workspace,

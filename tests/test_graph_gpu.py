@@ -195,3 +195,38 @@ def test_optimizer_state_survives_rebuild_and_state_dict_roundtrip():
         step(b, o_b)
     for k, v in want.items():
         assert torch.equal(dict(b.named_parameters())[k], v), k
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("cfg", ["lora_vit_lora_barcode_bert_ssl", "full_fine_tuning/one_cycle/image_dna_one_cycle"])
+def test_train_cl_graph_path_equals_eager(cfg, tmp_path, monkeypatch, capsys):
+    """``scripts/train_cl.py`` runs what ``bench.py`` measures.  The drop-in entry point under the replayed
+    hipGraph (default) gives the eager loop's epoch losses bit for bit, for the LoRA and the full fine-tuning configuration, at
+    full depth with dropout active, across an evaluation phase of ANOTHER batch size between the epochs (the engines' workspaces
+    are replaced there: the captured graph must notice and re-capture instead of replaying into freed memory)."""
+    import os
+    import sys as _sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    scripts = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bioscan-clip_amd", "scripts")
+    _sys.path.insert(0, scripts)
+    import train_cl
+    from bioscanclip.hip import graph as G
+    argv = [f"model_config={cfg}", "model_config.batch_size=32", "model_config.epochs=2", "synthetic_steps_per_epoch=6",
+            "synthetic_eval=true", "synthetic_eval_batches=1", "debug_flag=true", f"project_root_path={tmp_path}"]
+    runs, captures = {}, {}
+    orig = G.GraphedStep._signature
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BSCLIP_GRAPH", mode)
+        torch.manual_seed(77)
+        n = {"captures": 0}
+
+        def counting(self, _n=n):
+            _n["captures"] += 1
+            return orig(self)
+        monkeypatch.setattr(G.GraphedStep, "_signature", counting)
+        runs[mode] = train_cl.main(argv)
+        captures[mode] = n["captures"]
+    capsys.readouterr()
+    assert captures["0"] == 0 and captures["1"] > 0           # the default path really went through GraphedStep
+    assert len(runs["0"]) == 2 and runs["0"] == runs["1"], runs

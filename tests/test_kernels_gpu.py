@@ -503,7 +503,7 @@ def test_infonce_fused_epilogues_vs_logits_slabs(ops, N, nmod):
     ws = torch.empty(ops.infonce_workspace_floats(N, nmod), device="cuda")
     res, ms = {}, {}
     try:
-        for impl in (0, 1):
+        for impl in (2, 1):   # 2 = fused epilogues (forced), 1 = logits slabs; 0 = by size is the default
             ops.infonce_set_impl(impl)
             loss = torch.zeros(1, device="cuda")
             dz = [torch.empty(N, 768, device="cuda") for _ in range(nmod)]
@@ -518,12 +518,12 @@ def test_infonce_fused_epilogues_vs_logits_slabs(ops, N, nmod):
             res[impl] = (loss.item(), [d.clone() for d in dz])
     finally:
         ops.infonce_set_impl(0)
-    assert abs(res[0][0] - res[1][0]) < 2e-6 * abs(res[1][0]), (res[0][0], res[1][0])
-    for a, b in zip(res[0][1], res[1][1]):
+    assert abs(res[2][0] - res[1][0]) < 2e-6 * abs(res[1][0]), (res[2][0], res[1][0])
+    for a, b in zip(res[2][1], res[1][1]):
         assert rel_err(a, b) < 2e-5
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/infonce_timing.jsonl", "a") as f:
-        f.write(json.dumps({"N": N, "nmod": nmod, "fused_ms": ms[0], "slab_ms": ms[1]}) + "\n")
+        f.write(json.dumps({"N": N, "nmod": nmod, "fused_ms": ms[2], "slab_ms": ms[1]}) + "\n")
 
 
 # ------------------------------------------------------------------------------- full fine-tuning kernels

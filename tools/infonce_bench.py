@@ -10,7 +10,7 @@ for N, nmod, nl in ((256, 2, 256), (2048, 3, 256), (8192, 3, 1024)):
     label = torch.arange(N).cuda()
     ws = torch.empty(ops.infonce_workspace_floats(N, nmod), device="cuda")
     out = {}
-    for impl in (0, 1):
+    for impl in (2, 1, 0):   # fused (forced), logits slabs, by size (the default)
         ops.infonce_set_impl(impl)
         loss = torch.zeros(1, device="cuda")
         dz = [torch.empty(nl, 768, device="cuda") for _ in range(nmod)]
@@ -24,5 +24,5 @@ for N, nmod, nl in ((256, 2, 256), (2048, 3, 256), (8192, 3, 1024)):
         torch.cuda.synchronize()
         out[impl] = (e0.elapsed_time(e1) / 10, loss.item())
     ops.infonce_set_impl(0)
-    print(f"N={N:5d} modalities={nmod} local rows={nl:5d}: fused {out[0][0]:8.3f} ms   logits slabs {out[1][0]:8.3f} ms   "
-          f"(loss {out[0][1]:.6f} / {out[1][1]:.6f})", flush=True)
+    print(f"N={N:5d} modalities={nmod} local rows={nl:5d}: fused {out[2][0]:8.3f} ms   logits slabs {out[1][0]:8.3f} ms   "
+          f"default (by size) {out[0][0]:8.3f} ms   (loss {out[2][1]:.6f} / {out[1][1]:.6f})", flush=True)
