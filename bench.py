@@ -35,10 +35,10 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md chip t
 GFLOP_PER_PAIR_ID = 118.3   # fwd 58.8 + LoRA-regime bwd
 GFLOP_PER_TRIPLE_IDT = 119.3
 # HBM-side bytes per launch of the dominant kernel: NOT measured by this run (PMC passes need rocprofv3 around the process).
-# Offline figure: (11 x 953.3 + 12 x 644.9 + 154.5) / 24 MB from the per-shape FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE
+# Offline figure: (11 x 959.6 + 12 x 639.6 + 154.4) / 24 MB from the per-shape FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE
 # passes of profiles/r03_b_fc1_pmc.txt (tools/scripts/r03_pmc.sh; the kernel's loop and stores are unchanged since
 # profiles/r02_c_fc1_pmc.txt, which gave the same numbers).
-FC1_TRAFFIC_BYTES_B256 = 765.8e6
+FC1_TRAFFIC_BYTES_B256 = 766.1e6
 FC1_TRAFFIC_SOURCE = "offline rocprofv3 --pmc passes (profiles/r03_b_fc1_pmc.txt, tools/scripts/r03_pmc.sh), not collected by this run"
 METRIC = "paired samples/sec/node (I+D+T, global batch) + step MFMA-roofline % at 1/2/4/8 GPU"   # BASELINE.json:metric, verbatim
 
