@@ -77,13 +77,8 @@ class GpuAugment:
         return {"box": box, "hflip": hflip, "vflip": vflip,
                 "angle": self.degrees[0] + (self.degrees[1] - self.degrees[0]) * u()}
 
-    def __call__(self, images, params=None, device="cuda"):
-        """images: list of uint8 tensors [H, W, 3] (CPU or GPU).  Returns (f32 [B, 3, S, S] on ``device``, the draws used)."""
-        B = len(images)
-        sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
-        resized = [_resized_size(h, w, self.resize_to) for h, w in sizes]
-        if params is None:
-            params = [self.sample(h1, w1) for h1, w1 in resized]
+    def _records(self, sizes, resized, params):
+        """The 16-int parameter record per image that ``bsclip_augment_images`` reads (csrc/pipeline.hip)."""
         f2i = lambda f: struct.unpack("<i", struct.pack("<f", f))[0]
         rec, off = [], 0
         for (h0, w0), (h1, w1), p in zip(sizes, resized, params):
@@ -95,9 +90,24 @@ class GpuAugment:
             rec += [lo - (1 << 32) if lo >= (1 << 31) else lo, off >> 32, h0, w0, h1, w1,
                     i, j, h, w, int(p["hflip"]), int(p["vflip"]), int(p["angle"] != 0.0), f2i(math.cos(rot)), f2i(-math.sin(rot)), 0]
             off += h0 * w0 * 3
-        src = torch.cat([im.reshape(-1).to(device=device, dtype=torch.uint8) for im in images])
+        return rec
+
+    def run_packed(self, src, sizes, params=None, device="cuda"):
+        """``src``: uint8 device buffer holding the images back to back (H x W x 3 each, ``sizes`` = [(H, W), ...]) -- the form the
+        shard loader stages.  Returns (f32 [B, 3, S, S], the draws used)."""
+        B = len(sizes)
+        resized = [_resized_size(h, w, self.resize_to) for h, w in sizes]
+        if params is None:
+            params = [self.sample(h1, w1) for h1, w1 in resized]
+        rec = self._records(sizes, resized, params)
         cap = max(h1 * w1 for h1, w1 in resized)
         mid = torch.empty(B * 3 * cap, dtype=torch.float32, device=device)
         out = torch.empty(B, 3, self.out_size, self.out_size, dtype=torch.float32, device=device)
-        ops.augment_images(src, torch.tensor(rec, dtype=torch.int32, device=device), B, cap, mid, self.out_size, out)
+        ops.augment_images(src, torch.tensor(rec, dtype=torch.int32).to(device, non_blocking=True), B, cap, mid, self.out_size, out)
         return out, params
+
+    def __call__(self, images, params=None, device="cuda"):
+        """images: list of uint8 tensors [H, W, 3] (CPU or GPU).  Returns (f32 [B, 3, S, S] on ``device``, the draws used)."""
+        sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
+        src = torch.cat([im.reshape(-1).to(device=device, dtype=torch.uint8) for im in images])
+        return self.run_packed(src, sizes, params, device=device)

@@ -118,12 +118,21 @@ def main_process(rank: int, world_size: int, args):
     steps = int(getattr(args, "synthetic_steps_per_epoch", 20))
     with_text = hasattr(mc, 'language')
     dataset = getattr(args, "dataset", "synthetic")
-    if dataset not in ("synthetic", "synthetic_raw"):
-        raise NotImplementedError("the HDF5 reader is outside the accelerated path (SURVEY 8f-3; h5py is absent): use "
-                                  "dataset=synthetic, or dataset=synthetic_raw to run the GPU input pipeline (augmentation + "
-                                  "5-mer tokeniser) on raw uint8 images / nucleotide strings")
-    Loader = SyntheticRawLoader if dataset == "synthetic_raw" else SyntheticCLIPLoader
-    pre_train_dataloader = Loader(int(mc.batch_size), steps, with_text=with_text, rank=rank, world_size=world_size)
+    from bioscanclip.util import shards
+    if shards.is_shard(str(dataset)):
+        # a pre-decoded shard directory (bioscanclip/util/shards.py): the reference's Dataset_for_CL + prepare() (dataset.py:41-48,
+        # 97-275) -- DistributedSampler(drop_last=True) order, pinned double-buffered H2D on a side stream, GPU augmentation and
+        # k-mer tokeniser; shuffled like the reference's pre-training loader (train_cl.py: shuffle=True)
+        pre_train_dataloader = shards.ShardLoader(str(dataset), int(mc.batch_size), rank=rank, world_size=world_size, shuffle=True,
+                                                  seed=int(getattr(args, "seed", 0)), for_training=True, with_text=with_text,
+                                                  device=device)
+    elif dataset not in ("synthetic", "synthetic_raw"):
+        raise NotImplementedError("the HDF5 file itself is outside the accelerated path (SURVEY 8f-3; h5py is absent): convert a "
+                                  "split with bioscanclip.util.shards.convert_hdf5_split and pass dataset=<shard directory>, or use "
+                                  "dataset=synthetic / dataset=synthetic_raw")
+    else:
+        Loader = SyntheticRawLoader if dataset == "synthetic_raw" else SyntheticCLIPLoader
+        pre_train_dataloader = Loader(int(mc.batch_size), steps, with_text=with_text, rank=rank, world_size=world_size)
 
     print_when_rank_zero("Initialize model...", rank)
     if not hasattr(args, "allow_random_init"):
@@ -163,6 +172,8 @@ def main_process(rank: int, world_size: int, args):
     best_epoch, best_overall_acc = None, None
     losses = []
     for epoch in range(mc.epochs):
+        if hasattr(pre_train_dataloader, "set_epoch"):
+            pre_train_dataloader.set_epoch(epoch)   # a new shuffle per epoch (DistributedSampler.set_epoch)
         losses.append(train_epoch(getattr(args, "activate_wandb", False), mc.epochs, epoch, pre_train_dataloader, model,
                                   optimizer, criterion, device, rank=rank, scheduler=scheduler,
                                   for_open_clip=False))
