@@ -25,7 +25,9 @@ wherever h5py and PIL exist (not in this image: documented, exercised by nothing
   * a producer thread gathers batch k+1 from the memory-mapped arrays into PINNED staging buffers while batch k trains, then, on
     a side HIP stream, copies it to the device and runs the two per-sample transforms there (``GpuAugment``: Resize 256 ->
     RandomResizedCrop 224 -> flips -> rotation, or Resize -> CenterCrop for evaluation; ``tokenize_barcodes``); the consumer's
-    stream waits on the slot's event, the host never blocks on the copy (three slots: produce / consume / in flight).
+    stream waits on the batch's event, the host never blocks on the copy.  Three staging slots; a slot's pinned buffers are refilled
+    only after its previous copies have executed; the tensors handed to the consumer are fresh allocations of the side stream
+    (``record_stream`` keeps the allocator from recycling them under the consumer).
 """
 import json
 import os
@@ -151,6 +153,8 @@ class ShardLoader:
         self.batch_size, self.rank, self.world_size = int(batch_size), rank, world_size
         self.shuffle, self.seed, self.epoch = shuffle, seed, 0
         self.for_training, self.with_text, self.device = for_training, with_text, torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.augment = GpuAugment(for_training=for_training, seed=(seed + 17 * rank) if augment_seed is None else augment_seed)
         self.stream = torch.cuda.Stream(device=self.device)
         self._slots = [dict(cap_img=0, cap_dna=0) for _ in range(self.SLOTS)]
@@ -227,8 +231,6 @@ class ShardLoader:
         from bioscanclip.hip import ops
         B = len(host["sizes"])
         with torch.cuda.stream(self.stream):
-            if "free" in slot:
-                self.stream.wait_event(slot["free"])          # the consumer is done with what this slot held before
             slot["img_dev"][:host["nbytes"]].copy_(slot["img_host"][:host["nbytes"]], non_blocking=True)
             n_dna = host["n_dna"]
             slot["dna_dev"][:max(n_dna, 1)].copy_(slot["dna_host"][:max(n_dna, 1)], non_blocking=True)
@@ -259,6 +261,10 @@ class ShardLoader:
                 torch.cuda.set_device(dev)
                 for k, b in enumerate(batches):
                     slot = self._slots[k % self.SLOTS]
+                    if "out" in slot:
+                        # the slot's pinned buffers are about to be refilled: its previous H2D copies (and the kernels that read
+                        # its device staging buffers) must have run -- three batches ago, so this never waits in practice
+                        slot["out"]["ready"].synchronize()
                     host = self._stage(slot, b)
                     q.put((k, b, self._enqueue(slot, host)))
                 q.put(None)
@@ -267,7 +273,6 @@ class ShardLoader:
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
-        prev = None
         while True:
             item = q.get()
             if item is None:
@@ -276,15 +281,10 @@ class ShardLoader:
                 raise item
             k, b, out = item
             cur = torch.cuda.current_stream(dev)
-            if prev is not None:                                # the consumer has enqueued everything that reads the previous batch
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                self._slots[prev % self.SLOTS]["free"] = ev
             cur.wait_event(out["ready"])
             for t in (out["image"], out["dna"], *[x for x in out["text"] if x is not None]):
                 t.record_stream(cur)
             self.last_params, self.last_indices = out["params"], b
-            prev = k
             yield (out["processid"], out["image"], out["dna"], out["text"][0], out["text"][1], out["text"][2], out["label"])
         th.join()
 
