@@ -35,6 +35,10 @@ GRAD_STREAM_BF16 = os.environ.get("BSCLIP_GRAD_STREAM", "bf16").lower() != "f32"
 # Cost, measured on the CPU oracle at depth 12: the distance to the f32 reference grows by ~10 % (2.5e-2 -> 2.8e-2),
 # the gradients' not at all.  "f32" restores round 2's stream.  Full fine-tuning and fp8 trunks keep f32.
 RESID_STREAM_BF16 = os.environ.get("BSCLIP_RESID_STREAM", "bf16").lower() != "f32"
+# Patch embedding on split-bf16 operands (hi.hi + lo.hi + hi.lo in one K = 2304 GEMM): the first GEMM's operand rounding is the
+# one every block amplifies -- exact to ~2^-16 it takes the ViT's distance to the f32 reference at depth 12 from 2.5e-2 to
+# 1.7e-2 on the CPU emulation, for +0.8 % of the ViT's forward FLOPs.  "0" restores the plain bf16 GEMM.
+PATCH_SPLIT = os.environ.get("BSCLIP_PATCH_SPLIT", "1") != "0"
 
 
 _WS_GEN = itertools.count(1)   # every workspace gets a unique, never reused number (hip/graph.py keys captured graphs on it)
@@ -205,6 +209,10 @@ class ViTEngine(EncoderEngineBase):
         assert H == 768 and self.S == 197 and vit.patch_embed.proj.weight.shape[-1] == 16, \
             "HIP ViT engine is built for vit_base_patch16_224"
         self.w_patch = _bf16(vit.patch_embed.proj.weight.reshape(H, -1), dev)
+        # split-bf16 patch embedding (PATCH_SPLIT): the weight as [hi | hi | lo] against im2col rows [hi | lo | hi]
+        w32 = vit.patch_embed.proj.weight.detach().reshape(H, -1).to(dev, F32)
+        w_hi = w32.to(BF16)
+        self.w_patch3 = torch.cat([w_hi, w_hi, (w32 - w_hi.to(F32)).to(BF16)], dim=1).contiguous()
         self.b_patch = _f32(vit.patch_embed.proj.bias, dev)
         self.cls = _f32(vit.cls_token.reshape(-1), dev)
         self.pos = _f32(vit.pos_embed.reshape(self.S, H), dev)
@@ -244,7 +252,7 @@ class ViTEngine(EncoderEngineBase):
         M = B * S
         z = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
         ws = {"B": B, "M": M, "gen": next(_WS_GEN)}
-        ws["cols"] = z(B * 196, H)
+        ws["cols"] = z(B * 196, 3 * H if (PATCH_SPLIT and not self.full_ft) else H)
         rb = ws["resid_bf16"] = RESID_STREAM_BF16 and not self.full_ft and not self.fp8
         ws["x"] = [z(M, H, dt=BF16 if rb else F32) for _ in range(2 * L + 1)]   # residual stream after every sub-layer
         ws["h1"] = [z(M, H + KPAD) for _ in range(L)]                 # LN1 output + LoRA t (QKV operand)
@@ -295,7 +303,8 @@ class ViTEngine(EncoderEngineBase):
         x = ws["x"]
         EPI_R, EPI_P = (EPI_RESID_BF16, EPI_PATCH_BF16) if ws["resid_bf16"] else (EPI_RESID_F32, EPI_PATCH_F32)
         ops.im2col_patch16(image, ws["cols"])
-        ops.gemm(ws["cols"], self.w_patch, x[0], EPI_P, bias=self.b_patch, resid=self.pos)
+        ops.gemm(ws["cols"], self.w_patch3 if ws["cols"].shape[1] == 3 * H else self.w_patch, x[0], EPI_P, bias=self.b_patch,
+                 resid=self.pos)
         ops.vit_cls_rows(x[0], self.cls, self.pos, B, S, H)
         L = len(self.layers)
         for l, lay in enumerate(self.layers):

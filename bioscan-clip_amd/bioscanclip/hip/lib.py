@@ -54,7 +54,7 @@ SIGNATURES = {
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, F, U, I, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
-    "bsclip_im2col_patch16": (I, [P, I, P, P]),
+    "bsclip_im2col_patch16": (I, [P, I, P, I, I, P]),
     "bsclip_mask_to_bias": (I, [P, I, P, P]),
     "bsclip_vit_cls_rows": (I, [P, I, P, P, I, I, I, P]),
     "bsclip_bert_embed": (I, [P, P, I, I, I, P, I, P, P, P, P]),

@@ -264,8 +264,9 @@ def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=No
 def im2col_patch16(image, cols):
     B = image.shape[0]
     _req(image.dtype == F32 and image.is_contiguous() and tuple(image.shape[1:]) == (3, 224, 224), "image f32 [B,3,224,224]")
-    _req(cols.dtype == BF16 and cols.is_contiguous() and cols.shape[0] >= B * 196 and cols.shape[1] == 768, "cols bf16 [B*196,768]")
-    check(_l.load().bsclip_im2col_patch16(_p(image), B, _p(cols), _stream()))
+    _req(cols.dtype == BF16 and cols.is_contiguous() and cols.shape[0] >= B * 196 and cols.shape[1] in (768, 2304),
+         "cols bf16 [B*196, 768] (or [B*196, 2304]: split-bf16 rows [hi | lo | hi])")
+    check(_l.load().bsclip_im2col_patch16(_p(image), B, _p(cols), cols.shape[1], int(cols.shape[1] == 2304), _stream()))
 
 
 def mask_to_bias(mask, bias):

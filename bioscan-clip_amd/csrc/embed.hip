@@ -9,8 +9,13 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // out[(b*196 + py*14 + px), c*256 + ky*16 + kx] = image[b, c, py*16+ky, px*16+kx]; one thread = 8 output columns
+// SPLIT: the row is written as [hi | lo | hi] (3 x 768 columns), hi = bf16(x), lo = bf16(x - hi): against a weight stored as
+// [hi | hi | lo] one bf16 MFMA GEMM with K = 2304 forms hi.hi + lo.hi + hi.lo, i.e. the product to ~2^-16 instead of 2^-8
+// relative (the trick the loss GEMM uses).  The patch embedding is 0.4 % of the step's FLOPs and the one GEMM whose operand
+// rounding (5.3e-3 at its output) every later block amplifies: DESIGN.md 4.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void im2col_patch16_kernel(const float* __restrict__ img, int B,
-                                                              bf16_t* __restrict__ out) {
+                                                              bf16_t* __restrict__ out, int ld) {
     const long total = (long)B * 196 * 96;
     for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
         const int chunk = (int)(it % 96);
@@ -27,7 +32,17 @@ __global__ __launch_bounds__(256) void im2col_patch16_kernel(const float* __rest
         o[1] = pack_bf2(a[2], a[3]);
         o[2] = pack_bf2(d[0], d[1]);
         o[3] = pack_bf2(d[2], d[3]);
-        *reinterpret_cast<u32x4*>(out + (size_t)row * 768 + col) = o;
+        *reinterpret_cast<u32x4*>(out + (size_t)row * ld + col) = o;
+        if constexpr (SPLIT) {
+            auto hi = [](unsigned w, int k) { return bf2f((bf16_t)(k ? w >> 16 : w & 0xffff)); };
+            u32x4 l;
+            l[0] = pack_bf2(a[0] - hi(o[0], 0), a[1] - hi(o[0], 1));
+            l[1] = pack_bf2(a[2] - hi(o[1], 0), a[3] - hi(o[1], 1));
+            l[2] = pack_bf2(d[0] - hi(o[2], 0), d[1] - hi(o[2], 1));
+            l[3] = pack_bf2(d[2] - hi(o[3], 0), d[3] - hi(o[3], 1));
+            *reinterpret_cast<u32x4*>(out + (size_t)row * ld + 768 + col) = l;
+            *reinterpret_cast<u32x4*>(out + (size_t)row * ld + 1536 + col) = o;
+        }
     }
 }
 
@@ -188,13 +203,19 @@ extern "C" int bsclip_mask_to_bias(const int64_t* mask, int n, float* bias, void
     return BSCLIP_OK;
 }
 
-extern "C" int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16, void* stream) {
+extern "C" int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16, int ld_cols, int split, void* stream) {
     BSCLIP_REQUIRE(image && cols_bf16 && B > 0, "bsclip_im2col_patch16: bad args");
+    BSCLIP_REQUIRE(ld_cols % 8 == 0 && ld_cols >= (split ? 2304 : 768) && (((uintptr_t)cols_bf16) & 15) == 0,
+                   "bsclip_im2col_patch16: ld_cols=%d (>= %d, multiple of 8, 16-byte aligned rows)", ld_cols, split ? 2304 : 768);
     const long total = (long)B * 196 * 96;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(im2col_patch16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       image, B, static_cast<bf16_t*>(cols_bf16));
+    if (split)
+        hipLaunchKernelGGL((im2col_patch16_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           image, B, static_cast<bf16_t*>(cols_bf16), ld_cols);
+    else
+        hipLaunchKernelGGL((im2col_patch16_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           image, B, static_cast<bf16_t*>(cols_bf16), ld_cols);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

@@ -183,7 +183,9 @@ int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, c
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column
  * order (c, ky, kx) = conv weight.flatten(1).  cls rows: x[b*197] = cls + pos[0].
  * bert_embed: word[id] + pos[t] + type[tt] -> f32 [B*S, H] (HF BertEmbeddings before LayerNorm). */
-int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16, void* stream);
+/* split != 0: each row is written as [hi | lo | hi] (3 x 768 columns, ld_cols >= 2304) for the split-bf16 patch-embed GEMM
+ * against a weight stored as [hi | hi | lo] (K = 2304: hi.hi + lo.hi + hi.lo, ~2^-16 relative instead of 2^-8) */
+int bsclip_im2col_patch16(const float* image, int B, void* cols_bf16, int ld_cols, int split, void* stream);
 /* HF extended attention mask (BertModel, language_encoder.py:89): bias[i] = mask[i] ? 0 : finfo(f32).min */
 int bsclip_mask_to_bias(const int64_t* mask, int n, float* bias, void* stream);
 /* x[b*S, :] = cls_token + pos_embed[0] (x f32, or bf16 when x_bf16 != 0: the bf16 residual stream) */

@@ -33,6 +33,9 @@ def _q(x, emulate_bf16):
 # in f32 and rounded once when stored.  The rounding-aware evaluation (emulate_bf16=True) restates that rounding point too; set
 # to False to emulate the f32 stream (BSCLIP_RESID_STREAM=f32).  The plain f32 evaluation never rounds anything.
 EMULATE_RESID_BF16 = True
+# The ViT patch embedding runs on split-bf16 operands (hip/engine.py PATCH_SPLIT: hi.hi + lo.hi + hi.lo, ~2^-16 relative): the
+# rounding-aware evaluation leaves that one GEMM's operands unrounded.  False emulates the plain bf16 GEMM (BSCLIP_PATCH_SPLIT=0).
+EMULATE_PATCH_SPLIT = True
 
 
 def _rq(x, emulate_bf16):
@@ -88,7 +91,7 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
     # conv k=s=16 == im2col GEMM; column order (c, ky, kx) matches weight.flatten(1)
     gh, gw = image.shape[2] // ps, image.shape[3] // ps
     cols = image.reshape(B, 3, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, 3 * ps * ps)
-    x = linear(cols, w_pe.reshape(D, -1), p("patch_embed.proj.bias"), eb)
+    x = linear(cols, w_pe.reshape(D, -1), p("patch_embed.proj.bias"), eb and not EMULATE_PATCH_SPLIT)
     x = _rq(torch.cat([p("cls_token").expand(B, -1, -1), x], dim=1) + p("pos_embed"), eb)
     tap = (lambda name, t: taps.__setitem__(name, t.detach())) if taps is not None else (lambda name, t: None)
     tap("x0", x)

@@ -30,8 +30,10 @@ from oracle import refcpu, synth  # noqa: E402
 NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)  # parity = deterministic path
 # (embedding vs f32 oracle / golden, worst trainable-gradient tensor vs f32 oracle / golden): 2x the measured values
 # (gpurun_out/parity.jsonl, copied into DESIGN.md 4)
-TOL = {"dna_L2": (1.1e-2, 4e-2), "dna_L12": (2.6e-2, 7.5e-2), "txt_L4": (7e-3, 3.5e-2),
-       "vit_L2": (2.3e-2, 5e-2), "vit_L12": (4.3e-2, 1.9e-1)}
+# round 3 (bf16 residual stream + split-bf16 patch embedding), measured: dna_L2 7.2e-3 / 2.4e-2, dna_L12 1.5e-2 / 6.1e-2,
+# txt_L4 4.5e-3 / 2.1e-2, vit_L2 9.1e-3 / 1.9e-2, vit_L12 1.7e-2 / 7.2e-2 (round 2: vit_L12 2.1e-2 / 9.3e-2, tolerance 4.3e-2 / 1.9e-1)
+TOL = {"dna_L2": (1.4e-2, 4.7e-2), "dna_L12": (3e-2, 1.2e-1), "txt_L4": (9e-3, 4.2e-2),
+       "vit_L2": (1.9e-2, 4e-2), "vit_L12": (3.4e-2, 1.45e-1)}
 SELF_FACTOR = 1.5   # HIP-vs-emulating-oracle <= SELF_FACTOR x (emulating oracle f32-accumulate vs f64-accumulate)
 
 

@@ -320,11 +320,30 @@ def test_im2col_and_cls(ops):
     ops.im2col_patch16(img, cols)
     ref = img.reshape(B, 3, 14, 16, 14, 16).permute(0, 2, 4, 1, 3, 5).reshape(B * 196, 768)
     assert torch.equal(cols, ref.bfloat16())
+    # split-bf16 rows [hi | lo | hi] and the K = 2304 product against [hi | hi | lo] weights: ~2^-16 instead of 2^-8 relative
+    from bioscanclip.hip.lib import EPI_F32
+    cols3 = torch.empty(B * 196, 2304, device="cuda", dtype=torch.bfloat16)
+    ops.im2col_patch16(img, cols3)
+    hi = ref.bfloat16()
+    assert torch.equal(cols3[:, :768], hi) and torch.equal(cols3[:, 1536:], hi)
+    assert torch.equal(cols3[:, 768:1536], (ref - hi.float()).bfloat16())
+    w = dev(rnd(768, 768, seed=7, scale=0.05))
+    w = w - w.mean(dim=1, keepdim=True)                       # zero-sum filters: the regime where operand rounding costs most
+    w_hi = w.bfloat16()
+    w3 = torch.cat([w_hi, w_hi, (w - w_hi.float()).bfloat16()], dim=1).contiguous()
+    exact = (ref.double() @ w.double().t()).float()
+    out3, out1 = torch.empty(B * 196, 768, device="cuda"), torch.empty(B * 196, 768, device="cuda")
+    ops.gemm(cols3, w3, out3, EPI_F32)
+    ops.gemm(cols, w_hi, out1, EPI_F32)
+    assert rel_err(out3, exact) < 3e-5 and rel_err(out1, exact) > 1e-3, (rel_err(out3, exact), rel_err(out1, exact))
     x = torch.zeros(B * 197, 768, device="cuda")
     cls, pos = dev(rnd(768, seed=2)), dev(rnd(197, 768, seed=3))
     ops.vit_cls_rows(x, cls, pos, B, 197, 768)
     got = x.reshape(B, 197, 768)
     assert torch.equal(got[:, 0], (cls + pos[0]).expand(B, -1)) and (got[:, 1:] == 0).all()
+    xb = torch.zeros(B * 197, 768, device="cuda", dtype=torch.bfloat16)
+    ops.vit_cls_rows(xb, cls, pos, B, 197, 768)
+    assert torch.equal(xb.reshape(B, 197, 768)[:, 0], (cls + pos[0]).bfloat16().expand(B, -1))
 
 
 @pytest.mark.parametrize("H,vocab", [(768, 1027), (512, 30522)])
