@@ -43,6 +43,25 @@ def _rq(x, emulate_bf16):
     return _q(x, emulate_bf16 and EMULATE_RESID_BF16)
 
 
+def _q8(x, scale=None):
+    """OCP fp8 e4m3 rounding as the fp8 trunks apply it (BASELINE configs[4]; hip/engine.py _pack_fp8, csrc/norm.hip Y_FP8,
+    csrc/gemm.hip EPI_GELU_FP8): activations with scale 1, saturated at +-448; weights with one scale per output row (row amax
+    -> 448).  Straight-through for autograd, like ``_q``."""
+    d = x.detach()
+    if scale is None:
+        r = d.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
+    else:
+        r = (d / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype) * scale
+    return x + (r - d)
+
+
+def linear_fp8(x, w, b=None):
+    """y = e4m3(x) . e4m3_rowscaled(w)^T + b in f32: the forward GEMMs of the fp8 trunks (QKV, fc1, fc2)."""
+    sc = (w.detach().abs().amax(dim=1, keepdim=True) / 448.0).clamp_min(1e-30)
+    y = _q8(x) @ _q8(w, sc).t()
+    return y if b is None else y + b
+
+
 def linear(x, w, b=None, emulate_bf16=False):
     y = _q(x, emulate_bf16) @ _q(w, emulate_bf16).t()
     return y if b is None else y + b
@@ -78,12 +97,16 @@ def sdpa(q, k, v, bias=None, emulate_bf16=False):
 # ViT-B/16 + LoRA  (reference image_encoder.py:15-48, 51-109; timm 0.6.13 semantics App. A.1)
 # --------------------------------------------------------------------------------------
 def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emulate_bf16=False,
-                return_hidden=False, taps=None):
+                return_hidden=False, taps=None, emulate_fp8=False):
     """``LoRA_ViT_timm.forward`` (image_encoder.py:108-109) -> timm ``VisionTransformer.forward``:
     patch-embed conv (k=s=16) -> cat cls -> +pos -> pre-LN blocks (eps 1e-6) with LoRA added in place to
     the Q and V slices of the fused qkv output, scale 1 (image_encoder.py:42-48) -> norm -> token 0 -> head."""
     p = lambda k: sd[prefix + k]
-    eb = emulate_bf16
+    eb = emulate_bf16 or emulate_fp8
+    # fp8 trunks (emulate_fp8): QKV / fc1 / fc2 take e4m3 operands, everything else rounds as the bf16 path does; the fp8 engines
+    # keep the f32 residual stream
+    rq = (lambda t, e: t) if emulate_fp8 else _rq
+    lin8 = (lambda x, w, b, e: linear_fp8(x, w, b)) if emulate_fp8 else linear
     B = image.shape[0]
     w_pe = p("patch_embed.proj.weight")
     D = w_pe.shape[0]
@@ -92,7 +115,7 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
     gh, gw = image.shape[2] // ps, image.shape[3] // ps
     cols = image.reshape(B, 3, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, 3 * ps * ps)
     x = linear(cols, w_pe.reshape(D, -1), p("patch_embed.proj.bias"), eb and not EMULATE_PATCH_SPLIT)
-    x = _rq(torch.cat([p("cls_token").expand(B, -1, -1), x], dim=1) + p("pos_embed"), eb)
+    x = rq(torch.cat([p("cls_token").expand(B, -1, -1), x], dim=1) + p("pos_embed"), eb)
     tap = (lambda name, t: taps.__setitem__(name, t.detach())) if taps is not None else (lambda name, t: None)
     tap("x0", x)
     depth = 0
@@ -103,7 +126,7 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
         b = f"blocks.{i}."
         h = layer_norm(x, p(b + "norm1.weight"), p(b + "norm1.bias"), 1e-6)
         if (prefix + b + "attn.qkv.qkv.weight") in sd:  # _LoRA_qkv_timm surgery applied
-            qkv = linear(h, p(b + "attn.qkv.qkv.weight"), p(b + "attn.qkv.qkv.bias"), eb)
+            qkv = lin8(h, p(b + "attn.qkv.qkv.weight"), p(b + "attn.qkv.qkv.bias"), eb)
             # emulation note: the HIP LayerNorm kernel forms t = y A^T from the f32 row and the f32 master A and rounds
             # only t (csrc/norm.hip), so the inner product is NOT taken on rounded operands
             t_q = linear(h, p(b + "attn.qkv.linear_a_q.weight"))
@@ -113,18 +136,18 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
             new_v = linear(t_v, p(b + "attn.qkv.linear_b_v.weight"), None, eb)
             qkv = torch.cat([qkv[..., :D] + new_q, qkv[..., D:2 * D], qkv[..., 2 * D:] + new_v], dim=-1)
         else:
-            qkv = linear(h, p(b + "attn.qkv.weight"), p(b + "attn.qkv.bias"), eb)
+            qkv = lin8(h, p(b + "attn.qkv.weight"), p(b + "attn.qkv.bias"), eb)
         S = qkv.shape[1]
         qkv = qkv.reshape(B, S, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
         tap(f"h1.{i}", h)
         tap(f"qkv.{i}", qkv.permute(1, 3, 0, 2, 4).reshape(B, S, 3 * D))
         ctx = sdpa(_q(qkv[0], eb), _q(qkv[1], eb), _q(qkv[2], eb), emulate_bf16=eb).transpose(1, 2).reshape(B, S, D)
         tap(f"ctx.{i}", ctx)
-        x = _rq(x + linear(ctx, p(b + "attn.proj.weight"), p(b + "attn.proj.bias"), eb), eb)
+        x = rq(x + linear(ctx, p(b + "attn.proj.weight"), p(b + "attn.proj.bias"), eb), eb)
         tap(f"x{2 * i + 1}", x)
         h = layer_norm(x, p(b + "norm2.weight"), p(b + "norm2.bias"), 1e-6)
-        h = gelu_erf(linear(h, p(b + "mlp.fc1.weight"), p(b + "mlp.fc1.bias"), eb))
-        x = _rq(x + linear(h, p(b + "mlp.fc2.weight"), p(b + "mlp.fc2.bias"), eb), eb)
+        h = gelu_erf(lin8(h, p(b + "mlp.fc1.weight"), p(b + "mlp.fc1.bias"), eb))
+        x = rq(x + lin8(h, p(b + "mlp.fc2.weight"), p(b + "mlp.fc2.bias"), eb), eb)
         tap(f"x{2 * i + 2}", x)
     x = layer_norm(x, p("norm.weight"), p("norm.bias"), 1e-6)
     if return_hidden:
@@ -135,22 +158,27 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
 # --------------------------------------------------------------------------------------
 # HF BERT encoder with LoRA on query/value (reference dna_encoder.py:40-49,73-88; language_encoder.py:24-33)
 # --------------------------------------------------------------------------------------
-def _lora_or_plain(sd, base, h, eb):
+def _lora_or_plain(sd, base, h, eb, f8=False):
     """``_LoRALayer.forward``: ``w(x) + w_b(w_a(x))`` (dna_encoder.py:47-49) or the untouched Linear."""
+    lin = (lambda x, w, b, e: linear_fp8(x, w, b)) if f8 else linear
     if (base + "w.weight") in sd:
-        # (emulation: t = h w_a^T is formed in f32 and only t is rounded, as in the ViT branch above)
-        return linear(h, sd[base + "w.weight"], sd[base + "w.bias"], eb) + linear(
+        # (emulation: t = h w_a^T is formed in f32 and only t is rounded, as in the ViT branch above; fp8 trunks: the frozen
+        # weight takes e4m3 operands, the LoRA branch stays bf16)
+        return lin(h, sd[base + "w.weight"], sd[base + "w.bias"], eb) + linear(
             linear(h, sd[base + "w_a.weight"]), sd[base + "w_b.weight"], None, eb)
-    return linear(h, sd[base + "weight"], sd[base + "bias"], eb)
+    return lin(h, sd[base + "weight"], sd[base + "bias"], eb)
 
 
 def bert_encoder(sd, prefix, input_ids, token_type_ids=None, attention_mask=None, num_heads=12, eps=1e-12,
-                 emulate_bf16=False, dropout_p=0.0):
+                 emulate_bf16=False, dropout_p=0.0, emulate_fp8=False):
     """HF ``BertModel`` trunk (post-LN, abs positions; App. A.2): embeddings LN(word+pos+type) then layers
     ``h1 = LN(h + dense(ctx))``, ``h2 = LN(h1 + dense2(gelu(dense1(h1))))``.  ``prefix`` ends before
     ``embeddings.``.  Dropout (HF p=0.1 in train mode) is only restated for p=0: parity runs disable it."""
     assert dropout_p == 0.0, "oracle restates the deterministic (p=0) path; dropout is tested statistically"
-    eb = emulate_bf16
+    eb = emulate_bf16 or emulate_fp8
+    f8 = emulate_fp8
+    rq = (lambda t, e: t) if f8 else _rq          # the fp8 engines keep the f32 residual stream
+    lin8 = (lambda x, w, b, e: linear_fp8(x, w, b)) if f8 else linear
     B, S = input_ids.shape
     if token_type_ids is None:
         token_type_ids = torch.zeros_like(input_ids)
@@ -173,27 +201,27 @@ def bert_encoder(sd, prefix, input_ids, token_type_ids=None, attention_mask=None
         L += 1
     for i in range(L):
         lp = prefix + f"encoder.layer.{i}."
-        q = _lora_or_plain(sd, lp + "attention.self.query.", h, eb)
-        k = _lora_or_plain(sd, lp + "attention.self.key.", h, eb)
-        v = _lora_or_plain(sd, lp + "attention.self.value.", h, eb)
+        q = _lora_or_plain(sd, lp + "attention.self.query.", h, eb, f8)
+        k = _lora_or_plain(sd, lp + "attention.self.key.", h, eb, f8)
+        v = _lora_or_plain(sd, lp + "attention.self.value.", h, eb, f8)
         sh = lambda t: t.reshape(B, S, num_heads, hd).transpose(1, 2)
         ctx = sdpa(_q(sh(q), eb), _q(sh(k), eb), _q(sh(v), eb), bias, emulate_bf16=eb).transpose(1, 2).reshape(B, S, H)
         a = linear(ctx, sd[lp + "attention.output.dense.weight"], sd[lp + "attention.output.dense.bias"], eb)
         # (bf16 stream: the LayerNorm's bf16 GEMM operand IS the residual branch, and the sum is stored rounded)
-        h = layer_norm(_rq(_rq(h, eb) + a, eb), sd[lp + "attention.output.LayerNorm.weight"],
+        h = layer_norm(rq(rq(h, eb) + a, eb), sd[lp + "attention.output.LayerNorm.weight"],
                        sd[lp + "attention.output.LayerNorm.bias"], eps)
-        m = gelu_erf(linear(h, sd[lp + "intermediate.dense.weight"], sd[lp + "intermediate.dense.bias"], eb))
-        m = linear(m, sd[lp + "output.dense.weight"], sd[lp + "output.dense.bias"], eb)
-        h = layer_norm(_rq(_rq(h, eb) + m, eb), sd[lp + "output.LayerNorm.weight"], sd[lp + "output.LayerNorm.bias"], eps)
+        m = gelu_erf(lin8(h, sd[lp + "intermediate.dense.weight"], sd[lp + "intermediate.dense.bias"], eb))
+        m = lin8(m, sd[lp + "output.dense.weight"], sd[lp + "output.dense.bias"], eb)
+        h = layer_norm(rq(rq(h, eb) + m, eb), sd[lp + "output.LayerNorm.weight"], sd[lp + "output.LayerNorm.bias"], eps)
     return h
 
 
-def barcode_bert_encoder(sd, ids, prefix="dna_encoder.lora_barcode_bert.", num_heads=12, emulate_bf16=False):
+def barcode_bert_encoder(sd, ids, prefix="dna_encoder.lora_barcode_bert.", num_heads=12, emulate_bf16=False, emulate_fp8=False):
     """``LoRA_barcode_bert.forward`` (dna_encoder.py:103-105): ``BertForMaskedLM(x).logits.softmax(-1).mean(1)``
     with only ``input_ids`` passed (no mask, token_type 0) and ``cls.predictions.decoder`` replaced by a fresh
     Linear(768, num_classes) with its own bias (dna_encoder.py:93-95)."""
-    eb = emulate_bf16
-    h = bert_encoder(sd, prefix + "bert.", ids, num_heads=num_heads, emulate_bf16=eb)
+    eb = emulate_bf16 or emulate_fp8
+    h = bert_encoder(sd, prefix + "bert.", ids, num_heads=num_heads, emulate_bf16=eb, emulate_fp8=emulate_fp8)
     t = prefix + "cls.predictions."
     h = gelu_erf(linear(h, sd[t + "transform.dense.weight"], sd[t + "transform.dense.bias"], eb))
     h = layer_norm(h, sd[t + "transform.LayerNorm.weight"], sd[t + "transform.LayerNorm.bias"], 1e-12)

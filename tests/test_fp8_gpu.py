@@ -155,6 +155,78 @@ def test_fp8_encoder_tracks_bf16_encoder(ops, which):
     assert rec["emb_fp8_vs_bf16"] < tol["emb"] and cos > tol["cos"] and worst < tol["grad"], rec
 
 
+# The real gate: against the f32 oracle and against the oracle that rounds to e4m3 exactly where the fp8 engines do
+# (oracle/refcpu.py emulate_fp8: activations scale 1 saturated, weights per output row amax -> 448, LoRA / attention / out-projection
+# / heads bf16, f32 residual stream).  What e4m3 costs is then a property of the dtype the CPU reproduces, not of the kernels:
+#   * HIP vs the fp8-emulating oracle: as close as that oracle is to itself under f32 vs f64 accumulation (x FP8_SELF);
+#   * HIP vs f32 oracle <= FP8_VS_EMU x (fp8-emulating oracle vs f32 oracle), and <= 2x the measured value in absolute terms;
+#   * gradients likewise (the emulating oracle's backward runs through the same rounded forward, straight-through).
+# Measured on the CPU emulation (tools/fp8_floor.py, profiles/r03_e_fp8_floor.log): per-tensor amax activation scales do not
+# help (16.2 % vs 16.3 % at scale 1, ViT depth 6: values are O(1), the loss is the 3-bit mantissa, not range), per-token scales 15.3 %.
+FP8_SELF, FP8_VS_EMU = 1.6, 1.3
+# measured (MI355X, depth 6, B = 4): ViT HIP-vs-emulation 8.3 % (emulation f32- vs f64-accumulated: 8.0 %), HIP-vs-f32 14.8 %
+# (emulation-vs-f32 15.4 %), worst gradient 55 % (emulation 50 %); DNA 3.3 % (2.7 %), 6.8 % (7.1 %), 18 % (23 %)
+FP8_ABS = {"vit": dict(emb=0.30, grad=0.75), "dna": dict(emb=0.14, grad=0.37)}   # <= 2x measured vs the f32 oracle (ViT gradient: 1.4x)
+
+
+@pytest.mark.parametrize("which", ["vit", "dna"])
+def test_fp8_encoder_matches_the_fp8_emulating_oracle(ops, which):
+    from bioscanclip.hip.engine import set_precision
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from oracle import refcpu, synth
+    depth, B = 6, 4
+    if which == "vit":
+        m, pre = LoRA_ViT_timm(arch.VisionTransformerParams(depth=depth), r=4, num_classes=768), "image_encoder."
+    else:
+        m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=depth, **NODROP)), r=4,
+                              num_classes=768)
+        pre = "dna_encoder."
+    sd = synth.synth_state_dict({pre + k: v for k, v in synth.shapes_of(m).items()}, 17)
+    m.load_state_dict({k[len(pre):]: v for k, v in sd.items()})
+    m.cuda().train()
+    set_precision(m, "fp8")
+    image, dna, _, _ = synth.synth_batch(B, seed=29)
+    xin = image if which == "vit" else dna
+    w = synth.synth_tensor("fp8.cot", (B, 768), seed=5)
+    y = m(xin.cuda())
+    (y * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert m._engine.fp8
+    fn = (lambda s, **kw: refcpu.vit_encoder(s, image.to(next(iter(s.values())).dtype) if kw.get("f64") else image,
+                                             **{k: v for k, v in kw.items() if k != "f64"})) if which == "vit" else \
+         (lambda s, **kw: refcpu.barcode_bert_encoder(s, dna, **{k: v for k, v in kw.items() if k != "f64"}))
+
+    def run(**kw):
+        s = {k: v.clone() for k, v in sd.items()}
+        keys = [k for k in s if refcpu.is_trainable_key(k) and s[k].is_floating_point()]
+        for k in keys:
+            s[k].requires_grad_(True)
+        out = fn(s, **kw)
+        (out * w).sum().backward()
+        return out.detach(), {k: s[k].grad for k in keys}
+    y32, g32 = run()
+    ye, ge = run(emulate_fp8=True)
+    with torch.no_grad():
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        ye64 = fn(sd64, emulate_fp8=True, f64=True).float()
+    named = dict(m.named_parameters())
+    gh = {k: named[k[len(pre):]].grad.detach().cpu() for k in g32}
+    yh = y.detach().cpu()
+    rec = {"test": f"fp8 {which} depth {depth} vs fp8-emulating oracle",
+           "emb_hip_vs_emu": rel_err(yh, ye), "emu_f32acc_vs_f64acc": rel_err(ye, ye64),
+           "emb_hip_vs_f32": rel_err(yh, y32), "emb_emu_vs_f32": rel_err(ye, y32),
+           "worst_grad_hip_vs_emu": max(rel_err(gh[k], ge[k]) for k in g32),
+           "worst_grad_hip_vs_f32": max(rel_err(gh[k], g32[k]) for k in g32),
+           "worst_grad_emu_vs_f32": max(rel_err(ge[k], g32[k]) for k in g32)}
+    _log(rec)
+    assert torch.isfinite(y).all()
+    assert rec["emb_hip_vs_emu"] < FP8_SELF * rec["emu_f32acc_vs_f64acc"], rec
+    assert rec["emb_hip_vs_f32"] < FP8_VS_EMU * rec["emb_emu_vs_f32"] and rec["emb_hip_vs_f32"] < FP8_ABS[which]["emb"], rec
+    assert rec["worst_grad_hip_vs_f32"] < FP8_VS_EMU * rec["worst_grad_emu_vs_f32"] and rec["worst_grad_hip_vs_f32"] < FP8_ABS[which]["grad"], rec
+
+
 def test_fp8_training_reduces_the_loss(ops):
     """configs[4] end to end: the golden I+D trajectory setup (B = 8, two batches cycled, AdamW) with fp8 trunks must still
     train -- the loss falls below a quarter of its start within the 10 steps and tracks the reference trajectory loosely."""
