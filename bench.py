@@ -296,12 +296,13 @@ def main():
     opt = FusedAdamW(model.parameters(), lr=a.lr if a.lr is not None else (1e-6 if a.full_ft else 1e-3))
 
     # One process, one GPU: the whole step is captured once into a hipGraph and replayed (bioscanclip/hip/graph.py) -- the
-    # host does three calls per step instead of ~1 500.  With a process group the step stays eager: the collectives are issued
-    # from Python (tower-stream all-gathers, per-encoder all-reduces).
+    # host does three calls per step instead of ~1 500.
     graphed = None
-    if not (world > 1 or force_dist or a.no_graph):
-        from bioscanclip.hip.graph import GraphedStep
-        graphed = GraphedStep(model, opt, crit, warmup=2)
+    if not a.no_graph:
+        from bioscanclip.hip.graph import GraphedDistStep, GraphedStep
+        # with a process group: three captured graphs (towers' forward | loss + backward | AdamW), the all-gathers and all-reduces
+        # issued eagerly between them (hip/graph.py GraphedDistStep) -- a rank's host work drops from ~35 ms to ~1 ms per step
+        graphed = (GraphedDistStep if world > 1 or force_dist else GraphedStep)(model, opt, crit, warmup=2)
 
     def step():
         nonlocal graphed
@@ -389,7 +390,9 @@ def main():
                        "local_batch": B, "global_batch": N, "parallelism": f"dp{world}",
                        "dropout": ("DISABLED (diagnostic run, not the benchmark configuration)" if nodrop else
                                    "HF defaults active (BERT hidden 0.1, attention-probs 0.1; timm ViT drop 0), train mode"),
-                       "launch_path": "hipGraph replay (one captured step)" if graphed is not None else "eager (Python enqueue)",
+                       "launch_path": ("eager (Python enqueue)" if graphed is None else
+                                       "three captured hipGraphs (forward | loss + backward | AdamW), collectives issued eagerly between them"
+                                       if world > 1 or force_dist else "hipGraph replay (one captured step)"),
                        "final_loss": round(final_loss, 6)},
             "step_roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),

@@ -9,8 +9,9 @@ optimizer step.  Returns the mean loss of the epoch.
 Launch path (round 3): on one rank the step runs as ONE replayed hipGraph (``bioscanclip.hip.graph.GraphedStep``: the same
 Python body captured once -- bitwise the eager step, tests/test_graph_gpu.py) and the loss is read one step late, so the host
 never waits for the step it has just enqueued: what ``bench.py`` measures is what ``scripts/train_cl.py`` runs.  A batch whose
-shape differs from the captured one (a last, smaller batch) is enqueued eagerly.  ``BSCLIP_GRAPH=0`` forces the eager loop; with
-more than one rank the step stays eager (the collectives are issued from Python).
+shape differs from the captured one (a last, smaller batch) is enqueued eagerly.  ``BSCLIP_GRAPH=0`` forces the eager loop.  With
+more than one rank the step is three captured graphs (forward | loss + backward | AdamW) with the all-gathers and all-reduces
+issued eagerly between them (``GraphedDistStep``).
 """
 import os
 
@@ -44,13 +45,17 @@ def _graphed_step(model, optimizer, criterion, device):
     from bioscanclip.hip import dist as hdist
     if os.environ.get("BSCLIP_GRAPH", "1") == "0" or torch.device(device).type != "cuda":
         return None
-    if not hasattr(optimizer, "enable_device_hyper") or not hdist._inactive(None) or hasattr(criterion, "prefetch_labels"):
+    if not hasattr(optimizer, "enable_device_hyper"):
         return None
-    from bioscanclip.hip.graph import GraphedStep
+    multi = not hdist._inactive(None)
+    if multi != hasattr(criterion, "prefetch_labels"):     # a process group without the global-batch loss (or the reverse): eager
+        return None
+    from bioscanclip.hip.graph import GraphedDistStep, GraphedStep
     key = (id(optimizer), id(criterion))
     g = getattr(model, "_bsclip_graphed", None)
     if g is None or g[0] != key:
-        g = (key, GraphedStep(model, optimizer, criterion, warmup=2))
+        # more than one rank: three captured graphs with the collectives issued eagerly between them (GraphedDistStep)
+        g = (key, (GraphedDistStep if multi else GraphedStep)(model, optimizer, criterion, warmup=2))
         model._bsclip_graphed = g
     return g[1]
 
