@@ -1140,6 +1140,10 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
         const long t256 = (long)ceil_div(M, 256) * (N / 256);
         if (N % 256 == 0 && t256 >= 192) tile = 4;
         else tile = 1;
+        // the two-workgroups-per-CU kernel (gemm_duo.h) ties the ping-pong kernel on most shapes and wins where a tile is short
+        // (12 K-tiles) and the grid is a few rounds deep: the ViT's N = K = 768 GEMMs (out-projection and its dX: 60 vs 67 us,
+        // 76 vs 79 us at M = 50 432; profiles/r03_f_gemm_tiles.log).  BarcodeBERT's M = 34 048 (1.56 rounds) stays on ping-pong.
+        if (tile == 4 && N == 768 && K == 768 && t256 >= 500 && EPI != BSCLIP_EPI_GELU_BF16) tile = 5;
     }
     if ((tile == 3 || tile == 4 || tile == 6 || tile == 7) && N % 256 != 0) tile = 2;
     switch (tile) {

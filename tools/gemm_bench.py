@@ -7,14 +7,16 @@ sys.path.insert(0, os.path.join(ROOT, "bioscan-clip_amd"))
 import torch  # noqa: E402
 
 from bioscanclip.hip import ops  # noqa: E402
-from bioscanclip.hip.lib import EPI_BF16, EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32  # noqa: E402
+from bioscanclip.hip.lib import EPI_BF16, EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_BF16, EPI_RESID_F32  # noqa: E402
+
+EPI_R = EPI_RESID_F32 if os.environ.get('RESID', 'bf16') == 'f32' else EPI_RESID_BF16   # the residual stream's dtype (default: the engines')
 
 B = int(os.environ.get("B", "256"))
 TILES = tuple(int(t) for t in os.environ.get("TILES", "1,2,3,4,5").split(","))
 SHAPES = []
 for name, M in (("vit", B * 197), ("dna", B * 133)):
-    SHAPES += [(f"{name}.qkv", M, 2304, 832, EPI_BF16), (f"{name}.proj", M, 768, 768, EPI_RESID_F32),
-               (f"{name}.fc1", M, 3072, 768, EPI_GELU_BF16), (f"{name}.fc2", M, 768, 3072, EPI_RESID_F32),
+    SHAPES += [(f"{name}.qkv", M, 2304, 832, EPI_BF16), (f"{name}.proj", M, 768, 768, EPI_R),
+               (f"{name}.fc1", M, 3072, 768, EPI_GELU_BF16), (f"{name}.fc2", M, 768, 3072, EPI_R),
                (f"{name}.dfc2", M, 3072, 768, EPI_DGELU_BF16), (f"{name}.dfc1", M, 768, 3072, EPI_BF16),
                (f"{name}.dproj", M, 768, 768, EPI_BF16), (f"{name}.dqkv", M, 768, 2304, EPI_BF16)]
 
@@ -26,8 +28,8 @@ def run(M, N, K, epi, iters):
     f32 = epi == EPI_RESID_F32
     out = torch.empty(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
     kw = {}
-    if epi == EPI_RESID_F32:
-        kw["resid"] = torch.randn(M, N, device="cuda")
+    if epi in (EPI_RESID_F32, EPI_RESID_BF16):
+        kw["resid"] = torch.randn(M, N, device="cuda").to(out.dtype)
     if epi in (EPI_GELU_BF16, EPI_DGELU_BF16):
         kw["aux"] = torch.randint(0, 256, (M, N), device="cuda", dtype=torch.uint8)
     res = {}
