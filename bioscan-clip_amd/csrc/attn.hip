@@ -300,11 +300,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         const unsigned dbase = (bh * S + (unsigned)qrow) * SP + 4 * h;  // dropout index of (q, key 4h)
         // pass 1: delta_q = sum_key P[q,key] dP[q,key], from the SAME P and dP the gradient uses, so that
         // sum_key dS[q,key] = 0 holds to f32 rounding (delta from the bf16-rounded O does not: it loses the cancellation
-        // whenever the values of a head are nearly equal across keys).  P is recomputed in pass 2 rather than kept:
-        // 7 tiles x 16 registers would push the kernel past 256 VGPRs.
+        // whenever the values of a head are nearly equal across keys).  Round 3: P is formed ONCE -- pass 1 keeps it as packed
+        // bf16 (8 registers per key tile, 56 for S = 197), pass 2 recomputes only dP (f32: dP - delta is where the cancellation
+        // lives) and multiplies: one S product, 16 exp and 16 fma per tile less.  A bf16 P puts a 2^-9 RELATIVE error on each
+        // dS element (it is rounded to bf16 for the dQ product anyway); delta itself still comes from the f32 P.
         float dpart = 0.f;
-#pragma unroll 1
-        for (int kt = 0; kt < NB; ++kt) {
+        bf16x8 p16[NB][2];
+#pragma unroll
+        for (int kt = 0; kt < NB; ++kt) {   // unrolled: p16 must be indexed statically (a runtime index would put it in scratch)
+            asm volatile("" ::: "memory");    // ... but keep each tile's LDS reads inside its own iteration (register pressure)
             f32x16 s, dp = zero16();
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -326,37 +330,38 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                     const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, nlse_q));
                     if constexpr (DROP) dpart = fmaf(pr, dp[4 * g + i] * k4[i], dpart);
                     else dpart = fmaf(pr, dp[4 * g + i], dpart);
+                    s[4 * g + i] = pr;
                 }
             }
+            p16[kt][0] = pack8(s, 0);
+            p16[kt][1] = pack8(s, 1);
         }
         const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
         if (h == 0) sDelta[q0 + (lane & 31)] = delta_q;
         if (blk == wave) stamp(6);
         // pass 2: dS^T = P^T (dP^T - delta);  dQ^T += K^T dS^T, scaled once at the end
         f32x16 dq[2] = {zero16(), zero16()};
-#pragma unroll 1
+#pragma unroll
         for (int kt = 0; kt < NB; ++kt) {
-            f32x16 s, dp = zero16();
+            asm volatile("" ::: "memory");
+            f32x16 dp = zero16();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * kt + 8 * g + 4 * h);
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s[4 * g + i] = b4[i];
-            }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 pu = __builtin_bit_cast(u32x4, p16[kt][s2]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);
-                dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);
-            }
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int g = 2 * s2 + g2;
+                    f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
-                if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, nlse_q));
-                    if constexpr (DROP) dp[4 * g + i] = pr * (dp[4 * g + i] * k4[i] - delta_q);
-                    else dp[4 * g + i] = pr * (dp[4 * g + i] - delta_q);
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned w = pu[2 * g2 + (i >> 1)];
+                        const float pr = __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+                        if constexpr (DROP) dp[4 * g + i] = pr * (dp[4 * g + i] * k4[i] - delta_q);
+                        else dp[4 * g + i] = pr * (dp[4 * g + i] - delta_q);
+                    }
                 }
             }
 #pragma unroll
