@@ -77,6 +77,11 @@ def ddp_setup(rank: int, world_size: int, port):
     torch.cuda.set_device(local_rank)
     if world_size > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", rank=rank, world_size=world_size)
+    if world_size > 1:
+        # host-thread budget for N ranks on one host: the step has no CPU tensor math (three graph launches and a handful of
+        # collectives per step, hip/graph.py GraphedDistStep), so each rank keeps a 2-thread intra-op pool -- with the input
+        # loader's producer thread and the runtime's helper threads that is <= 6 runnable threads per rank, 48 for 8 ranks
+        torch.set_num_threads(int(os.environ.get("BSCLIP_HOST_THREADS", "2")))
     return local_rank
 
 
