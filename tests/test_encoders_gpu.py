@@ -68,7 +68,7 @@ def _f64(sd):
     return {k: (v.detach().double() if v.is_floating_point() else v) for k, v in sd.items()}
 
 
-def _compare_encoder(name, module, prefix, sd, hip_in, oracle_fn, cot_key, gold):
+def _compare_encoder(name, module, prefix, sd, hip_in, oracle_fn, cot_key, gold, log_name=None):
     tol_emb, tol_grad = TOL[name]
     module.to("cuda")
     module.train()
@@ -83,7 +83,7 @@ def _compare_encoder(name, module, prefix, sd, hip_in, oracle_fn, cot_key, gold)
     with torch.no_grad():
         y_emu64 = oracle_fn(_f64(sd), emulate=True, f64=True)                   # same rounding points, f64 accumulation
     e_f32, e_emu, e_self = rel_err(y, yo), rel_err(y, y_emu), rel_err(y_emu, y_emu64)
-    rec = {"test": name, "emb_vs_f32_oracle": e_f32, "emb_vs_bf16_emulating_oracle": e_emu,
+    rec = {"test": log_name or name, "emb_vs_f32_oracle": e_f32, "emb_vs_bf16_emulating_oracle": e_emu,
            "emulating_oracle_f32acc_vs_f64acc": e_self, "emulating_oracle_vs_f32_oracle": rel_err(y_emu, yo), "grads": {}}
     named = dict(module.named_parameters())
     worst = worst_emu = floor = 0.0
