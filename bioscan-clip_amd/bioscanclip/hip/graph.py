@@ -205,6 +205,8 @@ class GraphedDistStep(GraphedStep):
         for w in works:
             w.wait()
         self.gC.replay()
+        if hasattr(self.optimizer, "sync_updated_slices"):
+            self.optimizer.sync_updated_slices()      # sharded optimizer state (full fine-tuning): owners broadcast their slices
         return self.loss_buf
 
     def __call__(self, image, dna, text, label):

@@ -17,6 +17,51 @@ class FusedAdamW(torch.optim.Optimizer):
         self._flat_state = {}
         self._flats = []
         self._dev_hyper = False
+        self._shard = None        # (rank, world, group): optimizer-state sharding over the ranks (shard_state)
+
+    def shard_state(self, group=None):
+        """Multi-rank full fine-tuning (every rank would otherwise hold the full 2 x 4 B per parameter of AdamW
+        moments: 3.2 GB for I+D+T): each rank keeps the moments of ONE contiguous slice of every flat buffer and updates only
+        that slice; after the update every slice is broadcast from its owner (``sync_updated_slices``, W small collectives per
+        flat buffer -- they work on every backend and between graph replays).  Gradients are still all-reduced over the whole
+        buffer (hip/dist.py), so the update itself is the unsharded one, element for element."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            self._shard = None
+            return self
+        if self._flat_state:
+            raise RuntimeError("FusedAdamW.shard_state: call before the first step (moments are already allocated unsharded)")
+        self._shard = (dist.get_rank(group), dist.get_world_size(group), group)
+        return self
+
+    def _slice_of(self, f, rank=None):
+        """[lo, hi) of flat buffer ``f`` owned by ``rank`` (default: this rank): equal 4-element-aligned slices, the last one short."""
+        n = f.data.numel()
+        if self._shard is None:
+            return 0, n
+        r, W, _ = self._shard
+        r = r if rank is None else rank
+        per = (-(-n // W) + 3) // 4 * 4
+        return min(r * per, n), min((r + 1) * per, n)
+
+    def sync_updated_slices(self):
+        """Broadcast every rank's freshly updated parameter slice to the others.  Eager: called by ``step()`` outside a capture
+        and by ``GraphedDistStep`` after its optimizer graph."""
+        if self._shard is None:
+            return
+        import torch.distributed as dist
+        _, W, group = self._shard
+        works = []
+        for f in self._flats:
+            if not f.valid():
+                continue
+            for r in range(W):
+                lo, hi = self._slice_of(f, r)
+                if hi > lo:
+                    works.append(dist.broadcast(f.data[lo:hi], src=dist.get_global_rank(group, r) if group is not None else r,
+                                                group=group, async_op=True))
+        for w in works:
+            w.wait()
 
     def enable_device_hyper(self, on=True):
         """Read (lr, step) from device memory inside the kernel (``bsclip_adamw_step_dev``) instead of passing them as launch
@@ -61,6 +106,14 @@ class FusedAdamW(torch.optim.Optimizer):
         the moments like torch.optim.AdamW's do."""
         key = tuple(id(p) for p in f.params)
         st = self._flat_state.get(id(f))
+        if self._shard is not None:
+            lo, hi = self._slice_of(f)
+            if st is None or st["m"].numel() != hi - lo or st.get("key") != key:
+                st = {"m": torch.zeros(hi - lo, dtype=f.data.dtype, device=f.data.device),
+                      "v": torch.zeros(hi - lo, dtype=f.data.dtype, device=f.data.device), "step": 0, "key": key, "slice": (lo, hi)}
+                self._flat_state = {k: v for k, v in self._flat_state.items() if v.get("key") != key}
+                self._flat_state[id(f)] = st
+            return st
         if st is None or st["m"].numel() != f.data.numel() or st.get("key") != key:
             prev = next((v for v in self._flat_state.values() if v.get("key") == key and v["m"].numel() == f.data.numel()), None)
             st = {"m": torch.zeros_like(f.data), "v": torch.zeros_like(f.data), "step": 0, "key": key}
@@ -83,6 +136,9 @@ class FusedAdamW(torch.optim.Optimizer):
         return st
 
     def state_dict(self):
+        if self._shard is not None:
+            raise NotImplementedError("FusedAdamW: the moments are sharded over the ranks (shard_state); the reference checkpoints "
+                                      "the model only (train_cl.py:219-220)")
         for f in self._flats:                         # the per-parameter step counts follow the flat buffer's
             st = self._flat_state.get(id(f))
             if st is not None:
@@ -132,6 +188,11 @@ class FusedAdamW(torch.optim.Optimizer):
             st = self._state_for(f)
             f.bind_grads()
             st["step"] += 1
+            lo, hi = self._slice_of(f)
+            if hi <= lo:
+                handled.update(id(p) for p in f.params)
+                continue
+            fdata, fgrad = (f.data, f.grad) if self._shard is None else (f.data[lo:hi], f.grad[lo:hi])
             if self._dev_hyper:
                 capturing = torch.cuda.is_current_stream_capturing()
                 if "hyper" not in st:
@@ -146,10 +207,10 @@ class FusedAdamW(torch.optim.Optimizer):
                     if st.get("lr_staged") != lr:
                         st["hyper"].view(torch.float32)[0:1].fill_(lr)
                         st["lr_staged"] = lr
-                ops.adamw_step_dev(f.data, f.grad, st["m"], st["v"], st["hyper"], g["betas"][0], g["betas"][1], g["eps"],
+                ops.adamw_step_dev(fdata, fgrad, st["m"], st["v"], st["hyper"], g["betas"][0], g["betas"][1], g["eps"],
                                    g["weight_decay"])
             else:
-                ops.adamw_step(f.data, f.grad, st["m"], st["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                ops.adamw_step(fdata, fgrad, st["m"], st["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                g["weight_decay"], st["step"])
             handled.update(id(p) for p in f.params)
         for group in self.param_groups:
@@ -166,4 +227,6 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["step"] += 1
                 ops.adamw_step(p.data.view(-1), p.grad.view(-1), st["m"].view(-1), st["v"].view(-1), group["lr"],
                                group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"], st["step"])
+        if self._shard is not None and not torch.cuda.is_current_stream_capturing():
+            self.sync_updated_slices()
         return loss

@@ -150,6 +150,10 @@ def main_process(rank: int, world_size: int, args):
     if hasattr(mc, 'lr_config') and hasattr(mc.lr_config, 'lr'):
         lr = mc.lr_config.lr
     optimizer = FusedAdamW(model.parameters(), lr=lr)
+    if world_size > 1 and getattr(mc, "disable_lora", False):
+        # full fine-tuning on several ranks: each rank keeps the AdamW moments of one slice of every flat buffer (3.2 GB / W for
+        # I+D+T instead of 3.2 GB per rank) and broadcasts its updated slice (hip/optim.py shard_state)
+        optimizer.shard_state()
     scheduler = build_scheduler(args, optimizer, total_steps)
 
     if mc.for_open_clip:
