@@ -45,6 +45,7 @@ SIGNATURES = {
     "bsclip_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P]),
     "bsclip_init_tables": (I, [P]),
     "bsclip_gemm_set_tile": (I, [I]),
+    "bsclip_gemm_set_persistent_grid": (I, [I]),
     "bsclip_epi_args_size": (I, []),
     "bsclip_gemm_fp8": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), POINTER(Fp8Args), P]),
     "bsclip_quantize_rows_fp8": (I, [P, I, I, P, I, P, P]),

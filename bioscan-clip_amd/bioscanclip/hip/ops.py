@@ -152,6 +152,11 @@ def set_gemm_tile(tile):
     check(_l.load().bsclip_gemm_set_tile(tile))
 
 
+def set_gemm_persistent_grid(workgroups):
+    """Workgroups of the persistent GEMM kernel's launch (tile 8); 0 = one per CU."""
+    check(_l.load().bsclip_gemm_set_persistent_grid(workgroups))
+
+
 def layernorm_fwd(x, gamma, beta, eps, y_bf16=None, y_f32=None, lora_a=None, stats=None, M=None, dropout=None):
     ld_x = _rowmajor(x, "x")
     H = gamma.numel()

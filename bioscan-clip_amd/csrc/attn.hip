@@ -16,6 +16,8 @@
 // produce dK/dV, so nothing is accumulated across waves (no atomics, bitwise reproducible).
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -126,7 +128,17 @@ __device__ __forceinline__ f32x4 keep4(const DropCfg& d, unsigned idx) {
 // Dropout element index of P[q, key] for head-instance bh: ((bh * S + q) * SP + key), SP = padded length (multiple of
 // 32), so a lane's 4 consecutive keys share two hash pairs.
 
-template <int NB, bool DROP>
+// TAIL = number of valid rows of the LAST 32-row key / query tile (S - 32 (NB - 1)), as a template parameter for the production
+// sequence lengths (197 and 133 both leave 5) and 32 ("treat the tile as full") for every other S.  An accumulator register r of
+// a 32x32 tile holds row (r & 3) + 8 (r >> 2) + 4 h: the 4-register group g = r >> 2 covers rows [8g, 8g + 8), so in the last
+// tile only the first ceil(TAIL / 8) groups can hold a non-zero probability and only the first ceil(TAIL / 16) 16-deep k-steps
+// of a product over that tile's rows contribute.  Skipping the rest is decided at compile time (the tile loops are unrolled) --
+// round 2's attempt with wave-uniform RUNTIME branches cost the schedule more than it saved.  S = 197 pads to 224 rows (29 %
+// more tile pairs than needed), S = 133 to 160 (45 %): this removes the VALU share and a quarter of the MFMAs of that padding.
+template <int TAIL> constexpr int tail_groups() { return TAIL >= 32 ? 4 : (TAIL + 7) / 8; }
+template <int TAIL> constexpr int tail_ksteps() { return TAIL > 16 ? 2 : 1; }
+
+template <int NB, bool DROP, int TAIL = 32>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S,
                                                                    int heads, const float* __restrict__ key_bias,
                                                                    float scale, bf16_t* __restrict__ ctx, int ld_ctx,
@@ -181,21 +193,29 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) acc = mfma32(frag_rm(sK, 32 * kt, ks, lane), qf[ks], acc);
+            const int nr = 4 * (kt == NB - 1 ? tail_groups<TAIL>() : 4);   // registers that can hold a valid key
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r]);
+            for (int r = 0; r < 16; ++r)
+                if (r < nr) m = fmaxf(m, acc[r]);
             p[kt] = acc;
         }
         m = fmaxf(m, __shfl_xor(m, 32, 64));  // raw-score units
         const float nm2 = -m * scale2;
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NB; ++kt)
+        for (int kt = 0; kt < NB; ++kt) {
+            const int nr = 4 * (kt == NB - 1 ? tail_groups<TAIL>() : 4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(p[kt][r], scale2, nm2));
-                p[kt][r] = e;
-                sum += e;
+                if (r < nr) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(p[kt][r], scale2, nm2));
+                    p[kt][r] = e;
+                    sum += e;
+                } else {
+                    p[kt][r] = 0.f;   // rows past the sequence: probability 0 by construction
+                }
             }
+        }
         sum += __shfl_xor(sum, 32, 64);
         if constexpr (DROP) {  // HF: dropout on the normalised probabilities (the row sum above is taken before it)
             const unsigned base = ((unsigned)(b * heads + hd) * S + (unsigned)qrow) * SP + 4 * h;
@@ -203,6 +223,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
             for (int kt = 0; kt < NB; ++kt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    if (g >= (kt == NB - 1 ? tail_groups<TAIL>() : 4)) continue;
                     const f32x4 k4 = keep4(drop, base + 32 * kt + 8 * g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) p[kt][4 * g + i] *= k4[i];
@@ -215,6 +236,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
         for (int kt = 0; kt < NB; ++kt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                if (s2 >= (kt == NB - 1 ? tail_ksteps<TAIL>() : 2)) continue;   // keys past the sequence carry probability 0
                 const bf16x8 pb = pack8(p[kt], s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_tr(sV, 32 * dt, 32 * kt + 16 * s2, lane), pb, o[dt]);
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
     }
 }
 
-template <int NB, bool DROP, bool DIAG = false>
+template <int NB, bool DROP, bool DIAG = false, int TAIL = 32>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
                                                                    const bf16_t* __restrict__ dctx, int ld_ctx,
                                                                    const float* __restrict__ lse, int S, int heads,
@@ -321,8 +343,14 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                 s = mfma32(frag_rm(sR0, 32 * kt, ks, lane), qf[ks], s);     // S^T[key, q] + bias / scale
                 dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);  // dP^T[key, q]
             }
+            const int ng = kt == NB - 1 ? tail_groups<TAIL>() : 4;   // register groups that can hold a valid key (compile time)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (g >= ng) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[4 * g + i] = 0.f;
+                    continue;
+                }
                 f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
 #pragma unroll
@@ -347,12 +375,19 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             f32x16 dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = mfma32(frag_rm(sR1, 32 * kt, ks, lane), dof[ks], dp);
+            const int ng = kt == NB - 1 ? tail_groups<TAIL>() : 4, ns2 = kt == NB - 1 ? tail_ksteps<TAIL>() : 2;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                if (s2 >= ns2) continue;
                 const u32x4 pu = __builtin_bit_cast(u32x4, p16[kt][s2]);
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
                     const int g = 2 * s2 + g2;
+                    if (g >= ng) {   // keys past the sequence inside a used k-step: dS = 0
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dp[4 * g + i] = 0.f;
+                        continue;
+                    }
                     f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
                     if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
 #pragma unroll
@@ -366,6 +401,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                if (s2 >= ns2) continue;
                 const bf16x8 dsb = pack8(dp, s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
@@ -404,8 +440,10 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             for (int r = 0; r < 16; ++r) bk16[r] = bias_k;
         }
         f32x16 dv[2] = {zero16(), zero16()}, dk[2] = {zero16(), zero16()};
-#pragma unroll 1
-        for (int qt = 0; qt < nqb; ++qt) {
+        // one query tile; TAILED = the last tile of the sequence (rows past S carry probability 0): only its first groups / k-steps
+        auto qtile = [&](int qt, auto tailed) {
+            constexpr bool TAILED = decltype(tailed)::value;
+            constexpr int ng = TAILED ? tail_groups<TAIL>() : 4, ns2 = TAILED ? tail_ksteps<TAIL>() : 2;
             f32x16 s = bk16, dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -414,6 +452,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (g >= ng) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[4 * g + i] = dp[4 * g + i] = 0.f;
+                    continue;
+                }
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * g + 4 * h);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + 32 * qt + 8 * g + 4 * h);
 #pragma unroll
@@ -431,7 +474,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                 }
             }
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
+            for (int s2 = 0; s2 < ns2; ++s2) {
                 const bf16x8 pb = pack8(s, s2), dsb = pack8(dp, s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -439,7 +482,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                     dk[dt] = mfma32(frag_tr(sR0, 32 * dt, 32 * qt + 16 * s2, lane), dsb, dk[dt]);  // Q^T dS
                 }
             }
-        }
+        };
+        const int nfull = (TAIL < 32 && nqb == NB) ? nqb - 1 : nqb;   // wave-uniform
+#pragma unroll 1
+        for (int qt = 0; qt < nfull; ++qt) qtile(qt, std::false_type{});
+        if (nfull < nqb) qtile(nqb - 1, std::true_type{});
         const int key = k0 + (lane & 31);
         if (key < S) {
             store_dt(dk, scale, dqb + (size_t)key * ld_d + HW, lane);
@@ -451,16 +498,14 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
 
 }  // namespace
 
+#define ATTN_FWD_LAUNCH(NBV, DR, TL)                                                                            \
+    hipLaunchKernelGGL((attn_fwd_kernel<NBV, DR, TL>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,             \
+                       static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale, static_cast<bf16_t*>(ctx), ld_ctx, \
+                       lse, drop, nqb)
 #define ATTN_FWD_CASE(NBV)                                                                                      \
     case NBV:                                                                                                   \
-        if (drop.thr16)                                                                                         \
-            hipLaunchKernelGGL((attn_fwd_kernel<NBV, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
-                               static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,              \
-                               static_cast<bf16_t*>(ctx), ld_ctx, lse, drop, nqb);                                   \
-        else                                                                                                    \
-            hipLaunchKernelGGL((attn_fwd_kernel<NBV, false>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,      \
-                               static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale,              \
-                               static_cast<bf16_t*>(ctx), ld_ctx, lse, drop, nqb);                                   \
+        if (drop.thr16) ATTN_FWD_LAUNCH(NBV, true, 32);                                                         \
+        else ATTN_FWD_LAUNCH(NBV, false, 32);                                                                   \
         break;
 
 extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias,
@@ -475,24 +520,31 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
     const int nqb = q_rows > 0 ? (q_rows + 31) / 32 : (S + 31) / 32;
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    switch ((S + 31) / 32) {
-        ATTN_FWD_CASE(1) ATTN_FWD_CASE(2) ATTN_FWD_CASE(3) ATTN_FWD_CASE(4) ATTN_FWD_CASE(5) ATTN_FWD_CASE(6)
-        ATTN_FWD_CASE(7)
+    // the production sequence lengths get the instantiation that knows their last tile holds 5 rows (see tail_groups)
+    if (S == 197) {
+        if (drop.thr16) ATTN_FWD_LAUNCH(7, true, 5);
+        else ATTN_FWD_LAUNCH(7, false, 5);
+    } else if (S == 133) {
+        if (drop.thr16) ATTN_FWD_LAUNCH(5, true, 5);
+        else ATTN_FWD_LAUNCH(5, false, 5);
+    } else {
+        switch ((S + 31) / 32) {
+            ATTN_FWD_CASE(1) ATTN_FWD_CASE(2) ATTN_FWD_CASE(3) ATTN_FWD_CASE(4) ATTN_FWD_CASE(5) ATTN_FWD_CASE(6)
+            ATTN_FWD_CASE(7)
+        }
     }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }
 
+#define ATTN_BWD_LAUNCH(NBV, DR, TL)                                                                             \
+    hipLaunchKernelGGL((attn_bwd_kernel<NBV, DR, false, TL>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
+                       static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, lse, S, heads, \
+                       key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, nqb)
 #define ATTN_BWD_CASE(NBV)                                                                                       \
     case NBV:                                                                                                    \
-        if (drop.thr16)                                                                                          \
-            hipLaunchKernelGGL((attn_bwd_kernel<NBV, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,        \
-                               static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, \
-                               lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, nqb);       \
-        else                                                                                                     \
-            hipLaunchKernelGGL((attn_bwd_kernel<NBV, false>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
-                               static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, \
-                               lse, S, heads, key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, nqb);       \
+        if (drop.thr16) ATTN_BWD_LAUNCH(NBV, true, 32);                                                          \
+        else ATTN_BWD_LAUNCH(NBV, false, 32);                                                                    \
         break;
 
 extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
@@ -508,9 +560,15 @@ extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, in
     const int nqb = q_rows > 0 ? (q_rows + 31) / 32 : (S + 31) / 32;
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    switch ((S + 31) / 32) {
-        ATTN_BWD_CASE(1) ATTN_BWD_CASE(2) ATTN_BWD_CASE(3) ATTN_BWD_CASE(4) ATTN_BWD_CASE(5) ATTN_BWD_CASE(6)
-        ATTN_BWD_CASE(7)
+    // S = 133 gains 5 % from the trimmed last tile; at S = 197 the trimmed instantiation schedules worse (268.6 vs 265.0 us)
+    if (S == 133) {
+        if (drop.thr16) ATTN_BWD_LAUNCH(5, true, 5);
+        else ATTN_BWD_LAUNCH(5, false, 5);
+    } else {
+        switch ((S + 31) / 32) {
+            ATTN_BWD_CASE(1) ATTN_BWD_CASE(2) ATTN_BWD_CASE(3) ATTN_BWD_CASE(4) ATTN_BWD_CASE(5) ATTN_BWD_CASE(6)
+            ATTN_BWD_CASE(7)
+        }
     }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;

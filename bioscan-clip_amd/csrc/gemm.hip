@@ -1102,8 +1102,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 }
 
 #include "gemm_duo.h"
+#include "gemm_pers.h"
 
 int g_tile_override = 0;
+const bool g_pers_off = getenv("BSCLIP_GEMM_PERSISTENT") && atoi(getenv("BSCLIP_GEMM_PERSISTENT")) == 0;   // A/B switch
 [[maybe_unused]] int g_diag_ablate = 0;  // tools/gemm_ablate.py: which parts of the K loop the diagnostic EPI_BF16 build leaves out
 
 template <int BM, int BN, int WM, int WN, int EPI, bool HB>
@@ -1144,11 +1146,24 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
         // (12 K-tiles) and the grid is a few rounds deep: the ViT's N = K = 768 GEMMs (out-projection and its dX: 60 vs 67 us,
         // 76 vs 79 us at M = 50 432; profiles/r03_f_gemm_tiles.log).  BarcodeBERT's M = 34 048 (1.56 rounds) stays on ping-pong.
         if (tile == 4 && N == 768 && K == 768 && t256 >= 500 && EPI != BSCLIP_EPI_GELU_BF16) tile = 5;
+        // the persistent form (gemm_pers.h) hides a tile's 2.5-3 us prologue under the previous tile; it pays where tiles are
+        // short (K <= 832: 12-13 K-tiles) and a workgroup walks several of them; with 36-48 K-tiles its four-round epilogue
+        // costs more than the prologue it saves (profiles/r03_i_gemm_pers.log)
+        if (tile == 4 && pers_supported(EPI) && K <= 1024 && K >= 2 * BK && t256 >= 512 && !g_pers_off) tile = 8;
     }
-    if ((tile == 3 || tile == 4 || tile == 6 || tile == 7) && N % 256 != 0) tile = 2;
+    if ((tile == 3 || tile == 4 || tile == 6 || tile == 7 || tile == 8) && N % 256 != 0) tile = 2;
     switch (tile) {
         case 4: launch_pp<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
         case 5: launch_duo<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;
+        case 8:
+            if constexpr (pers_supported(EPI)) {
+                if (K >= 2 * BK && (size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldb * 2 < (1ull << 32)) {
+                    launch_pers<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s);
+                    break;
+                }
+            }
+            launch_pp<EPI, HB>(A, lda, B, ldb, C, ldc, M, N, K, e, s);
+            break;
 #ifdef BSCLIP_DIAG
         case 6: launch_pp<EPI, HB, 1>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // two-tiles-ahead DMA (comparison)
         case 7: launch_pp<EPI, HB, 2>(A, lda, B, ldb, C, ldc, M, N, K, e, s); break;  // four barriers per K-tile (experimental)
@@ -1281,11 +1296,17 @@ extern "C" int bsclip_init_tables(void* stream) {
 
 extern "C" int bsclip_gemm_set_tile(int tile) {
 #ifdef BSCLIP_DIAG
-    BSCLIP_REQUIRE(tile >= 0 && tile <= 7, "bsclip_gemm_set_tile: tile %d not in 0..7", tile);
+    BSCLIP_REQUIRE(tile >= 0 && tile <= 8, "bsclip_gemm_set_tile: tile %d not in 0..8", tile);
 #else
-    BSCLIP_REQUIRE(tile >= 0 && tile <= 5, "bsclip_gemm_set_tile: tile %d not in 0..5", tile);
+    BSCLIP_REQUIRE((tile >= 0 && tile <= 5) || tile == 8, "bsclip_gemm_set_tile: tile %d not in 0..5, 8", tile);
 #endif
     g_tile_override = tile;
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_gemm_set_persistent_grid(int workgroups) {
+    BSCLIP_REQUIRE(workgroups >= 0 && workgroups <= 4096, "bsclip_gemm_set_persistent_grid: %d not in 0..4096", workgroups);
+    g_pers_grid = workgroups;
     return BSCLIP_OK;
 }
 

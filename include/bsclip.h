@@ -107,10 +107,14 @@ int bsclip_lora_baug_set(void* b_aug, int ld_b, int H, const float* lora_bq, con
  * its own stream; call this once (and synchronise) before launching GEMMs from several streams. */
 int bsclip_init_tables(void* stream);
 /* tile override for benchmarking: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x256 ping-pong,
- * 5 = the 256x128 kernel that runs two workgroups per CU (csrc/gemm_duo.h); the diagnostic
+ * 5 = the 256x128 kernel that runs two workgroups per CU (csrc/gemm_duo.h), 8 = the persistent form of 4 (one workgroup per CU
+ * walks the tiles, the next tile's first K-tile staged under the current one's last; csrc/gemm_pers.h); the diagnostic
  * library (-DBSCLIP_DIAG, `make diag`) adds 6 = ping-pong with the LDS-DMA two K-tiles ahead (slower) and 7 = four instead of
  * eight barriers per K-tile (equal), kept for comparison only */
 int bsclip_gemm_set_tile(int tile);
+/* workgroups of the persistent kernel's launch: 0 = one per CU (the default); a small number makes every workgroup walk many
+ * tiles of a small problem (tests) */
+int bsclip_gemm_set_persistent_grid(int workgroups);
 #ifdef BSCLIP_DIAG
 /* ---- diagnostic builds: only in libbsclip_hip_diag.so (`make -C bioscan-clip_amd/csrc diag`), never in the product library.
  * bsclip_gemm_diag: the 256x256 kernel with per-workgroup phase stamps (start, prologue, K loop, end, epilogue sections) in

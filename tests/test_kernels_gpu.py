@@ -40,7 +40,7 @@ def dgelu(x):
 
 
 # ------------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 8])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 64), (300, 256, 128), (1000, 768, 832), (2500, 512, 576), (197 * 8, 2304, 832),
                                    (5120, 768, 3072)])
 def test_gemm_epilogues(ops, tile, M, N, K):
@@ -92,6 +92,53 @@ def test_gemm_epilogues(ops, tile, M, N, K):
         ops.set_gemm_tile(0)
 
 
+@pytest.mark.parametrize("wgs", [1, 3, 7])
+@pytest.mark.parametrize("M,N,K", [(2500, 512, 576), (1300, 768, 832), (900, 1024, 128), (197 * 8, 2304, 768)])
+def test_gemm_persistent_walks_tiles(ops, wgs, M, N, K):
+    """The persistent kernel (tile 8) with a grid far below the tile count: every workgroup walks several tiles, the next tile's
+    first K-tile staged under the current one's last (odd and even K-tile counts flip the LDS set parity differently).  Same
+    MFMA order and epilogue arithmetic as the ping-pong kernel: bit-identical outputs, rows beyond M untouched."""
+    from bioscanclip.hip.lib import (EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_BF16, EPI_RESID_F32)
+    a = dev(rnd(M, K + 16, seed=1).bfloat16())[:, :K]
+    b = dev(rnd(N, K, seed=2, scale=0.1).bfloat16())
+    bias = dev(rnd(N, seed=3))
+    r = dev(rnd(M, N, seed=4))
+    rb = r.bfloat16()
+    zz = torch.randint(0, 256, (M, N), generator=torch.Generator().manual_seed(5), dtype=torch.uint8).cuda()
+    drop = (0.1, 1234)
+
+    def run():
+        outs = {}
+        for name, epi, dt, kw in (("f32", EPI_F32, torch.float32, dict(bias=bias)), ("bf16", EPI_BF16, torch.bfloat16, dict(bias=bias)),
+                                  ("bf16_nobias", EPI_BF16, torch.bfloat16, {}),
+                                  ("gelu", EPI_GELU_BF16, torch.bfloat16, dict(bias=bias, aux="z")),
+                                  ("resid32", EPI_RESID_F32, torch.float32, dict(bias=bias, resid=r)),
+                                  ("resid16", EPI_RESID_BF16, torch.bfloat16, dict(bias=bias, resid=rb)),
+                                  ("resid16_drop", EPI_RESID_BF16, torch.bfloat16, dict(bias=bias, resid=rb, dropout=drop)),
+                                  ("dgelu", EPI_DGELU_BF16, torch.bfloat16, dict(aux=zz))):
+            out = torch.full((M + 3, N), float("nan"), device="cuda", dtype=dt)
+            if kw.get("aux") == "z":
+                kw = dict(kw, aux=torch.zeros(M, N, device="cuda", dtype=torch.uint8))
+                outs[name + "_aux"] = kw["aux"]
+            ops.gemm(a, b, out, epi, M=M, **kw)
+            outs[name] = out
+        return outs
+
+    try:
+        ops.set_gemm_tile(4)
+        ref = run()
+        ops.set_gemm_tile(8)
+        ops.set_gemm_persistent_grid(wgs)
+        got = run()
+    finally:
+        ops.set_gemm_tile(0)
+        ops.set_gemm_persistent_grid(0)
+    for k in ref:
+        assert torch.equal(ref[k][:M], got[k][:M]), k
+        if ref[k].is_floating_point() and ref[k].shape[0] > M:
+            assert torch.isnan(got[k][M:].float()).all(), f"{k}: rows beyond M were written"
+
+
 def test_gemm_layout_identity(ops):
     """A = I with an asymmetric B catches row/col swaps in the C write (cdna guide 3)."""
     from bioscanclip.hip.lib import EPI_F32
@@ -99,7 +146,7 @@ def test_gemm_layout_identity(ops):
     a = torch.eye(K, device="cuda", dtype=torch.bfloat16)
     b = (torch.arange(N, device="cuda")[:, None] * 2 + torch.arange(K, device="cuda")[None, :] % 7).float()
     b = b.bfloat16()
-    for tile in (1, 2, 3, 4, 5):
+    for tile in (1, 2, 3, 4, 5, 8):
         ops.set_gemm_tile(tile)
         out = torch.empty(K, N, device="cuda")
         ops.gemm(a, b, out, EPI_F32)
