@@ -181,10 +181,34 @@ __device__ __forceinline__ unsigned dg8_pack4(float a, float b, float c, float d
     w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, DG8_SCALE, DG8_OFF * DG8_SCALE), 3, w);
     return w;
 }
+// the same for two pairs, the scaling on the packed-f32 VALU (one v_pk_fma_f32 per pair instead of two v_fma_f32)
+typedef float dg8_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dg8_pack4(dg8_f32x2 ab, dg8_f32x2 cd) {
+    ab = ab * DG8_SCALE + DG8_OFF * DG8_SCALE;
+    cd = cd * DG8_SCALE + DG8_OFF * DG8_SCALE;
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(ab[0], 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(ab[1], 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(cd[0], 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(cd[1], 3, w);
+    return w;
+}
 __device__ __forceinline__ f32x4 dg8_unpack4(unsigned w) {
     return f32x4{fmaf((float)(w & 0xff), DG8_STEP, -DG8_OFF), fmaf((float)((w >> 8) & 0xff), DG8_STEP, -DG8_OFF),
                  fmaf((float)((w >> 16) & 0xff), DG8_STEP, -DG8_OFF), fmaf((float)(w >> 24), DG8_STEP, -DG8_OFF)};
 }
+
+// ---- non-temporal (streaming) global stores for kernel outputs that nothing in the same kernel reads back: the lines do not
+// displace the operand tiles other workgroups are re-reading from L2 (GEMM epilogues: csrc/gemm_pers.h has the measurement) ----
+typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned nt_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store(void* p, uint4 v) {
+    __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, static_cast<nt_u32x4*>(p));
+}
+__device__ __forceinline__ void nt_store(void* p, uint2 v) {
+    __builtin_nontemporal_store(nt_u32x2{v.x, v.y}, static_cast<nt_u32x2*>(p));
+}
+__device__ __forceinline__ void nt_store(void* p, f32x4 v) { __builtin_nontemporal_store(v, static_cast<f32x4*>(p)); }
 
 // ---- async global -> LDS, 16 B per lane (LDS dest = wave-uniform base + lane*16) ---------------------
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

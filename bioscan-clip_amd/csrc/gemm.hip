@@ -47,6 +47,7 @@ struct EpiArgs {
     DropCfg drop;  // RESID only: C = dropout(acc + bias) + resid  (HF BertSelfOutput / BertOutput)
     int n_total;   // logical row width for the dropout element index
     unsigned long long* diag;  // diagnostic build only: per-workgroup phase stamps (100 MHz wall clock)
+    int pers_gw;               // persistent kernel: column tiles per super-column of its tile order (set by launch_pers)
     // fp8 main operands (OP != 0): C = epilogue(alpha[n] * (A8 . B8^T + A_aug . B_aug^T) + bias)
     const float* alpha;                   // [N] dequantisation scale of output column n (activation scale x weight-row scale)
     const bf16_t* a_aug;                  // bf16 [M, 64] K-augmentation block (LoRA t columns), nullable
@@ -73,46 +74,87 @@ constexpr int EPI_LOSS_W = 101;
 // The two-output GELU epilogue (gelu and gelu' of 128 values per lane) computed with exp + rcp was VALU-bound (~24
 // instructions per value, 12 us per tile with no MFMA to hide behind), and a 16-B-per-entry interpolation table was bound by
 // the LDS array instead: 64 lanes gathering random 16-B entries conflict ~3x per 16-lane group (phase stamps: 4.4 us per
-// 64-row slab).  Entries are therefore 8 B -- {Phi(x_i), phi(x_i)} on a 1/64 grid over [-8, 8], nearest grid point, one
-// ds_read_b64 per value -- and the neighbourhood comes from the derivatives, which are free: Phi' = phi, phi' = -x phi, so
-//   Phi(x_i + d) = Phi_i + d phi_i (1 - x_i d / 2) + O(d^3 |phi''| / 6)   <= 2e-8   for |d| <= 1/128,
-//   phi(x_i + d) = phi_i (1 - x_i d)               + O(d^2 |phi''| / 2)   <= 1.3e-5,
-// both far inside the bf16 rounding of the outputs.  Computed once on the device in f64 with erf().
-constexpr int GELU_LUT_N = 1024;                      // intervals
-constexpr int GELU_LUT_BYTES = (GELU_LUT_N + 1) * 8;  // 8200
+// 64-row slab).  Entries are therefore 8 B -- {Phi(x_i), phi(x_i)}, nearest grid point, one ds_read_b64 per value -- and the
+// neighbourhood comes from the derivatives, which are free: Phi' = phi, phi' = -x phi.
+// Round 3: the epilogue is still VALU-bound (8.8 us of a 30-us fc1 tile), so the index arithmetic went on a diet.  256 entries on
+// a 1/16 grid over [-8, 8): the index is ONE v_cvt_pk_u8_f32 (round to nearest even, saturating at 0 / 255) of t = 16 x + 128
+// -- no clamp, no float->int->float round trip beyond v_cvt_f32_ubyte0 -- and saturated inputs are harmless because
+// phi(+-8) ~ 5e-15 multiplies whatever distance they have from the last grid point.  First order in d = x - x_i, |d| <= 1/32:
+//   Phi(x_i + d) = Phi_i + d phi_i          + O(d^2 |x phi| / 2) <= 1.2e-4   (bf16 rounding of the output: 2e-3 half-ulp),
+//   phi(x_i + d) = phi_i (1 - x_i d)        + O(d^2 phi / 2)     <= 2e-4     (8-bit code step of gelu': 4.9e-3).
+// Computed once on the device in f64 with erf().
+constexpr int GELU_LUT_N = 255;                       // last index
+constexpr int GELU_LUT_BYTES = (GELU_LUT_N + 1) * 8;  // 2048
 __device__ float2 g_gelu_lut[GELU_LUT_N + 1];
 
 __global__ void gelu_lut_init_kernel() {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > GELU_LUT_N) return;
-    const double x = -8.0 + i / 64.0;
+    const double x = -8.0 + i / 16.0;
     g_gelu_lut[i] = float2{(float)(0.5 * (1.0 + erf(x * 0.70710678118654752440))),
                            (float)(0.39894228040143267794 * exp(-0.5 * x * x))};
 }
 
-// Two values per call so that the arithmetic runs on the packed-f32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32);
-// the clamp, the float<->int conversions and the table address stay per value.  Phi is taken to first order as well
-// (error d^2 |phi'| / 2 <= 7.4e-6 for |d| <= 1/128).
+// Two values per call so that the arithmetic runs on the packed-f32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32); the
+// index conversions and the table address stay per value.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_lut2(const char* lut, f32x2 x, f32x2& gl, f32x2& dg) {
-    f32x2 xc, fi, Phi, phi;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) xc[k] = __builtin_amdgcn_fmed3f(x[k], -8.0f, 8.0f);
-    const f32x2 t = xc * 64.0f + 512.5f;
+    const f32x2 t = x * 16.0f + 128.0f;
+    f32x2 Phi, phi;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int i = (int)t[k];  // t in [0.5, 1024.5]: truncation = nearest grid point
+        const unsigned i = __builtin_amdgcn_cvt_pk_u8_f32(t[k], 0, 0u);   // nearest grid point (RNE), saturated to [0, 255]
         const float2 e = *reinterpret_cast<const float2*>(lut + i * 8);
-        fi[k] = (float)i;
         Phi[k] = e.x;
         phi[k] = e.y;
     }
-    const f32x2 xi = fi * 0.015625f - 8.0f;
-    const f32x2 d = xc - xi;
-    const f32x2 cdf = d * phi + Phi;
-    const f32x2 pdf = phi - (xi * d) * phi;
+    // the grid point as a float without a per-value conversion: (t + 1.5 * 2^23) - 1.5 * 2^23 = RNE(t) for |t| < 2^22, packed.
+    // A saturated index keeps its small d here and takes its table entry from the end of the grid, where phi ~ 5e-15.
+    f32x2 fi = t + 12582912.0f;
+    asm volatile("" : "+v"(fi));   // keep the two additions apart
+    fi -= 12582912.0f;
+    const f32x2 d16 = t - fi;                       // 16 (x - x_i)
+    const f32x2 e = d16 * phi;
+    const f32x2 cdf = e * 0.0625f + Phi;
+    const f32x2 xi16 = fi * 0.00390625f - 0.5f;     // x_i / 16
+    const f32x2 pdf = phi - xi16 * e;
     gl = x * cdf;
     dg = x * pdf + cdf;
+}
+
+// Sixteen values per call: ALL sixteen table gathers are issued before the first result is used.  Written pair by pair (above)
+// the compiler waits for each pair's two ds_read_b64 before the next pair's go out -- 64 serial LDS round trips per 128 values and
+// lane with two waves per SIMD to hide them: the GELU epilogue was bound by LDS LATENCY (4.8 us per 64-row slab; cutting its VALU
+// count by a fifth changed nothing), not by the VALU or the LDS array.
+__device__ __forceinline__ void gelu_lut16(const char* lut, const f32x4 (&x)[4], f32x4 (&gl)[4], f32x4 (&dg)[4]) {
+    f32x4 t[4], Phi[4], phi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = x[q] * 16.0f + 128.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned i = __builtin_amdgcn_cvt_pk_u8_f32(t[q][c], 0, 0u);   // nearest grid point (RNE), saturated to [0, 255]
+            const float2 e = *reinterpret_cast<const float2*>(lut + i * 8);
+            Phi[q][c] = e.x;
+            phi[q][c] = e.y;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // the grid point as a float without a per-value conversion: (t + 1.5 * 2^23) - 1.5 * 2^23 = RNE(t) for |t| < 2^22, packed.
+        // A saturated index keeps its small d here and takes its table entry from the end of the grid, where phi ~ 5e-15.
+        f32x4 fi = t[q] + 12582912.0f;
+        asm volatile("" : "+v"(fi));   // keep the two additions apart
+        fi -= 12582912.0f;
+        const f32x4 d16 = t[q] - fi;                       // 16 (x - x_i)
+        const f32x4 e = d16 * phi[q];
+        const f32x4 cdf = e * 0.0625f + Phi[q];
+        const f32x4 xi16 = fi * 0.00390625f - 0.5f;        // x_i / 16
+        const f32x4 pdf = phi[q] - xi16 * e;
+        gl[q] = x[q] * cdf;
+        dg[q] = x[q] * pdf + cdf;
+    }
 }
 
 __device__ __forceinline__ f32x4 bf4_to_f32(uint2 u) {
@@ -964,7 +1006,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                         gelu_lut2(lut, f32x2{v[0], v[1]}, gl0, dg0);
                         gelu_lut2(lut, f32x2{v[2], v[3]}, gl1, dg1);
                         *reinterpret_cast<unsigned*>(slab2 + (16 * i + fr) * S8 + (64 * wc + 32 * ni + 16 * j + 4 * fq)) =
-                            dg8_pack4(dg0[0], dg0[1], dg1[0], dg1[1]);
+                            dg8_pack4(dg0, dg1);
                         if constexpr (EPI == BSCLIP_EPI_GELU_FP8) {  // the next GEMM's fp8 operand: e4m3, scale 1, saturated
                             *reinterpret_cast<unsigned*>((g ? smem + 64 * SB : smem) + (16 * i + fr) * S8 +
                                                          (64 * wc + 32 * ni + 16 * j + 4 * fq)) =
@@ -986,7 +1028,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             const int r = it * 8 + wq * 2 + (lane >> 5);
             const int m = m0 + 128 * g + 64 * mi + r;
             const uint4 v = *reinterpret_cast<const uint4*>(src + r * SB + (lane & 31) * 16);
-            if (m < M) *reinterpret_cast<uint4*>(dst + (size_t)m * ld + n0 + (lane & 31) * 8) = v;
+            if (m < M) nt_store(dst + (size_t)m * ld + n0 + (lane & 31) * 8, v);
         }
     };
     // 64 x 256 B slab of 8-bit codes: 16 lanes x 16 B per row, 16 rows per pass of the group's 256 threads
@@ -997,7 +1039,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
             const int r = it * 16 + (t >> 4);
             const int m = m0 + 128 * g + 64 * mi + r;
             const uint4 v = *reinterpret_cast<const uint4*>(src + r * S8 + (t & 15) * 16);
-            if (m < M) *reinterpret_cast<uint4*>(dst + (size_t)m * ld + n0 + (t & 15) * 16) = v;
+            if (m < M) nt_store(dst + (size_t)m * ld + n0 + (t & 15) * 16, v);
         }
     };
     auto stage_f32 = [&](int mi) {
@@ -1057,29 +1099,29 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
                 f32x4 v = *reinterpret_cast<const f32x4*>(slab + r * SF + lane * 16);
                 if (m < M) {
                     if constexpr (EPI == BSCLIP_EPI_F32) {
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
+                        nt_store(static_cast<float*>(C) + (size_t)m * ldc + n, v);
                     } else if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
                         if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
                         v += R[it];
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
+                        nt_store(static_cast<float*>(C) + (size_t)m * ldc + n, v);
                     } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
                         v *= R[it];
                         uint2 o;
                         o.x = pack_bf2(v[0], v[1]);
                         o.y = pack_bf2(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = o;
+                        nt_store(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, o);
                     } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
                         const int b = m / 196, p = m - b * 196;
                         v += R[it];
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = v;
+                        nt_store(static_cast<float*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n, v);
                     } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
                         if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
                         v += R[it];
-                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = f32_to_bf4(v);
+                        nt_store(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, f32_to_bf4(v));
                     } else if constexpr (EPI == BSCLIP_EPI_PATCH_BF16) {
                         const int b = m / 196, p = m - b * 196;
                         v += R[it];
-                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = f32_to_bf4(v);
+                        nt_store(static_cast<bf16_t*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n, f32_to_bf4(v));
                     }
                 }
             }
@@ -1279,6 +1321,44 @@ extern "C" int bsclip_gemm_duo_diag(const void* A, int lda, const void* B, int l
             break;
         default: BSCLIP_REQUIRE(false, "bsclip_gemm_duo_diag: epilogue %d has no diagnostic build", epilogue);
     }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+// The persistent kernel with per-workgroup stamps, diag[grid * 16] (layout: gemm_pers.h); tools/gemm_pers_phases.py.
+extern "C" int bsclip_gemm_pers_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                     int epilogue, const bsclip_epi_args* args, unsigned long long* diag, int workgroups,
+                                     void* stream) {
+    BSCLIP_REQUIRE(A && B && C && diag && args, "bsclip_gemm_pers_diag: null pointer");
+    BSCLIP_REQUIRE(K % 64 == 0 && K >= 128 && N % 256 == 0 && workgroups > 0, "bsclip_gemm_pers_diag: K %% 64, K >= 128, N %% 256");
+    EpiArgs e{};
+    e.bias = args->bias;
+    e.resid = static_cast<const float*>(args->resid);
+    e.ld_resid = args->ld_resid;
+    e.aux = static_cast<unsigned char*>(args->aux);
+    e.ld_aux = args->ld_aux;
+    e.drop = make_drop(0.f, 0);
+    e.n_total = N;
+    e.diag = diag;
+    const int tiles_m = ceil_div(M, 256), tiles_n = N / 256, nt = tiles_m * tiles_n;
+    e.pers_gw = tiles_n;
+    const dim3 grid(nt < workgroups ? nt : workgroups), block(512);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16_t* a = static_cast<const bf16_t*>(A);
+    const bf16_t* b = static_cast<const bf16_t*>(B);
+#define PERS_DIAG(EPI, HB)                                                                                                  \
+    case EPI:                                                                                                               \
+        hipLaunchKernelGGL((gemm_nt_pers_kernel<EPI, HB, true>), grid, block, 0, s, a, lda, b, ldb, C, ldc, M, N, K, tiles_n, nt, e); \
+        break;
+    switch (epilogue) {
+        PERS_DIAG(BSCLIP_EPI_BF16, false)
+        PERS_DIAG(BSCLIP_EPI_GELU_BF16, true)
+        PERS_DIAG(BSCLIP_EPI_RESID_F32, true)
+        PERS_DIAG(BSCLIP_EPI_RESID_BF16, true)
+        PERS_DIAG(BSCLIP_EPI_DGELU_BF16, false)
+        default: BSCLIP_REQUIRE(false, "bsclip_gemm_pers_diag: epilogue %d has no diagnostic build", epilogue);
+    }
+#undef PERS_DIAG
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

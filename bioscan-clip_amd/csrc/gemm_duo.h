@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __res
                         f32x2 gl0, dg0, gl1, dg1;
                         gelu_lut2(lut, f32x2{v[0], v[1]}, gl0, dg0);
                         gelu_lut2(lut, f32x2{v[2], v[3]}, gl1, dg1);
-                        *reinterpret_cast<unsigned*>(slab2 + r * S8 + cn) = dg8_pack4(dg0[0], dg0[1], dg1[0], dg1[1]);
+                        *reinterpret_cast<unsigned*>(slab2 + r * S8 + cn) = dg8_pack4(dg0, dg1);
                         o.x = pack_bf2(gl0[0], gl0[1]);
                         o.y = pack_bf2(gl1[0], gl1[1]);
                     } else {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __res
                 const int r = it * 16 + (tid >> 4);
                 const int m = m0 + 128 * (r >> 6) + 64 * mi + (r & 63);
                 const uint4 v = *reinterpret_cast<const uint4*>(slab + r * SB + (tid & 15) * 16);
-                if (m < M) *reinterpret_cast<uint4*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n0 + (tid & 15) * 8) = v;
+                if (m < M) nt_store(static_cast<bf16_t*>(C) + (size_t)m * ldc + n0 + (tid & 15) * 8, v);
             }
             if constexpr (GELU) {
                 if (e.aux) {  // 8-bit rows: 128 B = 8 lanes x 16 B, 32 rows per pass
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __res
                         const int r = it * 32 + (tid >> 3);
                         const int m = m0 + 128 * (r >> 6) + 64 * mi + (r & 63);
                         const uint4 v = *reinterpret_cast<const uint4*>(slab2 + r * S8 + (tid & 7) * 16);
-                        if (m < M) *reinterpret_cast<uint4*>(e.aux + (size_t)m * e.ld_aux + n0 + (tid & 7) * 16) = v;
+                        if (m < M) nt_store(e.aux + (size_t)m * e.ld_aux + n0 + (tid & 7) * 16, v);
                     }
                 }
             }
@@ -276,29 +276,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __res
                 f32x4 v = *reinterpret_cast<const f32x4*>(slab + r * SF + (tid & 31) * 16);
                 if (m < M) {
                     if constexpr (EPI == BSCLIP_EPI_F32) {
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
+                        nt_store(static_cast<float*>(C) + (size_t)m * ldc + n, v);
                     } else if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
                         if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
                         v += pre[mi][it];
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
+                        nt_store(static_cast<float*>(C) + (size_t)m * ldc + n, v);
                     } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
                         v *= pre[mi][it];
                         uint2 o;
                         o.x = pack_bf2(v[0], v[1]);
                         o.y = pack_bf2(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = o;
+                        nt_store(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, o);
                     } else if constexpr (EPI == BSCLIP_EPI_PATCH_F32) {
                         const int b = m / 196, p = m - b * 196;
                         v += pre[mi][it];
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = v;
+                        nt_store(static_cast<float*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n, v);
                     } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
                         if (e.drop.thr16) v = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, v);
                         v += pre[mi][it];
-                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = f32_to_bf4(v);
+                        nt_store(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, f32_to_bf4(v));
                     } else if constexpr (EPI == BSCLIP_EPI_PATCH_BF16) {
                         const int b = m / 196, p = m - b * 196;
                         v += pre[mi][it];
-                        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n) = f32_to_bf4(v);
+                        nt_store(static_cast<bf16_t*>(C) + (size_t)(b * 197 + 1 + p) * ldc + n, f32_to_bf4(v));
                     }
                 }
             }

@@ -27,11 +27,21 @@ constexpr bool pers_supported(int epi) {
            epi == BSCLIP_EPI_DGELU_BF16 || epi == BSCLIP_EPI_RESID_BF16;
 }
 
-template <int EPI, bool HAS_BIAS, bool DIAG = false>
+typedef unsigned pers_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned pers_u32x2 __attribute__((ext_vector_type(2)));
+template <bool NT, class T>
+__device__ __forceinline__ void pers_store(void* p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, static_cast<T*>(p));
+    else *static_cast<T*>(p) = v;
+}
+
+template <int EPI, bool HAS_BIAS, bool DIAG = false, bool NT = false>
 __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restrict__ A, int lda,
                                                             const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                             int ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e) {
     static_assert(pers_supported(EPI), "persistent kernel: epilogue not instantiated");
+    const int gw = e.pers_gw;                    // column tiles per super-column, divides tiles_n
+    const int tiles_m = ntiles / tiles_n;
     if constexpr (epi_is_resid(EPI)) BSCLIP_DROP_RESOLVE(e.drop);
     constexpr int SET1 = 98304, SPARE = 65536, HALF = 16384, B_OFF = 32768;
     constexpr bool GELU = EPI == BSCLIP_EPI_GELU_BF16;
@@ -49,9 +59,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
     unsigned offA[2][2], offB[2][2];
     int dm0 = 0, dn0 = 0;
     auto aim = [&](int v) {
+        // logical order: "super-columns" of gw column tiles, all row panels of one before the next -- an XCD's 32 concurrent tiles
+        // then share gw column tiles of B (which stays in its 4-MiB L2: fc1's B is 4.7 MB, 12 column tiles) instead of all of them
         const int wgid = xcd_remap(v, ntiles);
-        dn0 = (wgid % tiles_n) * 256;
-        dm0 = (wgid / tiles_n) * 256;
+        const int per_sc = tiles_m * gw;
+        const int sc = wgid / per_sc, rem = wgid - sc * per_sc;
+        dn0 = (sc * gw + rem % gw) * 256;
+        dm0 = (rem / gw) * 256;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -124,7 +138,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
         __builtin_amdgcn_s_barrier();          \
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
-    // diagnostic build: per workgroup {start, end, tiles done, -} then per tile (first 7) {K loop start, K loop end} (100 MHz)
+    // diagnostic build, per workgroup (100 MHz ticks): {start, end, tiles done, -, tile 1: K loop start, K loop end, then after each
+    // of the 8 epilogue barriers (stage q / store q, q = 0..3), tile 0: K loop start, K loop end}
     auto stamp = [&](int i) {
         if constexpr (DIAG) {
             if (tid == 0 && i < 16) e.diag[(size_t)blockIdx.x * 16 + i] = wall_clock64();
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
         const int vn = v + (int)gridDim.x;
         const bool hasN = vn < ntiles;   // wave-uniform
         if (g == 1) PERS_BARRIER();      // group 1 runs one barrier behind group 0 through the K loop
-        stamp(4 + 2 * done);
+        stamp(done == 0 ? 14 : done == 1 ? 4 : 99);
         for (int t = 0; t < nk; ++t) {
             const int set = (p + t) & 1;
             const char* base = smem + set * SET1;
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
             PERS_BARRIER();
         }
         if (g == 0) PERS_BARRIER();  // balance group 1's extra barrier
-        stamp(5 + 2 * done);
+        stamp(done == 0 ? 15 : done == 1 ? 5 : 99);
 
         // ---- epilogue of tile (m0, n0); staging in set E and the spare only ----
         const int E = (p + nk - 1) & 1;
@@ -239,35 +254,43 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
             for (int q = 0; q < 4; ++q) {
                 const int mi = q >> 1, ih = q & 1;
 #pragma unroll
-                for (int i2 = 0; i2 < 2; ++i2)
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    f32x4 x[4], gl[4], dg[4];   // [2 ni + j]
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const f32x4 x = acc[mi][ni][2 * ih + i2][j];
+                            x[2 * ni + j] = acc[mi][ni][2 * ih + i2][j];
                             acc[mi][ni][2 * ih + i2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    if constexpr (GELU) gelu_lut16(lut, x, gl, dg);
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
                             const int col = 64 * wc + 32 * ni + 16 * j + 4 * fqe;
+                            const int k = 2 * ni + j;
                             uint2 o;
                             if constexpr (GELU) {
-                                f32x2 gl0, dg0, gl1, dg1;
-                                gelu_lut2(lut, f32x2{x[0], x[1]}, gl0, dg0);
-                                gelu_lut2(lut, f32x2{x[2], x[3]}, gl1, dg1);
-                                *reinterpret_cast<unsigned*>(slab2 + (16 * i2 + fre) * S8 + col) = dg8_pack4(dg0[0], dg0[1], dg1[0], dg1[1]);
-                                o.x = pack_bf2(gl0[0], gl0[1]);
-                                o.y = pack_bf2(gl1[0], gl1[1]);
+                                *reinterpret_cast<unsigned*>(slab2 + (16 * i2 + fre) * S8 + col) =
+                                    dg8_pack4(dg8_f32x2{dg[k][0], dg[k][1]}, dg8_f32x2{dg[k][2], dg[k][3]});
+                                o.x = pack_bf2(gl[k][0], gl[k][1]);
+                                o.y = pack_bf2(gl[k][2], gl[k][3]);
                             } else {
-                                o.x = pack_bf2(x[0], x[1]);
-                                o.y = pack_bf2(x[2], x[3]);
+                                o.x = pack_bf2(x[k][0], x[k][1]);
+                                o.y = pack_bf2(x[k][2], x[k][3]);
                             }
                             *reinterpret_cast<uint2*>(slab + (16 * i2 + fre) * SB + col * 2) = o;
                         }
+                }
                 __syncthreads();
+                stamp(done == 1 ? 6 + 2 * q : 99);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {   // 32 rows x 512 B: 32 lanes per row, 8 rows per pass of the group's 256 threads
                     const int r = it * 8 + wq * 2 + (le >> 5);
                     const int m = m0 + 128 * g + 32 * q + r;
-                    const uint4 w = *reinterpret_cast<const uint4*>(slab + r * SB + (le & 31) * 16);
-                    if (m < M) *reinterpret_cast<uint4*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n0 + (le & 31) * 8) = w;
+                    const pers_u32x4 w = *reinterpret_cast<const pers_u32x4*>(slab + r * SB + (le & 31) * 16);
+                    if (m < M) pers_store<NT>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n0 + (le & 31) * 8, w);
                 }
                 if constexpr (GELU) {
                     if (e.aux) {
@@ -276,12 +299,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                         for (int it = 0; it < 2; ++it) {   // 32 rows x 256 B: 16 lanes per row
                             const int r = it * 16 + (t8 >> 4);
                             const int m = m0 + 128 * g + 32 * q + r;
-                            const uint4 w = *reinterpret_cast<const uint4*>(slab2 + r * S8 + (t8 & 15) * 16);
-                            if (m < M) *reinterpret_cast<uint4*>(e.aux + (size_t)m * e.ld_aux + n0 + (t8 & 15) * 16) = w;
+                            const pers_u32x4 w = *reinterpret_cast<const pers_u32x4*>(slab2 + r * S8 + (t8 & 15) * 16);
+                            if (m < M) pers_store<NT>(e.aux + (size_t)m * e.ld_aux + n0 + (t8 & 15) * 16, w);
                         }
                     }
                 }
                 if (q < 3 || hasN) __syncthreads();
+                stamp(done == 1 ? 7 + 2 * q : 99);
             }
         } else {
             // f32-staged epilogues read a second operand (residual stream / saved gelu') row-wise: issued one slab ahead
@@ -325,18 +349,24 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                     f32x4 x = *reinterpret_cast<const f32x4*>(slab + r * SF + le * 16);
                     if (m < M) {
                         if constexpr (EPI == BSCLIP_EPI_F32) {
-                            *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = x;
+                            pers_store<NT>(static_cast<float*>(C) + (size_t)m * ldc + n, x);
                         } else if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
                             if (e.drop.thr16) x = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, x);
                             x += R[it];
-                            *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = x;
+                            pers_store<NT>(static_cast<float*>(C) + (size_t)m * ldc + n, x);
                         } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
                             x *= R[it];
-                            *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = f32_to_bf4(x);
+                            {
+                                const uint2 o = f32_to_bf4(x);
+                                pers_store<NT>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, pers_u32x2{o.x, o.y});
+                            }
                         } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
                             if (e.drop.thr16) x = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, x);
                             x += R[it];
-                            *reinterpret_cast<uint2*>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n) = f32_to_bf4(x);
+                            {
+                                const uint2 o = f32_to_bf4(x);
+                                pers_store<NT>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, pers_u32x2{o.x, o.y});
+                            }
                         }
                     }
                 }
@@ -344,14 +374,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
             prefetch(0, pre[0]);
             stage(0);
             __syncthreads();
+            stamp(done == 1 ? 6 : 99);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q < 3) prefetch(q + 1, pre[(q + 1) & 1]);
                 consume(q, pre[q & 1]);
                 if (q < 3 || hasN) __syncthreads();
+                stamp(done == 1 ? 7 + 2 * q : 99);
                 if (q < 3) {
                     stage(q + 1);
                     __syncthreads();
+                    stamp(done == 1 ? 8 + 2 * q : 99);
                 }
             }
         }
@@ -371,10 +404,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
     }
 }
 
+// non-temporal output stores (default): a tile's 128-192 KB of output no longer displaces operand lines in L2 -- dfc2 269 -> 238 us,
+// fc1 ~ -3 %, the step 40.0 -> 39.4 ms (profiles/r03_i_gemm_pers.log); BSCLIP_GEMM_NT=0 is the A/B switch
+const bool g_pers_nt = !(getenv("BSCLIP_GEMM_NT") && atoi(getenv("BSCLIP_GEMM_NT")) == 0);
+const int g_pers_gw = getenv("BSCLIP_GEMM_GW") ? atoi(getenv("BSCLIP_GEMM_GW")) : 0;   // experiment: super-column width
 int g_pers_grid = 0;   // bsclip_gemm_set_persistent_grid: workgroups of the persistent launch, 0 = one per CU
 
 template <int EPI, bool HB>
-void launch_pers(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
+void launch_pers(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K, const EpiArgs& e_in,
                  hipStream_t s) {
     static int cus = 0;
     if (cus == 0) {
@@ -385,6 +422,21 @@ void launch_pers(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, in
     }
     const int tiles_m = ceil_div(M, 256), tiles_n = N / 256, nt = tiles_m * tiles_n;
     const int wgs = g_pers_grid > 0 ? g_pers_grid : cus;
-    hipLaunchKernelGGL((gemm_nt_pers_kernel<EPI, HB>), dim3(nt < wgs ? nt : wgs), dim3(512), 0, s, A, lda, B, ldb, C, ldc, M, N,
-                       K, tiles_n, nt, e);
+    EpiArgs e = e_in;
+    e.pers_gw = tiles_n;
+    {
+        const int want = g_pers_gw > 0 ? g_pers_gw : 6;
+        if (tiles_n > want)
+            for (int d = want; d >= 2; --d)
+                if (tiles_n % d == 0) {
+                    e.pers_gw = d;
+                    break;
+                }
+    }
+    if (g_pers_nt)
+        hipLaunchKernelGGL((gemm_nt_pers_kernel<EPI, HB, false, true>), dim3(nt < wgs ? nt : wgs), dim3(512), 0, s, A, lda, B, ldb, C,
+                           ldc, M, N, K, tiles_n, nt, e);
+    else
+        hipLaunchKernelGGL((gemm_nt_pers_kernel<EPI, HB>), dim3(nt < wgs ? nt : wgs), dim3(512), 0, s, A, lda, B, ldb, C, ldc, M, N,
+                           K, tiles_n, nt, e);
 }
