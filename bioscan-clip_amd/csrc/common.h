@@ -198,6 +198,19 @@ __device__ __forceinline__ f32x4 dg8_unpack4(unsigned w) {
                  fmaf((float)((w >> 16) & 0xff), DG8_STEP, -DG8_OFF), fmaf((float)(w >> 24), DG8_STEP, -DG8_OFF)};
 }
 
+// ---- workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release/acquire fence: the compiler
+// puts s_waitcnt vmcnt(0) in front of the s_barrier, i.e. every global load issued "ahead" is waited for at the next barrier and
+// every global store has to be acknowledged before the workgroup moves on.  An epilogue that stages through LDS only needs its
+// ds_writes / ds_reads ordered; global loads are waited for where their values are used, stores drain on their own. ----
+// (Fences scoped to the "local" address space keep the compiler's own counter bookkeeping intact; an inline-asm
+// "s_waitcnt lgkmcnt(0); s_barrier" makes it fall back to vmcnt(0) before every later global access.)
+#define BSCLIP_LDS_BARRIER()                                               \
+    do {                                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");    \
+        __builtin_amdgcn_s_barrier();                                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");    \
+    } while (0)
+
 // ---- non-temporal (streaming) global stores for kernel outputs that nothing in the same kernel reads back: the lines do not
 // displace the operand tiles other workgroups are re-reading from L2 (GEMM epilogues: csrc/gemm_pers.h has the measurement) ----
 typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));

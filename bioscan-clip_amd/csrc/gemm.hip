@@ -79,9 +79,10 @@ constexpr int EPI_LOSS_W = 101;
 // Round 3: the epilogue is still VALU-bound (8.8 us of a 30-us fc1 tile), so the index arithmetic went on a diet.  256 entries on
 // a 1/16 grid over [-8, 8): the index is ONE v_cvt_pk_u8_f32 (round to nearest even, saturating at 0 / 255) of t = 16 x + 128
 // -- no clamp, no float->int->float round trip beyond v_cvt_f32_ubyte0 -- and saturated inputs are harmless because
-// phi(+-8) ~ 5e-15 multiplies whatever distance they have from the last grid point.  First order in d = x - x_i, |d| <= 1/32:
-//   Phi(x_i + d) = Phi_i + d phi_i          + O(d^2 |x phi| / 2) <= 1.2e-4   (bf16 rounding of the output: 2e-3 half-ulp),
-//   phi(x_i + d) = phi_i (1 - x_i d)        + O(d^2 phi / 2)     <= 2e-4     (8-bit code step of gelu': 4.9e-3).
+// phi(+-8) ~ 5e-15 multiplies whatever distance they have from the last grid point.  With d = x - x_i, |d| <= 1/32:
+//   Phi(x_i + d) = Phi_i + d phi_i (1 - x_i d / 2) + O(d^3 |phi''| / 6) <= 2e-6   (first order alone leaves 1.2e-4: a third of
+//                                                                       the e4m3 / a tenth of the bf16 rounding of the output),
+//   phi(x_i + d) = phi_i (1 - x_i d)               + O(d^2 phi / 2)     <= 2e-4   (8-bit code step of gelu': 4.9e-3).
 // Computed once on the device in f64 with erf().
 constexpr int GELU_LUT_N = 255;                       // last index
 constexpr int GELU_LUT_BYTES = (GELU_LUT_N + 1) * 8;  // 2048
@@ -114,24 +115,25 @@ __device__ __forceinline__ void gelu_lut2(const char* lut, f32x2 x, f32x2& gl, f
     asm volatile("" : "+v"(fi));   // keep the two additions apart
     fi -= 12582912.0f;
     const f32x2 d16 = t - fi;                       // 16 (x - x_i)
-    const f32x2 e = d16 * phi;
-    const f32x2 cdf = e * 0.0625f + Phi;
-    const f32x2 xi16 = fi * 0.00390625f - 0.5f;     // x_i / 16
-    const f32x2 pdf = phi - xi16 * e;
+    const f32x2 e = d16 * phi;                      // 16 d phi_i
+    const f32x2 xd = (fi * 0.00390625f - 0.5f) * d16;   // x_i d  (x_i / 16 = i / 256 - 1 / 2)
+    const f32x2 cdf = e * (0.0625f - xd * 0.03125f) + Phi;   // Phi_i + d phi_i (1 - x_i d / 2)
+    const f32x2 pdf = phi - xd * phi;                        // phi_i (1 - x_i d)
     gl = x * cdf;
     dg = x * pdf + cdf;
 }
 
-// Sixteen values per call: ALL sixteen table gathers are issued before the first result is used.  Written pair by pair (above)
+// 4 NV values per call: ALL the table gathers are issued before the first result is used.  Written pair by pair (above)
 // the compiler waits for each pair's two ds_read_b64 before the next pair's go out -- 64 serial LDS round trips per 128 values and
 // lane with two waves per SIMD to hide them: the GELU epilogue was bound by LDS LATENCY (4.8 us per 64-row slab; cutting its VALU
 // count by a fifth changed nothing), not by the VALU or the LDS array.
-__device__ __forceinline__ void gelu_lut16(const char* lut, const f32x4 (&x)[4], f32x4 (&gl)[4], f32x4 (&dg)[4]) {
-    f32x4 t[4], Phi[4], phi[4];
+template <int NV>   // NV vectors of four values
+__device__ __forceinline__ void gelu_lut_batch(const char* lut, const f32x4 (&x)[NV], f32x4 (&gl)[NV], f32x4 (&dg)[NV]) {
+    f32x4 t[NV], Phi[NV], phi[NV];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = x[q] * 16.0f + 128.0f;
+    for (int q = 0; q < NV; ++q) t[q] = x[q] * 16.0f + 128.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NV; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned i = __builtin_amdgcn_cvt_pk_u8_f32(t[q][c], 0, 0u);   // nearest grid point (RNE), saturated to [0, 255]
@@ -141,17 +143,17 @@ __device__ __forceinline__ void gelu_lut16(const char* lut, const f32x4 (&x)[4],
         }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NV; ++q) {
         // the grid point as a float without a per-value conversion: (t + 1.5 * 2^23) - 1.5 * 2^23 = RNE(t) for |t| < 2^22, packed.
         // A saturated index keeps its small d here and takes its table entry from the end of the grid, where phi ~ 5e-15.
         f32x4 fi = t[q] + 12582912.0f;
         asm volatile("" : "+v"(fi));   // keep the two additions apart
         fi -= 12582912.0f;
         const f32x4 d16 = t[q] - fi;                       // 16 (x - x_i)
-        const f32x4 e = d16 * phi[q];
-        const f32x4 cdf = e * 0.0625f + Phi[q];
-        const f32x4 xi16 = fi * 0.00390625f - 0.5f;        // x_i / 16
-        const f32x4 pdf = phi[q] - xi16 * e;
+        const f32x4 e = d16 * phi[q];                      // 16 d phi_i
+        const f32x4 xd = (fi * 0.00390625f - 0.5f) * d16;  // x_i d  (x_i / 16 = i / 256 - 1 / 2)
+        const f32x4 cdf = e * (0.0625f - xd * 0.03125f) + Phi[q];   // Phi_i + d phi_i (1 - x_i d / 2)
+        const f32x4 pdf = phi[q] - xd * phi[q];                     // phi_i (1 - x_i d)
         gl[q] = x[q] * cdf;
         dg[q] = x[q] * pdf + cdf;
     }
@@ -987,7 +989,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     if constexpr (GELU) {  // 16 KiB table, L2-resident, behind the slabs
         for (int i = tid; i <= GELU_LUT_N; i += 512)
             *reinterpret_cast<float2*>(smem + 4 * 64 * SB + i * 8) = g_gelu_lut[i];
-        __syncthreads();
+        BSCLIP_LDS_BARRIER();
     }
     constexpr int S8 = 272;   // 8-bit slab row stride (256 + 16)
     char* slab2 = smem + 2 * 64 * SB + g * (64 * S8);  // second slab (GELU: gelu' side band, 8-bit codes)
@@ -1056,14 +1058,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
     for (int mi = 0; mi < 2; ++mi) {
         if constexpr (EPI == BSCLIP_EPI_BF16 || GELU) {
             stage_bf16(mi);
-            __syncthreads();
+            BSCLIP_LDS_BARRIER();
             stamp(4 + 2 * mi);
             if constexpr (EPI == BSCLIP_EPI_GELU_FP8) rows_u8(mi, smem + g * (64 * SB), static_cast<unsigned char*>(C), ldc);
             else rows_bf16(mi, smem + g * (64 * SB), static_cast<bf16_t*>(C), ldc);
             if constexpr (GELU) {
                 if (e.aux) rows_u8(mi, slab2, e.aux, e.ld_aux);  // gelu'(pre-activation) for the backward pass
             }
-            __syncthreads();
+            BSCLIP_LDS_BARRIER();
             stamp(5 + 2 * mi);
         }
     }
@@ -1128,14 +1130,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
         };
         prefetch(0, pre[0]);
         stage_f32(0);
-        __syncthreads();
+        BSCLIP_LDS_BARRIER();
         stamp(4);
         prefetch(1, pre[1]);
         consume(0, pre[0]);
-        __syncthreads();
+        BSCLIP_LDS_BARRIER();
         stamp(5);
         stage_f32(1);
-        __syncthreads();
+        BSCLIP_LDS_BARRIER();
         stamp(6);
         consume(1, pre[1]);
         stamp(7);
@@ -1325,7 +1327,7 @@ extern "C" int bsclip_gemm_duo_diag(const void* A, int lda, const void* B, int l
     return BSCLIP_OK;
 }
 
-// The persistent kernel with per-workgroup stamps, diag[grid * 16] (layout: gemm_pers.h); tools/gemm_pers_phases.py.
+// The persistent kernel with per-workgroup stamps, diag[grid * 32] (layout: gemm_pers.h); tools/gemm_pers_phases.py.
 extern "C" int bsclip_gemm_pers_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                      int epilogue, const bsclip_epi_args* args, unsigned long long* diag, int workgroups,
                                      void* stream) {
@@ -1341,7 +1343,7 @@ extern "C" int bsclip_gemm_pers_diag(const void* A, int lda, const void* B, int 
     e.n_total = N;
     e.diag = diag;
     const int tiles_m = ceil_div(M, 256), tiles_n = N / 256, nt = tiles_m * tiles_n;
-    e.pers_gw = tiles_n;
+    e.pers_gw = tiles_n | (getenv("BSCLIP_PERS_ABL") && atoi(getenv("BSCLIP_PERS_ABL")) == 1 ? 0x100 : 0);
     const dim3 grid(nt < workgroups ? nt : workgroups), block(512);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t* a = static_cast<const bf16_t*>(A);

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __res
         }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            if (mi == 1 || GELU) __syncthreads();  // slab free again (mi = 1) / table visible (mi = 0)
+            if (mi == 1 || GELU) BSCLIP_LDS_BARRIER();  // slab free again (mi = 1) / table visible (mi = 0)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __res
                     }
                     *reinterpret_cast<uint2*>(slab + r * SB + cn * 2) = o;
                 }
-            __syncthreads();
+            BSCLIP_LDS_BARRIER();
             // bf16 rows: 256 B = 16 lanes x 16 B, 16 rows per pass of the 256 threads
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -260,13 +260,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(const bf16_t* __res
         prefetch(0, pre[0]);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            if (mi == 1) __syncthreads();
+            if (mi == 1) BSCLIP_LDS_BARRIER();
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     *reinterpret_cast<f32x4*>(slab + (64 * wm + 16 * i + fr) * SF + (64 * wn + 16 * j + 4 * fq) * 4) = acc[mi][i][j];
-            __syncthreads();
+            BSCLIP_LDS_BARRIER();
             if (mi == 0) prefetch(1, pre[1]);  // the second half's rows fly while the first half is stored
 #pragma unroll
             for (int it = 0; it < 16; ++it) {

@@ -30,7 +30,8 @@ constexpr bool pers_supported(int epi) {
 typedef unsigned pers_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned pers_u32x2 __attribute__((ext_vector_type(2)));
 template <bool NT, class T>
-__device__ __forceinline__ void pers_store(void* p, T v) {
+__device__ __forceinline__ void pers_store(void* p, T v, bool skip = false) {
+    if (skip) return;   // diagnostic build only (tools/gemm_pers_phases.py ABL=1): is the slow start of a tile's K loop the stores?
     if constexpr (NT) __builtin_nontemporal_store(v, static_cast<T*>(p));
     else *static_cast<T*>(p) = v;
 }
@@ -40,7 +41,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                                                             const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                             int ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e) {
     static_assert(pers_supported(EPI), "persistent kernel: epilogue not instantiated");
-    const int gw = e.pers_gw;                    // column tiles per super-column, divides tiles_n
+    const int gw = e.pers_gw & 0xff;             // column tiles per super-column, divides tiles_n
+    const bool abl_st = DIAG && (e.pers_gw & 0x100);   // diagnostic build: leave the output stores out
     const int tiles_m = ntiles / tiles_n;
     if constexpr (epi_is_resid(EPI)) BSCLIP_DROP_RESOLVE(e.drop);
     constexpr int SET1 = 98304, SPARE = 65536, HALF = 16384, B_OFF = 32768;
@@ -58,23 +60,46 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
     // ---- LDS-DMA sources of the tile the DMA stream is aimed at: half h, chunk (wave) and (wave + 8) ----
     unsigned offA[2][2], offB[2][2];
     int dm0 = 0, dn0 = 0;
-    auto aim = [&](int v) {
+    // The offsets of the NEXT tile are formed in three pieces (tile coordinates, A rows, B rows) so that each fits the "load" half
+    // of a phase -- the time the other wave group spends in its MFMAs; formed in one go in phase 3 of K-tile nk - 2 they stretched
+    // that K-tile from 1.48 to 1.84 us (tools/gemm_pers_phases.py, KTILES=1).
+    unsigned nxtA[2][2], nxtB[2][2];
+    int nm0 = 0, nn0 = 0;
+    auto plan_tile = [&](int v) {
         // logical order: "super-columns" of gw column tiles, all row panels of one before the next -- an XCD's 32 concurrent tiles
         // then share gw column tiles of B (which stays in its 4-MiB L2: fc1's B is 4.7 MB, 12 column tiles) instead of all of them
         const int wgid = xcd_remap(v, ntiles);
         const int per_sc = tiles_m * gw;
         const int sc = wgid / per_sc, rem = wgid - sc * per_sc;
-        dn0 = (sc * gw + rem % gw) * 256;
-        dm0 = (rem / gw) * 256;
+        nn0 = (sc * gw + rem % gw) * 256;
+        nm0 = (rem / gw) * 256;
+    };
+    auto plan_rows = [&](unsigned (&o)[2][2], int r0, int rmax, int ld) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 128 * h + 8 * (wave + 8 * i) + (lane >> 3);
                 const int c = (lane & 7) ^ ((row >> 1) & 7);
-                offA[h][i] = (unsigned)min(dm0 + row, M - 1) * (unsigned)(lda * 2) + c * 16;
-                offB[h][i] = (unsigned)min(dn0 + row, N - 1) * (unsigned)(ldb * 2) + c * 16;
+                o[h][i] = (unsigned)min(r0 + row, rmax) * (unsigned)(ld * 2) + c * 16;
             }
+    };
+    auto take_plan = [&]() {
+        dm0 = nm0;
+        dn0 = nn0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                offA[h][i] = nxtA[h][i];
+                offB[h][i] = nxtB[h][i];
+            }
+    };
+    auto aim = [&](int v) {
+        plan_tile(v);
+        plan_rows(nxtA, nm0, M - 1, lda);
+        plan_rows(nxtB, nn0, N - 1, ldb);
+        take_plan();
     };
     const int dma_off = wave * 1024;
     auto dmaA = [&](int set, int h, int k0) {   // k0 = byte offset of the K-tile in the row
@@ -139,10 +164,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
     // diagnostic build, per workgroup (100 MHz ticks): {start, end, tiles done, -, tile 1: K loop start, K loop end, then after each
-    // of the 8 epilogue barriers (stage q / store q, q = 0..3), tile 0: K loop start, K loop end}
+    // of the 8 epilogue barriers (stage q / store q, q = 0..3), tile 0: K loop start, K loop end, tile 1: end of K-tile 0..15};
+    // 32 slots per workgroup
     auto stamp = [&](int i) {
         if constexpr (DIAG) {
-            if (tid == 0 && i < 16) e.diag[(size_t)blockIdx.x * 16 + i] = wall_clock64();
+            if (tid == 0 && i < 32) e.diag[(size_t)blockIdx.x * 32 + i] = wall_clock64();
         }
     };
     stamp(0);
@@ -178,22 +204,30 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
             const bool in1 = t + 1 < nk, in2 = t + 2 < nk;
             const bool do1 = in1 || hasN;
             const int k1 = in1 ? (t + 1) * 2 * BK : 0;   // past the tile's end: K-tile 0 of the next tile (offsets re-aimed)
+            const bool plan = in1 && !in2 && hasN;       // K-tile nk - 2: plan the next tile's offsets, a piece per phase
             // ---- phase 0 ----
             if (do1) dmaA(set ^ 1, 1, k1);
             readA(base, 0);
             readB(base, 0);
+            if (plan) {
+                int vv = vn;   // the opaque copy keeps this arithmetic HERE (hoisted to the top of the tile it lives through the K loop)
+                asm volatile("" : "+s"(vv));
+                plan_tile(vv);
+            }
             PERS_BARRIER();
             mma(0, 0);
             PERS_BARRIER();
             // ---- phase 1 ----
             if (do1) dmaB(set ^ 1, 0, k1);
             readA(base, 1);
+            if (plan) plan_rows(nxtA, nm0, M - 1, lda);
             PERS_BARRIER();
             mma(1, 0);
             PERS_BARRIER();
             // ---- phase 2 ----
             if (do1) dmaB(set ^ 1, 1, k1);
             readB(base, 1);
+            if (plan) plan_rows(nxtB, nn0, N - 1, ldb);
             PERS_BARRIER();
             mma(1, 1);
             PERS_BARRIER();
@@ -201,12 +235,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
             if (in2) {
                 dmaA(set, 0, (t + 2) * 2 * BK);
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // K-tile t+1 has landed; A-half0 of t+2 may fly
-            } else if (in1 && hasN) {
-                // every piece of this tile has been issued: the DMA stream moves on to the next tile.  (The opaque copy keeps the
-                // offset arithmetic HERE: hoisted to the top of the tile it is carried through the K loop as 64-bit pointers.)
-                int vv = vn;
-                asm volatile("" : "+s"(vv));
-                aim(vv);
+            } else if (plan) {
+                take_plan();   // every piece of this tile has been issued: the DMA stream moves on to the next tile
                 dmaA(set, 0, 0);
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             } else {
@@ -215,6 +245,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
             PERS_BARRIER();
             mma(0, 1);
             PERS_BARRIER();
+            stamp(done == 1 ? 16 + t : 99);   // diagnostic build: end of K-tile t of the second tile
         }
         if (g == 0) PERS_BARRIER();  // balance group 1's extra barrier
         stamp(done == 0 ? 15 : done == 1 ? 5 : 99);
@@ -263,7 +294,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                             x[2 * ni + j] = acc[mi][ni][2 * ih + i2][j];
                             acc[mi][ni][2 * ih + i2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
-                    if constexpr (GELU) gelu_lut16(lut, x, gl, dg);
+                    if constexpr (GELU) {   // two batches of eight values: sixteen at once spill (2 VGPRs, reloaded behind a vmcnt(0))
+                        f32x4 (&x2)[2][2] = reinterpret_cast<f32x4 (&)[2][2]>(x);
+                        f32x4 (&gl2)[2][2] = reinterpret_cast<f32x4 (&)[2][2]>(gl);
+                        f32x4 (&dg2)[2][2] = reinterpret_cast<f32x4 (&)[2][2]>(dg);
+                        gelu_lut_batch<2>(lut, x2[0], gl2[0], dg2[0]);
+                        gelu_lut_batch<2>(lut, x2[1], gl2[1], dg2[1]);
+                    }
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -283,14 +320,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                             *reinterpret_cast<uint2*>(slab + (16 * i2 + fre) * SB + col * 2) = o;
                         }
                 }
-                __syncthreads();
+                BSCLIP_LDS_BARRIER();
                 stamp(done == 1 ? 6 + 2 * q : 99);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {   // 32 rows x 512 B: 32 lanes per row, 8 rows per pass of the group's 256 threads
                     const int r = it * 8 + wq * 2 + (le >> 5);
                     const int m = m0 + 128 * g + 32 * q + r;
                     const pers_u32x4 w = *reinterpret_cast<const pers_u32x4*>(slab + r * SB + (le & 31) * 16);
-                    if (m < M) pers_store<NT>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n0 + (le & 31) * 8, w);
+                    if (m < M) pers_store<NT>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n0 + (le & 31) * 8, w, abl_st);
                 }
                 if constexpr (GELU) {
                     if (e.aux) {
@@ -300,32 +337,41 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                             const int r = it * 16 + (t8 >> 4);
                             const int m = m0 + 128 * g + 32 * q + r;
                             const pers_u32x4 w = *reinterpret_cast<const pers_u32x4*>(slab2 + r * S8 + (t8 & 15) * 16);
-                            if (m < M) pers_store<NT>(e.aux + (size_t)m * e.ld_aux + n0 + (t8 & 15) * 16, w);
+                            if (m < M) pers_store<NT>(e.aux + (size_t)m * e.ld_aux + n0 + (t8 & 15) * 16, w, abl_st);
                         }
                     }
                 }
-                if (q < 3 || hasN) __syncthreads();
+                if (q < 3 || hasN) BSCLIP_LDS_BARRIER();
                 stamp(done == 1 ? 7 + 2 * q : 99);
             }
         } else {
             // f32-staged epilogues read a second operand (residual stream / saved gelu') row-wise: issued one slab ahead
             char* slab = smem + (E ? SPARE : 0) + g * (32 * SF);
-            f32x4 pre[2][8];
-            auto prefetch = [&](int q, f32x4 (&R)[8]) {
+            // Raw (unconverted) words, so that nothing waits for a load where it is issued.  bf16 residual rows (2 VGPRs per piece)
+            // and 8-bit gelu' codes (1 VGPR) are fetched for ALL FOUR slabs of the tile up front -- the fragment registers are dead
+            // here -- so only the first slab's consume can see HBM latency; f32 residual rows (4 VGPRs) stay one slab ahead.
+            constexpr bool RAW2 = EPI == BSCLIP_EPI_RESID_BF16, RAW1 = EPI == BSCLIP_EPI_DGELU_BF16;
+            constexpr int DEPTH = (RAW2 || RAW1) ? 4 : 2;
+            using raw_t = std::conditional_t<RAW2, uint2, std::conditional_t<RAW1, unsigned, f32x4>>;
+            raw_t pre[DEPTH][8];
+            auto prefetch = [&](int q, raw_t (&R)[8]) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int m = min(m0 + 128 * g + 32 * q + it * 4 + wq, M - 1);
                     const int n = n0 + le * 4;
                     if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
                         R[it] = *reinterpret_cast<const f32x4*>(e.resid + (size_t)m * e.ld_resid + n);
-                    } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
-                        R[it] = bf4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(e.resid) + (size_t)m * e.ld_resid + n));
-                    } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
-                        R[it] = dg8_unpack4(*reinterpret_cast<const unsigned*>(e.aux + (size_t)m * e.ld_aux + n));
-                    } else {
-                        R[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    } else if constexpr (RAW2) {
+                        R[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(e.resid) + (size_t)m * e.ld_resid + n);
+                    } else if constexpr (RAW1) {
+                        R[it] = *reinterpret_cast<const unsigned*>(e.aux + (size_t)m * e.ld_aux + n);
                     }
                 }
+            };
+            auto cooked = [&](const raw_t& r) -> f32x4 {
+                if constexpr (RAW2) return bf4_to_f32(r);
+                else if constexpr (RAW1) return dg8_unpack4(r);
+                else return r;
             };
             auto stage = [&](int q) {
                 const int mi = q >> 1, ih = q & 1;
@@ -340,7 +386,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                             acc[mi][ni][2 * ih + i2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
             };
-            auto consume = [&](int q, const f32x4 (&R)[8]) {
+            auto consume = [&](int q, const raw_t (&R)[8]) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int r = it * 4 + wq;  // one 1-KiB row per wave instruction
@@ -349,41 +395,46 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                     f32x4 x = *reinterpret_cast<const f32x4*>(slab + r * SF + le * 16);
                     if (m < M) {
                         if constexpr (EPI == BSCLIP_EPI_F32) {
-                            pers_store<NT>(static_cast<float*>(C) + (size_t)m * ldc + n, x);
+                            pers_store<NT>(static_cast<float*>(C) + (size_t)m * ldc + n, x, abl_st);
                         } else if constexpr (EPI == BSCLIP_EPI_RESID_F32) {
                             if (e.drop.thr16) x = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, x);
-                            x += R[it];
-                            pers_store<NT>(static_cast<float*>(C) + (size_t)m * ldc + n, x);
+                            x += cooked(R[it]);
+                            pers_store<NT>(static_cast<float*>(C) + (size_t)m * ldc + n, x, abl_st);
                         } else if constexpr (EPI == BSCLIP_EPI_DGELU_BF16) {
-                            x *= R[it];
+                            x *= cooked(R[it]);
                             {
                                 const uint2 o = f32_to_bf4(x);
-                                pers_store<NT>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, pers_u32x2{o.x, o.y});
+                                pers_store<NT>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, pers_u32x2{o.x, o.y}, abl_st);
                             }
                         } else if constexpr (EPI == BSCLIP_EPI_RESID_BF16) {
                             if (e.drop.thr16) x = drop4(e.drop, (unsigned)m * (unsigned)e.n_total + (unsigned)n, x);
-                            x += R[it];
+                            x += cooked(R[it]);
                             {
                                 const uint2 o = f32_to_bf4(x);
-                                pers_store<NT>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, pers_u32x2{o.x, o.y});
+                                pers_store<NT>(static_cast<bf16_t*>(C) + (size_t)m * ldc + n, pers_u32x2{o.x, o.y}, abl_st);
                             }
                         }
                     }
                 }
             };
-            prefetch(0, pre[0]);
+            if constexpr (EPI != BSCLIP_EPI_F32) {
+#pragma unroll
+                for (int q = 0; q < DEPTH - 1; ++q) prefetch(q, pre[q]);
+            }
             stage(0);
-            __syncthreads();
+            BSCLIP_LDS_BARRIER();
             stamp(done == 1 ? 6 : 99);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (q < 3) prefetch(q + 1, pre[(q + 1) & 1]);
-                consume(q, pre[q & 1]);
-                if (q < 3 || hasN) __syncthreads();
+                if constexpr (EPI != BSCLIP_EPI_F32) {
+                    if (q + DEPTH - 1 < 4) prefetch(q + DEPTH - 1, pre[(q + DEPTH - 1) % DEPTH]);
+                }
+                consume(q, pre[q % DEPTH]);
+                if (q < 3 || hasN) BSCLIP_LDS_BARRIER();
                 stamp(done == 1 ? 7 + 2 * q : 99);
                 if (q < 3) {
                     stage(q + 1);
-                    __syncthreads();
+                    BSCLIP_LDS_BARRIER();
                     stamp(done == 1 ? 8 + 2 * q : 99);
                 }
             }
@@ -400,7 +451,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
 #undef PERS_BARRIER
     stamp(1);
     if constexpr (DIAG) {
-        if (tid == 0) e.diag[(size_t)blockIdx.x * 16 + 2] = done;
+        if (tid == 0) e.diag[(size_t)blockIdx.x * 32 + 2] = done;
     }
 }
 

@@ -128,9 +128,9 @@ int bsclip_gemm_diag(const void* A, int lda, const void* B, int ldb, void* C, in
  * landed, K loop done, end, HW_ID, XCC_ID, -, -}: section times and co-residency; tools/gemm_duo_phases.py */
 int bsclip_gemm_duo_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                          int epilogue, const bsclip_epi_args* args, unsigned long long* diag, void* stream);
-/* the persistent 256x256 kernel (bsclip_gemm_set_tile(8)) on `workgroups` workgroups with per-workgroup stamps, diag[grid * 16] =
+/* the persistent 256x256 kernel (bsclip_gemm_set_tile(8)) on `workgroups` workgroups with per-workgroup stamps, diag[grid * 32] =
  * {start, end, tiles done, -, second tile: K loop start, K loop end, after each of the 8 epilogue barriers, first tile: K loop
- * start, K loop end}; tools/gemm_pers_phases.py */
+ * start, K loop end, second tile: end of K-tile 0..15}; tools/gemm_pers_phases.py */
 int bsclip_gemm_pers_diag(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                           int epilogue, const bsclip_epi_args* args, unsigned long long* diag, int workgroups, void* stream);
 /* the attention backward kernel (S = 197 or 133, no mask, no dropout) with per-wave section stamps in 100 MHz ticks,

@@ -161,7 +161,10 @@ def _build_clip(with_text, seed):
 
 # trajectory tolerances (2x measured, gpurun_out/parity.jsonl): first-step embeddings / gradient fingerprints vs the
 # reference's, loss per step (relative), trainable parameters after the last step
-TRAJ_TOL = {False: dict(emb=1.4e-2, grad=0.12, loss=3.3e-2, params=6e-2), True: dict(emb=2e-2, grad=0.15, loss=5e-2, params=0.1)}
+# loss: the golden loss falls 50x over the run and every step amplifies the difference of the step before (measured per step,
+# two equally exact GELU tables: 0.0005 ... 0.013 in profiles/r03_h_parity.jsonl, 0.0009 ... 0.034 after round 3's table change),
+# so the late steps bound the tolerance, not the arithmetic of one step
+TRAJ_TOL = {False: dict(emb=1.4e-2, grad=0.12, loss=6e-2, params=6e-2), True: dict(emb=2e-2, grad=0.15, loss=6e-2, params=0.1)}
 
 
 @pytest.mark.parametrize("with_text", [False, True])

@@ -70,7 +70,7 @@ def test_gemm_fp8_matches_dequantised_matmul(ops, form, M, N, K, aug):
     assert (got != exp).float().mean().item() < 2e-3
     x = ref.double()
     dg = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
-    assert ((z.float() * (1.26 / 255) - 0.13) - dg.float()).abs().max().item() < 0.5 * 1.26 / 255 + 3e-4
+    assert ((z.float() * (1.26 / 255) - 0.13) - dg.float()).abs().max().item() < 0.5 * 1.26 / 255 + 6e-4
 
 
 def test_gemm_fp8_forms_agree_and_integer_exact(ops):

@@ -64,8 +64,8 @@ def test_gemm_epilogues(ops, tile, M, N, K):
         z = torch.empty(M, N, device="cuda", dtype=torch.uint8)
         ops.gemm(a, b, out16, EPI_GELU_BF16, bias=bias, aux=z)
         dg = z.float() * (1.26 / 255) - 0.13                     # side band = gelu'(pre-activation), 8-bit codes
-        # half a code step + the table's first-order error (1/16 grid: Phi 1.2e-4, |x| phi 2e-4 |x|, csrc/gemm.hip)
-        assert (dg - dgelu(ref)).abs().max().item() < 0.5 * 1.26 / 255 + 8e-4
+        # half a code step + the table's error in phi (1/16 grid, first order: 2e-4 |x|, csrc/gemm.hip)
+        assert (dg - dgelu(ref)).abs().max().item() < 0.5 * 1.26 / 255 + 6e-4
         assert rel_err(dg, dgelu(ref)) < TOL_BF16
         assert rel_err(out16.float(), gelu(ref)) < TOL_BF16
         # residual

@@ -22,13 +22,13 @@ for name, N, K, epi in (("qkv", 2304, 832, EPI_BF16), ("fc1", 3072, 768, EPI_GEL
         z = torch.randint(0, 256, (M, N), device="cuda", dtype=torch.uint8); keep.append(z); args.aux = z.data_ptr(); args.ld_aux = N
     nt = ((M + 255) // 256) * (N // 256)
     grid = min(nt, WGS)
-    diag = torch.zeros(grid * 16, dtype=torch.int64, device="cuda")
+    diag = torch.zeros(grid * 32, dtype=torch.int64, device="cuda")
     for _ in range(3):
         rc = h.bsclip_gemm_pers_diag(a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, epi, ctypes.byref(args),
                                      diag.data_ptr(), WGS, None)
         assert rc == 0, L.last_error()
     torch.cuda.synchronize()
-    raw = diag.cpu().reshape(grid, 16)
+    raw = diag.cpu().reshape(grid, 32)
     d = raw.double() / 100.0  # us
     two = raw[:, 2] >= 2
     total = d[:, 1].max() - d[:, 0].min()
@@ -43,6 +43,11 @@ for name, N, K, epi in (("qkv", 2304, 832, EPI_BF16), ("fc1", 3072, 768, EPI_GEL
         secs = [med(t[:, 6 + i] - t[:, 5 + i]) for i in range(8)]
         line += (f" | tile 0 epilogue {gap:5.2f} | tile 1: K-loop {k1:6.2f} ({k1 / nk:5.2f}/K-tile) epilogue {sum(secs):5.2f} = "
                  + " ".join(f"{x:4.2f}" for x in secs) + "  (stage q | store q, q = 0..3)")
+    if two.any() and os.environ.get("KTILES"):
+        t = d[two]
+        n = min(nk, 16)
+        ends = [t[:, 4]] + [t[:, 16 + i] for i in range(n)]
+        line += " | tile 1 K-tiles: " + " ".join(f"{med(ends[i + 1] - ends[i]):4.2f}" for i in range(n))
     per_wg = d[:, 1] - d[:, 0]
     line += f" | WG lifetime median {med(per_wg):6.1f} max {float(per_wg.max()):6.1f}"
     print(line, flush=True)
