@@ -35,11 +35,11 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md chip t
 GFLOP_PER_PAIR_ID = 118.3   # fwd 58.8 + LoRA-regime bwd
 GFLOP_PER_TRIPLE_IDT = 119.3
 # HBM-side bytes per launch of the dominant kernel: NOT measured by this run (PMC passes need rocprofv3 around the process).
-# Offline figure: (11 x 959.6 + 12 x 639.6 + 154.4) / 24 MB from the per-shape FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE
-# passes of profiles/r03_b_fc1_pmc.txt (tools/scripts/r03_pmc.sh; the kernel's loop and stores are unchanged since
-# profiles/r02_c_fc1_pmc.txt, which gave the same numbers).
-FC1_TRAFFIC_BYTES_B256 = 766.1e6
-FC1_TRAFFIC_SOURCE = "offline rocprofv3 --pmc passes (profiles/r03_b_fc1_pmc.txt, tools/scripts/r03_pmc.sh), not collected by this run"
+# Offline figure: (11 x 798.6 + 12 x 542.6 + 150.2) / 24 MB from the per-shape FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE
+# passes of profiles/r03_j_fc1_pmc.txt (tools/scripts/r03_pmc2.sh), taken after the persistent rewrite of the kernel
+# (766.1 MB before it: profiles/r03_b_fc1_pmc.txt).
+FC1_TRAFFIC_BYTES_B256 = 643.6e6
+FC1_TRAFFIC_SOURCE = "offline rocprofv3 --pmc passes (profiles/r03_j_fc1_pmc.txt, tools/scripts/r03_pmc2.sh), not collected by this run"
 METRIC = "paired samples/sec/node (I+D+T, global batch) + step MFMA-roofline % at 1/2/4/8 GPU"   # BASELINE.json:metric, verbatim
 
 
@@ -95,8 +95,9 @@ VIT_LAST_BLOCK_SKIPPED_GFLOP = (2 * 196 * 768 * (768 + 2 * 3072) * 2 + 4 * 196 *
 
 
 def time_dominant_gemm(B, device, reps=4):
-    """The kernel with the largest share of the step: gemm_nt_pp_kernel<EPI_GELU_BF16, bias> (fc1 + bias + exact GELU,
-    writes gelu(z) and gelu'(z)).  One step launches it 24 times: 11x ViT fc1 [B*197, 3072, 768] (the 12th ViT block's MLP
+    """The kernel with the largest share of the step: the fc1 + bias + exact GELU GEMM (writes gelu(z) and gelu'(z)) --
+    gemm_nt_pers_kernel<EPI_GELU_BF16, bias> (csrc/gemm_pers.h) for the two [M, 3072, 768] shapes, gemm_nt_pp_kernel<...> for the
+    768 x 768 transform.  One step launches it 24 times: 11x ViT fc1 [B*197, 3072, 768] (the 12th ViT block's MLP
     runs on the B token-0 rows only and goes to the small-grid kernel), 12x BarcodeBERT fc1 [B*133, 3072, 768] and once for
     cls.predictions.transform [B*133, 768, 768].  The same mix is timed here with HIP
     events on the launch stream, so the average duration is directly comparable with the kernel's row in the
@@ -129,12 +130,13 @@ def time_dominant_gemm(B, device, reps=4):
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             # bytes per launch at the L2's memory side, FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, averaged over the
-            # same launch mix; collected offline with rocprofv3 --pmc (profiles/r02_c_fc1_pmc.txt), valid for B=256
+            # same launch mix; collected offline with rocprofv3 --pmc (profiles/r03_j_fc1_pmc.txt), valid for B=256
             "traffic": FC1_TRAFFIC_BYTES_B256 if B == 256 else None,
             "traffic_note": FC1_TRAFFIC_SOURCE + "; algorithmic bytes per launch: "
                             "%.1f MB (A + W bf16, gelu bf16, gelu' 8-bit)" % (sum(((M * K + N * K) * 2.0 + 3.0 * M * N) * c for M, N, K, c in shapes)
                                                                              / launches / 1e6),
-            "kernel": "gemm_nt_pp_kernel<2 = EPI_GELU_BF16, true> (fc1 + bias + GELU; 24 launches per step)",
+            "kernel": "gemm_nt_pers_kernel<2 = EPI_GELU_BF16, true, false, true> (fc1 + bias + GELU, 23 launches per step) + "
+                      "gemm_nt_pp_kernel<2, true> (the 768x768 transform, 1 launch)",
             "launch_mix_MNK_count": [list(x) for x in shapes],
             "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "avg_launch_ms": round(mean_ms, 4)}
 
