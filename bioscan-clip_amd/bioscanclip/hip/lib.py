@@ -99,6 +99,7 @@ SIGNATURES = {
     "bsclip_adamw_step_dev": (I, [P, P, P, P, L, P, F, F, F, F, F, P]),
     "bsclip_set_dropout_step": (I, [P]),
     "bsclip_counter_add": (I, [P, U, P]),
+    "bsclip_clock_probe": (I, [P, P]),
 }
 
 # only in libbsclip_hip_diag.so (`make -C bioscan-clip_amd/csrc diag`, -DBSCLIP_DIAG); used by tools/, never by the product

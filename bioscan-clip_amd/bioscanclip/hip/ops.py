@@ -509,6 +509,25 @@ def counter_add(counter, inc=1):
     check(_l.load().bsclip_counter_add(_p(counter), int(inc) & 0xFFFFFFFF, _stream()))
 
 
+def clock_probe(out32):
+    """out32: zeroed int64 [32] on the GPU <- per XCD {shader-clock counter, 100 MHz real-time counter} when the current stream
+    gets here (include/bsclip.h)."""
+    _req(out32.is_cuda and out32.dtype == torch.int64 and out32.numel() >= 32 and out32.is_contiguous(), "clock_probe: int64 [32] on the GPU")
+    check(_l.load().bsclip_clock_probe(_p(out32), _stream()))
+
+
+def engine_clock_ghz(probe0, probe1):
+    """Median over the XCDs of the shader clock between two clock_probe() samples, in GHz (None if no XCD gives a sane reading)."""
+    a, b = probe0.cpu().view(16, 2), probe1.cpu().view(16, 2)
+    ghz = []
+    for x in range(16):
+        dc, dt = int(b[x, 0] - a[x, 0]), int(b[x, 1] - a[x, 1])
+        if a[x, 1] and b[x, 1] and dt > 0 and 0.5 < dc / (dt * 10.0) < 3.0:
+            ghz.append(dc / (dt * 10.0))
+    ghz.sort()
+    return ghz[len(ghz) // 2] if ghz else None
+
+
 def kmer_tokenize(blob, offsets, B, max_len, k, ids):
     _req(blob.dtype == torch.uint8 and blob.is_cuda and blob.is_contiguous(), "kmer_tokenize: uint8 GPU byte buffer")
     _req(offsets.dtype == torch.int64 and offsets.is_cuda and offsets.numel() == B + 1, "kmer_tokenize: offsets int64 [B+1]")

@@ -14,7 +14,7 @@ void bsclip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bsclip_last_error(void) { return g_err; }
-extern "C" int bsclip_abi_version(void) { return 5; }  // 5: adamw_step_dev step word is uint32 (device-advanced), dropout step passes through the mixer; 4: layernorm_bwd in_dropout, fp8 / pipeline / comm / full-FT entry points, 8-bit gelu side band
+extern "C" int bsclip_abi_version(void) { return 6; }  // 6: persistent GEMM (set_tile 8, set_persistent_grid), bsclip_clock_probe; 5: adamw_step_dev step word is uint32 (device-advanced), dropout step passes through the mixer; 4: layernorm_bwd in_dropout, fp8 / pipeline / comm / full-FT entry points, 8-bit gelu side band
 
 // ---- dropout step word ------------------------------------------------------------------------------------------
 static thread_local const unsigned* g_drop_step = nullptr;
@@ -28,6 +28,25 @@ extern "C" int bsclip_set_dropout_step(const uint32_t* step_dev) {
 namespace {
 __global__ void counter_add_kernel(unsigned* p, unsigned inc) { *p += inc; }
 }  // namespace
+
+namespace {
+// per XCD x: out[2x] = shader-clock counter (s_memtime), out[2x + 1] = 100 MHz real-time counter (s_memrealtime), sampled when the
+// stream reaches this node.  The shader-clock counter is per XCD, so every XCD records its own pair (64 one-wave workgroups cover the
+// eight XCDs; workgroups of one XCD write near-identical values).
+__global__ void clock_probe_kernel(unsigned long long* out) {
+    if (threadIdx.x != 0) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF;   // HW_REG_XCC_ID
+    out[2 * xcc] = __builtin_readcyclecounter();
+    out[2 * xcc + 1] = wall_clock64();
+}
+}  // namespace
+
+extern "C" int bsclip_clock_probe(unsigned long long* out32_dev, void* stream) {
+    BSCLIP_REQUIRE(out32_dev, "bsclip_clock_probe: null pointer");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(64), dim3(64), 0, static_cast<hipStream_t>(stream), out32_dev);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
 
 extern "C" int bsclip_counter_add(uint32_t* counter_dev, uint32_t inc, void* stream) {
     BSCLIP_REQUIRE(counter_dev, "bsclip_counter_add: null pointer");

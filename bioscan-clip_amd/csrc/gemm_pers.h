@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
         __builtin_amdgcn_s_barrier();          \
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
-    // diagnostic build, per workgroup (100 MHz ticks): {start, end, tiles done, -, tile 1: K loop start, K loop end, then after each
+    // diagnostic build, per workgroup (100 MHz ticks): {start, end, tiles done, s_memtime cycles start -> end, tile 1: K loop start, K loop end, then after each
     // of the 8 epilogue barriers (stage q / store q, q = 0..3), tile 0: K loop start, K loop end, tile 1: end of K-tile 0..15};
     // 32 slots per workgroup
     auto stamp = [&](int i) {
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
         }
     };
     stamp(0);
+    [[maybe_unused]] const unsigned long long cyc0 = DIAG ? __builtin_readcyclecounter() : 0ull;
 
     int v = blockIdx.x;
     aim(v);
@@ -294,7 +295,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                             x[2 * ni + j] = acc[mi][ni][2 * ih + i2][j];
                             acc[mi][ni][2 * ih + i2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
-                    if constexpr (GELU) {   // two batches of eight values: sixteen at once spill (2 VGPRs, reloaded behind a vmcnt(0))
+                    // two batches of eight values: sixteen at once spill (2 VGPRs, reloaded behind a vmcnt(0)).  Tried: the gathers of
+                    // batch b + 1 issued before the arithmetic of batch b (software pipeline over the slab's four batches) -- stage
+                    // time unchanged (2.1 us per slab): at the measured 2.0 GHz the slab's ~3 000 VALU cycles per SIMD are 1.5 us of it
+                    if constexpr (GELU) {
                         f32x4 (&x2)[2][2] = reinterpret_cast<f32x4 (&)[2][2]>(x);
                         f32x4 (&gl2)[2][2] = reinterpret_cast<f32x4 (&)[2][2]>(gl);
                         f32x4 (&dg2)[2][2] = reinterpret_cast<f32x4 (&)[2][2]>(dg);
@@ -451,7 +455,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
 #undef PERS_BARRIER
     stamp(1);
     if constexpr (DIAG) {
-        if (tid == 0) e.diag[(size_t)blockIdx.x * 32 + 2] = done;
+        if (tid == 0) {
+            e.diag[(size_t)blockIdx.x * 32 + 2] = done;
+            e.diag[(size_t)blockIdx.x * 32 + 3] = __builtin_readcyclecounter() - cyc0;   // shader-clock cycles of this workgroup's life
+        }
     }
 }
 

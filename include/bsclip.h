@@ -31,6 +31,12 @@ extern "C" {
 const char* bsclip_last_error(void);
 int bsclip_abi_version(void);
 
+/* Clock counters sampled when `stream` reaches this node: for XCD x (HW_REG_XCC_ID, 0..15) out32[2x] = its shader-clock counter
+ * (s_memtime), out32[2x + 1] = the 100 MHz real-time counter (s_memrealtime); entries of absent XCDs stay untouched (zero them
+ * first).  Two probes around a region give the clock the chip actually ran at in it, per XCD: delta(s_memtime) /
+ * delta(s_memrealtime) x 100 MHz.  bench.py reports the median, because the dense-MFMA peak a roofline is priced against
+ * assumes the 2.4 GHz peak engine clock. */
+int bsclip_clock_probe(unsigned long long* out32_dev, void* stream);
 /* Dropout step word (hipGraph support).  Kernel arguments are frozen when a launch is captured into a graph, so a seed passed
  * by value would repeat its mask on every replay.  After bsclip_set_dropout_step(ptr) every dropout-carrying launch made BY
  * THE CALLING THREAD adds (*ptr * 0x9E3779B9) to its seed when the kernel runs (NULL: seeds are used as passed).  The word

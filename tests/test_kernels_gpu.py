@@ -647,3 +647,26 @@ def test_gather_cast_rows(ops):
     dst = torch.empty(3 * 196, 768, device="cuda", dtype=torch.bfloat16)
     ops.gather_cast_rows(src, 3 * 196, 197, 196, 1, dst)
     assert torch.equal(dst, src.view(3, 197, 768)[:, 1:].reshape(-1, 768).bfloat16())
+
+
+def test_clock_probe_reads_a_plausible_engine_clock(ops):
+    """bsclip_clock_probe: per-XCD shader-clock and 100 MHz counters; two probes around some work give a clock between the
+    idle and the peak engine clock, and the real-time delta matches the host's clock."""
+    import time
+    p0, p1 = torch.zeros(32, dtype=torch.int64, device="cuda"), torch.zeros(32, dtype=torch.int64, device="cuda")
+    a = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    ops.clock_probe(p0)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        a = a @ a * 1e-3
+    ops.clock_probe(p1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ghz = ops.engine_clock_ghz(p0, p1)
+    assert ghz is not None and 0.5 < ghz < 3.0, ghz
+    q0, q1 = p0.cpu().view(16, 2), p1.cpu().view(16, 2)
+    seen = [x for x in range(16) if q0[x, 1] and q1[x, 1]]
+    assert len(seen) >= 1
+    ticks = max(int(q1[x, 1] - q0[x, 1]) for x in seen)          # 100 MHz
+    assert 0.5 * dt < ticks / 1e8 < 1.5 * dt + 1e-3, (ticks, dt)

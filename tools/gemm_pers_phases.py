@@ -48,6 +48,8 @@ for name, N, K, epi in (("qkv", 2304, 832, EPI_BF16), ("fc1", 3072, 768, EPI_GEL
         n = min(nk, 16)
         ends = [t[:, 4]] + [t[:, 16 + i] for i in range(n)]
         line += " | tile 1 K-tiles: " + " ".join(f"{med(ends[i + 1] - ends[i]):4.2f}" for i in range(n))
+    clk = raw[:, 3].double() / ((raw[:, 1] - raw[:, 0]).double() * 10.0)   # cycles per ns = GHz (100 MHz wall clock ticks)
+    line += f" | s_memtime clock {float(clk.median()):.2f} GHz"
     per_wg = d[:, 1] - d[:, 0]
     line += f" | WG lifetime median {med(per_wg):6.1f} max {float(per_wg.max()):6.1f}"
     print(line, flush=True)
