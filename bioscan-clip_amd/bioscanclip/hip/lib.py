@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint32, c_void_p
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libbsclip_hip.so")
+# BSCLIP_LIB: another build of the same ABI (A/B experiments: `make -C bioscan-clip_amd/csrc exp`); never a non-HIP path
+LIB_PATH = os.environ.get("BSCLIP_LIB") or os.path.join(_PKG_ROOT, "lib", "libbsclip_hip.so")
 
 (EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, EPI_DGELU_BF16, EPI_PATCH_F32, EPI_GELU_FP8, EPI_RESID_BF16,
  EPI_PATCH_BF16) = range(9)

@@ -223,6 +223,25 @@ __device__ __forceinline__ void nt_store(void* p, uint2 v) {
 }
 __device__ __forceinline__ void nt_store(void* p, f32x4 v) { __builtin_nontemporal_store(v, static_cast<f32x4*>(p)); }
 
+// ---- streaming accesses of the memory-bound kernels (rows read once, written once).  Compile-time switch for A/B runs:
+// -DBSCLIP_STREAM_NT marks them non-temporal so that they do not displace the operand tiles of a GEMM running on the other
+// tower's stream (`make exp` builds ../lib/libbsclip_hip_exp.so with it; BSCLIP_LIB selects the library) ----
+#ifdef BSCLIP_STREAM_NT
+__device__ __forceinline__ uint2 ld_stream(const uint2* p) {
+    const nt_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x2*>(p));
+    return uint2{v[0], v[1]};
+}
+__device__ __forceinline__ f32x4 ld_stream(const f32x4* p) { return __builtin_nontemporal_load(p); }
+template <class T>
+__device__ __forceinline__ void st_stream(void* p, T v) { nt_store(p, v); }
+__device__ __forceinline__ void st_stream(void* p, unsigned v) { __builtin_nontemporal_store(v, static_cast<unsigned*>(p)); }
+#else
+__device__ __forceinline__ uint2 ld_stream(const uint2* p) { return *p; }
+__device__ __forceinline__ f32x4 ld_stream(const f32x4* p) { return *p; }
+template <class T>
+__device__ __forceinline__ void st_stream(void* p, T v) { *static_cast<T*>(p) = v; }
+#endif
+
 // ---- async global -> LDS, 16 B per lane (LDS dest = wave-uniform base + lane*16) ---------------------
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -46,13 +46,13 @@ __device__ __forceinline__ void load_row(const void* x, int ld_x, int row, int l
         const bf16_t* p = static_cast<const bf16_t*>(x) + (size_t)row * ld_x;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const uint2 u = *reinterpret_cast<const uint2*>(p + j * 256 + lane * 4);
+            const uint2 u = ld_stream(reinterpret_cast<const uint2*>(p + j * 256 + lane * 4));
             v[j] = f32x4{bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
         }
     } else {
         const float* p = static_cast<const float*>(x) + (size_t)row * ld_x;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + j * 256 + lane * 4);
+        for (int j = 0; j < NV; ++j) v[j] = ld_stream(reinterpret_cast<const f32x4*>(p + j * 256 + lane * 4));
     }
 }
 
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
         if (y_f32) {
 #pragma unroll
             for (int j = 0; j < NV; ++j)
-                *reinterpret_cast<f32x4*>(y_f32 + (size_t)row * H + j * 256 + lane * 4) = v[j];
+                st_stream(y_f32 + (size_t)row * H + j * 256 + lane * 4, v[j]);
         }
         if (y_bf16) {
             bf16_t* yr = y_bf16 + (size_t)row * ld_y;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
                 unsigned char* y8 = reinterpret_cast<unsigned char*>(y_bf16) + (size_t)row * ld_y;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
-                    *reinterpret_cast<unsigned*>(y8 + j * 256 + lane * 4) = pack_fp8x4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    st_stream(y8 + j * 256 + lane * 4, pack_fp8x4(v[j][0], v[j][1], v[j][2], v[j][3]));
                 yr = t_aug + (size_t)row * ld_t - H;   // so that yr[H + lane] below is t_aug[row][lane]
             } else {
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
                     uint2 o;
                     o.x = pack_bf2(v[j][0], v[j][1]);
                     o.y = pack_bf2(v[j][2], v[j][3]);
-                    *reinterpret_cast<uint2*>(yr + j * 256 + lane * 4) = o;
+                    st_stream(yr + j * 256 + lane * 4, o);
                 }
             }
             if constexpr (LORA) {
@@ -211,20 +211,20 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
                 const bf16_t* p = static_cast<const bf16_t*>(g_resid) + (size_t)row * ld_gr;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(p + j * 256 + lane * 4);
+                    const uint2 u = ld_stream(reinterpret_cast<const uint2*>(p + j * 256 + lane * 4));
                     res[j] = f32x4{bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
-                    res[j] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g_resid) + (size_t)row * ld_gr + j * 256 + lane * 4);
+                    res[j] = ld_stream(reinterpret_cast<const f32x4*>(static_cast<const float*>(g_resid) + (size_t)row * ld_gr + j * 256 + lane * 4));
             }
         }
         if (g_gemm) {
             const bf16_t* p = g_gemm + (size_t)row * ld_g;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const uint2 u = *reinterpret_cast<const uint2*>(p + j * 256 + lane * 4);
+                const uint2 u = ld_stream(reinterpret_cast<const uint2*>(p + j * 256 + lane * 4));
                 dy[j] = f32x4{bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
             }
         }
@@ -266,9 +266,9 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
                     uint2 o;
                     o.x = pack_bf2(d[0], d[1]);
                     o.y = pack_bf2(d[2], d[3]);
-                    *reinterpret_cast<uint2*>(static_cast<bf16_t*>(dx_res) + (size_t)row * ld_dx + j * 256 + lane * 4) = o;
+                    st_stream(static_cast<bf16_t*>(dx_res) + (size_t)row * ld_dx + j * 256 + lane * 4, o);
                 } else {
-                    *reinterpret_cast<f32x4*>(static_cast<float*>(dx_res) + (size_t)row * ld_dx + j * 256 + lane * 4) = d;
+                    st_stream(static_cast<float*>(dx_res) + (size_t)row * ld_dx + j * 256 + lane * 4, d);
                 }
             }
             if (dx_bf16) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
                 uint2 o;
                 o.x = pack_bf2(d[0], d[1]);
                 o.y = pack_bf2(d[2], d[3]);
-                *reinterpret_cast<uint2*>(dx_bf16 + (size_t)row * ld_dxb + j * 256 + lane * 4) = o;
+                st_stream(dx_bf16 + (size_t)row * ld_dxb + j * 256 + lane * 4, o);
             }
         }
     }
