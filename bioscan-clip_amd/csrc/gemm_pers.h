@@ -466,7 +466,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
 // fc1 ~ -3 %, the step 40.0 -> 39.4 ms (profiles/r03_i_gemm_pers.log); BSCLIP_GEMM_NT=0 is the A/B switch
 const bool g_pers_nt = !(getenv("BSCLIP_GEMM_NT") && atoi(getenv("BSCLIP_GEMM_NT")) == 0);
 const int g_pers_gw = getenv("BSCLIP_GEMM_GW") ? atoi(getenv("BSCLIP_GEMM_GW")) : 0;   // experiment: super-column width
-int g_pers_grid = 0;   // bsclip_gemm_set_persistent_grid: workgroups of the persistent launch, 0 = one per CU
+int g_pers_grid = getenv("BSCLIP_GEMM_WGS") ? atoi(getenv("BSCLIP_GEMM_WGS")) : 0;   // bsclip_gemm_set_persistent_grid: workgroups of the persistent launch, 0 = one per CU
 
 template <int EPI, bool HB>
 void launch_pers(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K, const EpiArgs& e_in,
