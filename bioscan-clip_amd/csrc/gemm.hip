@@ -1149,6 +1149,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const bf16_t* __restric
 #include "gemm_pers.h"
 
 int g_tile_override = 0;
+// selection of the persistent kernel, tuned IN THE STEP (profiles/r03_m_pers_selection.log): per-shape microbenchmarks favour the
+// duo kernel on the ViT's 768x768 GEMMs and tie on K >= 2304, but with two tower streams sharing the chip the step is fastest
+// when every 256x256-tile GEMM with more tiles than CUs is persistent (39.24 -> 38.59 ms on one box)
+const int g_pers_max_k = getenv("BSCLIP_PERS_MAX_K") ? atoi(getenv("BSCLIP_PERS_MAX_K")) : 4096;
+const int g_pers_min_tiles = getenv("BSCLIP_PERS_MIN_TILES") ? atoi(getenv("BSCLIP_PERS_MIN_TILES")) : 256;
+const bool g_duo_off = !(getenv("BSCLIP_GEMM_DUO") && atoi(getenv("BSCLIP_GEMM_DUO")) == 1);   // bsclip_gemm_set_tile(5) still selects it
 const bool g_pers_off = getenv("BSCLIP_GEMM_PERSISTENT") && atoi(getenv("BSCLIP_GEMM_PERSISTENT")) == 0;   // A/B switch
 [[maybe_unused]] int g_diag_ablate = 0;  // tools/gemm_ablate.py: which parts of the K loop the diagnostic EPI_BF16 build leaves out
 
@@ -1189,11 +1195,11 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
         // the two-workgroups-per-CU kernel (gemm_duo.h) ties the ping-pong kernel on most shapes and wins where a tile is short
         // (12 K-tiles) and the grid is a few rounds deep: the ViT's N = K = 768 GEMMs (out-projection and its dX: 60 vs 67 us,
         // 76 vs 79 us at M = 50 432; profiles/r03_f_gemm_tiles.log).  BarcodeBERT's M = 34 048 (1.56 rounds) stays on ping-pong.
-        if (tile == 4 && N == 768 && K == 768 && t256 >= 500 && EPI != BSCLIP_EPI_GELU_BF16) tile = 5;
+        if (tile == 4 && N == 768 && K == 768 && t256 >= 500 && EPI != BSCLIP_EPI_GELU_BF16 && !g_duo_off) tile = 5;
         // the persistent form (gemm_pers.h) hides a tile's 2.5-3 us prologue under the previous tile; it pays where tiles are
         // short (K <= 832: 12-13 K-tiles) and a workgroup walks several of them; with 36-48 K-tiles its four-round epilogue
         // costs more than the prologue it saves (profiles/r03_i_gemm_pers.log)
-        if (tile == 4 && pers_supported(EPI) && K <= 1024 && K >= 2 * BK && t256 >= 512 && !g_pers_off) tile = 8;
+        if (tile == 4 && pers_supported(EPI) && K <= g_pers_max_k && K >= 2 * BK && t256 >= g_pers_min_tiles && !g_pers_off) tile = 8;
     }
     if ((tile == 3 || tile == 4 || tile == 6 || tile == 7 || tile == 8) && N % 256 != 0) tile = 2;
     switch (tile) {
