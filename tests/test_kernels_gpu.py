@@ -655,10 +655,12 @@ def test_clock_probe_reads_a_plausible_engine_clock(ops):
     import time
     p0, p1 = torch.zeros(32, dtype=torch.int64, device="cuda"), torch.zeros(32, dtype=torch.int64, device="cuda")
     a = torch.randn(4096, 4096, device="cuda")
+    for _ in range(40):            # library initialisation and the clock's ramp from idle stay outside the measured window
+        a = a @ a * 1e-3
     torch.cuda.synchronize()
-    ops.clock_probe(p0)
     t0 = time.perf_counter()
-    for _ in range(20):
+    ops.clock_probe(p0)
+    for _ in range(40):
         a = a @ a * 1e-3
     ops.clock_probe(p1)
     torch.cuda.synchronize()
@@ -669,4 +671,4 @@ def test_clock_probe_reads_a_plausible_engine_clock(ops):
     seen = [x for x in range(16) if q0[x, 1] and q1[x, 1]]
     assert len(seen) >= 1
     ticks = max(int(q1[x, 1] - q0[x, 1]) for x in seen)          # 100 MHz
-    assert 0.5 * dt < ticks / 1e8 < 1.5 * dt + 1e-3, (ticks, dt)
+    assert 0.3 * dt < ticks / 1e8 < 1.05 * dt + 1e-3, (ticks, dt)   # the probes run inside [t0, t0 + dt]; enqueue leads execution
