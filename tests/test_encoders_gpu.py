@@ -346,6 +346,8 @@ def test_training_on_a_fixed_batch_drives_the_loss_down():
     from bioscanclip.model.image_encoder import LoRA_ViT_timm
     from bioscanclip.model.loss_func import ContrastiveLoss
     from bioscanclip.model.simple_clip import SimpleCLIP
+    import gc
+    gc.collect()   # garbage of earlier tests (engines in reference cycles) must not be freed in the middle of the memory samples
     torch.manual_seed(5)
     model = SimpleCLIP(LoRA_ViT_timm(arch.VisionTransformerParams(depth=4), r=4, num_classes=768),
                        LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=4)), r=4,
@@ -367,7 +369,7 @@ def test_training_on_a_fixed_batch_drives_the_loss_down():
             mem.append(torch.cuda.memory_allocated())
     _log({"test": "fixed-batch training", "losses": losses})
     assert all(l == l for l in losses) and losses[-1] < 0.5 * losses[0], losses
-    assert max(mem[1:]) - min(mem[1:]) < 64 * 2 ** 20, mem
+    assert max(mem[1:]) - mem[1] < 64 * 2 ** 20, mem   # no growth from step to step (a collector run may only lower it)
     assert all(torch.isfinite(p).all() for p in model.parameters())
 
 
