@@ -96,8 +96,7 @@ VIT_LAST_BLOCK_SKIPPED_GFLOP = (2 * 196 * 768 * (768 + 2 * 3072) * 2 + 4 * 196 *
 
 def time_dominant_gemm(B, device, reps=4):
     """The kernel with the largest share of the step: the fc1 + bias + exact GELU GEMM (writes gelu(z) and gelu'(z)) --
-    gemm_nt_pers_kernel<EPI_GELU_BF16, bias> (csrc/gemm_pers.h) for the two [M, 3072, 768] shapes, gemm_nt_pp_kernel<...> for the
-    768 x 768 transform.  One step launches it 24 times: 11x ViT fc1 [B*197, 3072, 768] (the 12th ViT block's MLP
+    gemm_nt_pers_kernel<EPI_GELU_BF16, bias> (csrc/gemm_pers.h).  One step launches it 24 times: 11x ViT fc1 [B*197, 3072, 768] (the 12th ViT block's MLP
     runs on the B token-0 rows only and goes to the small-grid kernel), 12x BarcodeBERT fc1 [B*133, 3072, 768] and once for
     cls.predictions.transform [B*133, 768, 768].  The same mix is timed here with HIP
     events on the launch stream, so the average duration is directly comparable with the kernel's row in the
@@ -135,8 +134,7 @@ def time_dominant_gemm(B, device, reps=4):
             "traffic_note": FC1_TRAFFIC_SOURCE + "; algorithmic bytes per launch: "
                             "%.1f MB (A + W bf16, gelu bf16, gelu' 8-bit)" % (sum(((M * K + N * K) * 2.0 + 3.0 * M * N) * c for M, N, K, c in shapes)
                                                                              / launches / 1e6),
-            "kernel": "gemm_nt_pers_kernel<2 = EPI_GELU_BF16, true, false, true> (fc1 + bias + GELU, 23 launches per step) + "
-                      "gemm_nt_pp_kernel<2, true> (the 768x768 transform, 1 launch)",
+            "kernel": "gemm_nt_pers_kernel<2 = EPI_GELU_BF16, true, false, true> (fc1 + bias + GELU; 24 launches per step)",
             "launch_mix_MNK_count": [list(x) for x in shapes],
             "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "avg_launch_ms": round(mean_ms, 4)}
 
