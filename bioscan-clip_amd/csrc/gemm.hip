@@ -1192,13 +1192,14 @@ void launch_epi(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int
         const long t256 = (long)ceil_div(M, 256) * (N / 256);
         if (N % 256 == 0 && t256 >= 192) tile = 4;
         else tile = 1;
-        // the two-workgroups-per-CU kernel (gemm_duo.h) ties the ping-pong kernel on most shapes and wins where a tile is short
-        // (12 K-tiles) and the grid is a few rounds deep: the ViT's N = K = 768 GEMMs (out-projection and its dX: 60 vs 67 us,
-        // 76 vs 79 us at M = 50 432; profiles/r03_f_gemm_tiles.log).  BarcodeBERT's M = 34 048 (1.56 rounds) stays on ping-pong.
+        // the two-workgroups-per-CU kernel (gemm_duo.h) ties the ping-pong kernel on most shapes and wins, per shape, where a tile
+        // is short (12 K-tiles) and the grid is a few rounds deep: the ViT's N = K = 768 GEMMs (60 vs 67 us, 76 vs 79 us at
+        // M = 50 432; profiles/r03_f_gemm_tiles.log).  Off by default since the end of round 3 (BSCLIP_GEMM_DUO=1): in the step,
+        // beside the other tower's persistent kernels, it loses (profiles/r03_m_pers_selection.log).
         if (tile == 4 && N == 768 && K == 768 && t256 >= 500 && EPI != BSCLIP_EPI_GELU_BF16 && !g_duo_off) tile = 5;
-        // the persistent form (gemm_pers.h) hides a tile's 2.5-3 us prologue under the previous tile; it pays where tiles are
-        // short (K <= 832: 12-13 K-tiles) and a workgroup walks several of them; with 36-48 K-tiles its four-round epilogue
-        // costs more than the prologue it saves (profiles/r03_i_gemm_pers.log)
+        // the persistent form (gemm_pers.h) hides a tile's 2.5-3 us prologue under the previous tile.  Per shape it pays where
+        // tiles are short (K <= 832) and ties at 36-48 K-tiles (profiles/r03_i_gemm_pers.log); in the step it pays everywhere a
+        // workgroup has more than one tile to walk (g_pers_max_k / g_pers_min_tiles above)
         if (tile == 4 && pers_supported(EPI) && K <= g_pers_max_k && K >= 2 * BK && t256 >= g_pers_min_tiles && !g_pers_off) tile = 8;
     }
     if ((tile == 3 || tile == 4 || tile == 6 || tile == 7 || tile == 8) && N % 256 != 0) tile = 2;
