@@ -300,8 +300,9 @@ def main():
     graphed = None
     if not a.no_graph:
         from bioscanclip.hip.graph import GraphedDistStep, GraphedStep
-        # with a process group: three captured graphs (towers' forward | loss + backward | AdamW), the all-gathers and all-reduces
-        # issued eagerly between them (hip/graph.py GraphedDistStep) -- a rank's host work drops from ~35 ms to ~1 ms per step
+        # with a process group: per-tower captured graphs (forward_k | loss | backward_k | AdamW), each tower's all-gather and
+        # all-reduce issued eagerly from that tower's stream between them (hip/graph.py GraphedDistStep) -- a rank's host work
+        # drops from ~35 ms to ~1 ms per step and the collectives run beside the other towers' kernels
         graphed = (GraphedDistStep if world > 1 or force_dist else GraphedStep)(model, opt, crit, warmup=2)
 
     def step():
@@ -399,7 +400,7 @@ def main():
                        "dropout": ("DISABLED (diagnostic run, not the benchmark configuration)" if nodrop else
                                    "HF defaults active (BERT hidden 0.1, attention-probs 0.1; timm ViT drop 0), train mode"),
                        "launch_path": ("eager (Python enqueue)" if graphed is None else
-                                       "three captured hipGraphs (forward | loss + backward | AdamW), collectives issued eagerly between them"
+                                       "per-tower captured hipGraphs (forward_k | loss | backward_k | AdamW), each tower's all-gather / all-reduce issued from its stream between them"
                                        if world > 1 or force_dist else "hipGraph replay (one captured step)"),
                        "final_loss": round(final_loss, 6)},
             "step_roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,

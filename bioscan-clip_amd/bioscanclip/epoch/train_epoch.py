@@ -7,11 +7,11 @@ are optional, and under a process group of more than one rank the flat trainable
 optimizer step.  Returns the mean loss of the epoch.
 
 Launch path (round 3): on one rank the step runs as ONE replayed hipGraph (``bioscanclip.hip.graph.GraphedStep``: the same
-Python body captured once -- bitwise the eager step, tests/test_graph_gpu.py) and the loss is read one step late, so the host
+Python body captured once -- bitwise the eager step, tests/test_30_graph_gpu.py) and the loss is read one step late, so the host
 never waits for the step it has just enqueued: what ``bench.py`` measures is what ``scripts/train_cl.py`` runs.  A batch whose
 shape differs from the captured one (a last, smaller batch) is enqueued eagerly.  ``BSCLIP_GRAPH=0`` forces the eager loop.  With
-more than one rank the step is three captured graphs (forward | loss + backward | AdamW) with the all-gathers and all-reduces
-issued eagerly between them (``GraphedDistStep``).
+more than one rank the step is a set of per-tower captured graphs (forward_k | loss | backward_k | AdamW) with each tower's
+all-gather and all-reduce issued eagerly from that tower's stream between them (``GraphedDistStep``).
 """
 import os
 
@@ -54,7 +54,7 @@ def _graphed_step(model, optimizer, criterion, device):
     key = (id(optimizer), id(criterion))
     g = getattr(model, "_bsclip_graphed", None)
     if g is None or g[0] != key:
-        # more than one rank: three captured graphs with the collectives issued eagerly between them (GraphedDistStep)
+        # more than one rank: per-tower captured graphs with the collectives issued eagerly between them (GraphedDistStep)
         g = (key, (GraphedDistStep if multi else GraphedStep)(model, optimizer, criterion, warmup=2))
         model._bsclip_graphed = g
     return g[1]

@@ -63,6 +63,8 @@ def _comm_stream(device):
 _OVERLAP = {"on": False, "group": None}
 _PENDING_AR = []      # [(flat gradient buffer, work handle)] issued from _EncoderFn.backward, waited in allreduce_grads
 _ISSUED_AR = []       # the gradient buffers in the order their all-reduces were issued this step (must be rank-independent)
+_ISSUED_TAGS = []     # ... and what each of them is ("ViTEngine:1476096"): compared across the ranks by allreduce_grads
+_AR_ORDER = {"sig": None}
 _PENDING_LABELS = {}  # id(label tensor) -> (label tensor, gathered labels, work handle)
 
 
@@ -71,6 +73,7 @@ def enable_overlap(group=None, on=True):
     encoder autograd nodes (see the module docstring).  Set by GlobalBatchContrastiveLoss; harmless without a process
     group (every hook checks ``overlap_active``)."""
     _OVERLAP["on"], _OVERLAP["group"] = bool(on), group
+    _AR_ORDER["sig"] = None
     _PENDING_AR.clear()
     _PENDING_LABELS.clear()
 
@@ -100,12 +103,14 @@ def start_label_gather(label):
         _PENDING_LABELS[id(label)] = (label,) + _all_gather_async(label, _OVERLAP["group"])
 
 
-def start_allreduce(flat):
+def start_allreduce(flat, tag=""):
     """Called from an encoder's autograd node on that tower's stream once its whole backward is enqueued."""
     if overlap_active():
         if not _PENDING_AR:
             _ISSUED_AR.clear()
+            _ISSUED_TAGS.clear()
         _ISSUED_AR.append(flat.grad)
+        _ISSUED_TAGS.append(f"{tag}:{flat.grad.numel()}")
         _PENDING_AR.append((flat.grad, dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=_OVERLAP["group"],
                                                        async_op=True)))
 
@@ -155,6 +160,21 @@ def flat_buffers(model):
     return out
 
 
+def _check_issue_order(group):
+    """Collectives pair up across ranks by issue order alone, and the per-encoder all-reduces are issued from autograd's
+    thread: the first step compares the order (which encoder, how many elements) across ALL ranks, every later step compares
+    it with the first.  A mismatch would otherwise sum one encoder's gradients into another's, silently."""
+    sig = list(_ISSUED_TAGS)
+    if _AR_ORDER["sig"] is None:
+        theirs = [None] * dist.get_world_size(group)
+        dist.all_gather_object(theirs, sig, group=group)
+        if any(t != theirs[0] for t in theirs):
+            raise RuntimeError(f"gradient all-reduces were issued in different orders on different ranks: {theirs}")
+        _AR_ORDER["sig"] = sig
+    elif sig != _AR_ORDER["sig"]:
+        raise RuntimeError(f"gradient all-reduce issue order changed: {sig} vs {_AR_ORDER['sig']} on the first step")
+
+
 def allreduce_grads(model_or_buffers, group=None):
     """SUM the flat trainable-gradient buffers over the ranks.  Buffers whose all-reduce was already started by
     ``start_allreduce`` (overlap mode) are only waited for."""
@@ -162,6 +182,8 @@ def allreduce_grads(model_or_buffers, group=None):
         return
     bufs = model_or_buffers if isinstance(model_or_buffers, (list, tuple)) else [f.grad for f in flat_buffers(model_or_buffers)]
     started = {b.data_ptr(): w for b, w in _PENDING_AR}
+    if _PENDING_AR:
+        _check_issue_order(group)
     _PENDING_AR.clear()
     works = [started.pop(b.data_ptr(), None) or dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True)
              for b in bufs]
@@ -227,7 +249,7 @@ class NativeComm:
     unique id travels from rank 0 through whatever channel the caller has (here: an existing ``torch.distributed`` group of any
     backend, or nothing at world_size 1).  The product path keeps ``torch.distributed`` (identical collectives, same RCCL
     underneath); this class is the drop-in for it and is exercised at world_size 1 on the one-GPU test box
-    (tests/test_dist_gpu.py)."""
+    (tests/test_90_dist_gpu.py)."""
 
     def __init__(self, rank=0, world=1, group=None, device=None):
         import ctypes

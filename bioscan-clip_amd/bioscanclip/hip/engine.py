@@ -758,7 +758,7 @@ class _EncoderFn(torch.autograd.Function):
                                "next training-mode forward (the reference loop does: train_epoch.py:28-42)")
         ctx.engine.backward(dout.contiguous())
         from .dist import start_allreduce
-        start_allreduce(ctx.engine.flat)  # global-batch step: this tower's gradients are complete on this stream
+        start_allreduce(ctx.engine.flat, type(ctx.engine).__name__)  # global-batch step: this tower's gradients are complete on this stream
         here = torch.cuda.current_stream()
         # gradients are complete before anything queued afterwards on the stream the tower was forked from -- and, outside a
         # stream capture, on the default stream (inside a capture that wait would pull the default stream into the graph and

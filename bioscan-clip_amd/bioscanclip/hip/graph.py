@@ -10,10 +10,33 @@ in-flight node reads host memory the host could rewrite), launch the graph, and 
     (``bsclip_adamw_step_dev``), inputs from static buffers;
   * nothing in the step synchronises or allocates outside the capture's private pool (workspaces are built by the eager
     warm-up steps; the library never allocates).
-One process group collective inside a capture is avoided on purpose: with world_size > 1 the step stays eager (the towers'
-all-gathers and the per-encoder all-reduces are issued from Python).
+No process-group collective sits inside a captured region: with world_size > 1 the step is a handful of per-tower graphs with
+the collectives issued between them (``GraphedDistStep``).
 """
+import os
+import time
+
 import torch
+
+# Capture mode (round 4, the GPUTEST_r03 abort).  hipEventQuery / hipStreamQuery are on HIP's list of calls that are illegal
+# while ANY stream of the process is being captured in the default "global" mode -- from every thread.  ProcessGroupNCCL's
+# watchdog thread polls the end events of the collectives it still lists (hipEventQuery, every ~100 ms): when such a poll
+# landed inside a global-mode capture the query failed, the watchdog rethrew from its own thread and the process died with
+# SIGABRT (ProcessGroupNCCL.cpp:2099, WorkNCCL::finishedGPUExecutionInternal).  torch.cuda.synchronize() completes the GPU work
+# but does not make the watchdog drop its Work objects, so whether a poll hits the capture window was a race.  Two measures,
+# either sufficient: (1) every capture here is "thread_local": only the capturing thread is held to the restricted call set,
+# the watchdog's queries stay legal; (2) ``quiesce_process_group`` before a capture: all device work done, then long enough
+# for the watchdog to retire everything it lists, so that it has nothing to query.
+CAPTURE_MODE = os.environ.get("BSCLIP_CAPTURE_MODE", "thread_local")
+
+
+def quiesce_process_group():
+    """No collective in flight and none on the ProcessGroupNCCL watchdog's list when a capture begins."""
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        time.sleep(float(os.environ.get("BSCLIP_PG_QUIESCE_S", "0.35")))     # > 3 watchdog polls (100 ms each)
+        torch.cuda.synchronize()
 
 
 class GraphedStep:
@@ -105,10 +128,10 @@ class GraphedStep:
             self.loss = self._body()
             return self.loss
         if self.graph is None:
-            torch.cuda.synchronize()
+            quiesce_process_group()
             self.captured_for = self._signature()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
                 self.loss = self._body()
             # the capture ran the host half of the step once (step counts) without executing anything; lr is delivered outside
             # the graph, before the replay that consumes it
@@ -120,25 +143,36 @@ class GraphedStep:
         return self.loss
 
 
+class _Tower:
+    __slots__ = ("name", "enc", "x", "stream", "gF", "gB", "emb", "z", "dz", "full", "flat", "work")
+
+
 class GraphedDistStep(GraphedStep):
-    """The global-batch step (world_size > 1) as THREE captured hipGraphs with the collectives issued eagerly between them:
+    """The global-batch step (world_size > 1) as per-tower captured hipGraphs with the collectives issued eagerly BETWEEN them,
+    each from the stream of the tower whose data it moves (round 4; round 3 replayed forward | loss + backward | AdamW serially
+    and lost north_star's overlap):
 
-        [all-gather labels]  graph A: zero_grad + the towers' forward  ->  [all-gather each modality's embeddings]
-        graph B: loss over the gathered batch (own rows re-inserted) + backward through every encoder  ->  [all-reduce (SUM)
-        each encoder's flat gradient buffer]  ->  graph C: fused AdamW.
+        main stream     [all-gather labels] ............ wait(gathers) gL: loss over the gathered batch, dL/dz per modality .... wait(all-reduces) gC: fused AdamW
+        tower stream k  gF[k]: zero this encoder's gradients, forward, l2norm -> [all-gather z_k] .... gB[k]: backward of tower k -> [all-reduce(SUM) flat grads k]
 
-    Eagerly a rank spends ~35 ms of host time per step on ~1 100 ctypes launches (the GPU step is 41 ms at local batch 256:
-    the rank is host-bound next to 7 others); here it issues 3 graph launches and 5-7 collectives.  No RCCL call sits inside a
-    captured region -- the collectives are ordinary ``torch.distributed`` calls on the process group between replays, so the
-    path is the one RCCL is exercised on everywhere -- at the price of the overlap the eager path has (a modality's 0.8 MB
-    all-gather beside the other towers' encoders, a 6 MB all-reduce beside the other tower's backward: tens of microseconds).
-    Kernel for kernel the replays are the eager step: tests/test_dist_gpu.py holds the two to the same losses and parameters
-    on two ranks."""
+    A modality's all-gather is enqueued the moment its tower's forward graph is launched, ordered behind THAT tower only: it runs
+    on the process group's stream beside the other towers' encoders (the image tower is launched first and finishes last; the
+    DNA and text gathers hide under it).  Each encoder's flat-gradient all-reduce is enqueued behind its own backward graph and
+    runs beside the other towers' backward.  The loss graph waits for the gathers, the optimizer graph for the all-reduces:
+    stream waits, never host waits (RCCL backend).  Per step the host issues 2 T + 2 graph launches and 2 T + 1 collectives
+    (T towers) instead of ~1 100 ctypes launches.  No RCCL call sits inside a captured region -- the collectives are ordinary
+    ``torch.distributed`` calls, the path RCCL is exercised on everywhere.  Kernel for kernel and stream for stream the replays
+    are the eager global-batch step: tests/test_90_dist_gpu.py holds the two to the same losses and parameters on two ranks,
+    bit for bit."""
 
     def __init__(self, model, optimizer, criterion, warmup=2, group=None):
         super().__init__(model, optimizer, criterion, warmup)
         self.group = group if group is not None else getattr(criterion, "group", None)
-        self.gA = self.gB = self.gC = None
+        self.towers = None
+        self.gL = self.gC = None
+
+    def n_graphs(self):
+        return 0 if self.towers is None else sum((t.gF is not None) + (t.gB is not None) for t in self.towers) + 2
 
     def _eager(self):
         image, dna, text, label = self.static
@@ -157,57 +191,113 @@ class GraphedDistStep(GraphedStep):
         self.loss_buf.copy_(loss.detach())
         return self.loss_buf
 
+    def _make_towers(self):
+        from ..model.simple_clip import _tower_stream
+        image, dna, text, _ = self.static
+        dev = self.static[3].device
+        out = []
+        # the eager step's host order (SimpleCLIP.forward: image, DNA, text) and the eager step's streams
+        for k, name, enc, x in ((1, "image", self.model.image_encoder, image), (0, "dna", self.model.dna_encoder, dna),
+                                (2, "text", self.model.language_encoder, text)):
+            if enc is None:
+                continue
+            t = _Tower()
+            t.name, t.enc, t.x, t.stream = name, enc, x, _tower_stream(k, dev)
+            t.gF = t.gB = t.emb = t.z = t.dz = t.full = t.flat = t.work = None
+            out.append(t)
+        if len(out) < 2:
+            raise ValueError("Too less element for calculating the contrastive loss.")
+        return out
+
     def _capture(self):
         import torch.distributed as dist
         from . import dist as hdist
-        from .functional import infonce
-        image, dna, text, label = self.static
+        from .functional import infonce, l2_normalize
+        label = self.static[3]
         W, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         B = label.shape[0]
         self.row0 = rank * B
         dev = label.device
         self.labels_full = torch.empty(W * B, dtype=label.dtype, device=dev)
+        towers = self._make_towers()
+        mode = dict(capture_error_mode=CAPTURE_MODE)
         was_on = hdist._OVERLAP["on"]
         hdist._OVERLAP["on"] = False            # no collective is issued from inside a captured region
         try:
-            torch.cuda.synchronize()
+            quiesce_process_group()
             self.captured_for = self._signature()
-            self.gA = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.gA):
-                self.optimizer.zero_grad()
-                outs = self.model(image, dna, text)
-            self.emb = [o for o in outs if o is not None]
-            self.full = [torch.empty(W * B, e.shape[1], dtype=torch.float32, device=dev) for e in self.emb]
-            self.gB = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.gB, pool=self.gA.pool()):
-                gathered = [hdist._InsertLocal.apply(e, f, self.row0) for e, f in zip(self.emb, self.full)]
+            pool = None
+            for t in towers:                    # forward of one tower, on that tower's stream
+                eng = getattr(t.enc, "_engine", None)
+                t.flat = getattr(eng, "flat", None)
+                t.gF = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(t.gF, pool=pool, stream=t.stream, **mode):
+                    if t.flat is not None:
+                        t.flat.bind_grads()
+                        t.flat.grad.zero_()     # optimizer.zero_grad() for this encoder
+                    t.emb = l2_normalize(t.enc(t.x))
+                pool = t.gF.pool() if pool is None else pool
+                t.full = torch.empty(W * B, t.emb.shape[1], dtype=torch.float32, device=dev)
+            self.gL = torch.cuda.CUDAGraph()    # loss over the gathered batch, own rows re-inserted; dL/dz of every modality
+            with torch.cuda.graph(self.gL, pool=pool, **mode):
+                for t in towers:
+                    t.z = t.emb.detach().requires_grad_(t.emb.requires_grad)
+                gathered = [hdist._InsertLocal.apply(t.z, t.full, self.row0) for t in towers]
                 loss = infonce(gathered, self.labels_full, self.criterion.logit_scale, row0=self.row0, n_local=B)
-                loss.backward()
+                live = [t for t in towers if t.z.requires_grad]
+                for t, g in zip(live, torch.autograd.grad(loss, [t.z for t in live])):
+                    t.dz = g
                 self.loss_buf.copy_(loss.detach())
-            self.flats = [f for f in hdist.flat_buffers(self.model)]
+            for t in towers:                    # backward of one tower, on that tower's stream
+                if t.dz is None:
+                    continue
+                t.gB = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(t.gB, pool=pool, stream=t.stream, **mode):
+                    t.emb.backward(t.dz)
             self.gC = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.gC, pool=self.gA.pool()):
+            with torch.cuda.graph(self.gC, pool=pool, **mode):
                 self.optimizer.step()
         finally:
             hdist._OVERLAP["on"] = was_on
-        self.graph = self.gA                    # "captured" marker for the base class's bookkeeping
+        self.towers = towers
+        self.graph = self.gL                    # "captured" marker for the base class's bookkeeping
 
     def _replay(self):
         import torch.distributed as dist
         label = self.static[3]
-        lw = dist.all_gather_into_tensor(self.labels_full, label.contiguous(), group=self.group, async_op=True)
-        self.gA.replay()
-        works = [dist.all_gather_into_tensor(f, e.detach(), group=self.group, async_op=True) for e, f in zip(self.emb, self.full)]
-        for w in [lw] + works:
-            w.wait()
-        self.gB.replay()
-        works = [dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self.flats]
+        main = torch.cuda.current_stream()
+        works = [dist.all_gather_into_tensor(self.labels_full, label.contiguous(), group=self.group, async_op=True)]
+        for t in self.towers:
+            t.stream.wait_stream(main)
+            with torch.cuda.stream(t.stream):
+                t.gF.replay()
+                # issued with the tower's stream current: the collective is ordered behind this tower only
+                works.append(dist.all_gather_into_tensor(t.full, t.emb.detach(), group=self.group, async_op=True))
         for w in works:
-            w.wait()
+            w.wait()                            # RCCL: `main` waits for the collective's stream; gloo (tests): the host does
+        for t in self.towers:
+            main.wait_stream(t.stream)
+        self.gL.replay()
+        for t in self.towers:
+            t.work = None
+            if t.gB is None:
+                continue
+            t.stream.wait_stream(main)
+            with torch.cuda.stream(t.stream):
+                t.gB.replay()
+                if t.flat is not None:
+                    t.work = dist.all_reduce(t.flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for t in self.towers:
+            if t.work is not None:
+                t.work.wait()
+            main.wait_stream(t.stream)
         self.gC.replay()
         if hasattr(self.optimizer, "sync_updated_slices"):
             self.optimizer.sync_updated_slices()      # sharded optimizer state (full fine-tuning): owners broadcast their slices
         return self.loss_buf
+
+    def _drop(self):
+        self.graph = self.gL = self.gC = self.towers = None
 
     def __call__(self, image, dna, text, label):
         self._stage(image, dna, text, label)
@@ -216,7 +306,7 @@ class GraphedDistStep(GraphedStep):
             self.loss = self._eager()
             return self.loss
         if self.graph is not None and self._signature() != self.captured_for:
-            self.graph = self.gA = self.gB = self.gC = None
+            self._drop()
             self.loss = self._eager()
             return self.loss
         if self.graph is None:

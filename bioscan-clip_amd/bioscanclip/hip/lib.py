@@ -39,7 +39,7 @@ class Fp8Args(Structure):
 
 P, I, F, L, U = c_void_p, c_int, c_float, c_int64, c_uint32
 
-# name -> (restype, argtypes); mirrors include/bsclip.h one to one (tests/test_abi.py checks both directions)
+# name -> (restype, argtypes); mirrors include/bsclip.h one to one (tests/test_00_abi.py checks both directions)
 SIGNATURES = {
     "bsclip_last_error": (c_char_p, []),
     "bsclip_abi_version": (I, []),

@@ -109,8 +109,13 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._shard is not None:
             lo, hi = self._slice_of(f)
             if st is None or st["m"].numel() != hi - lo or st.get("key") != key:
+                prev = next((v for v in self._flat_state.values() if v.get("key") == key and v.get("slice") == (lo, hi)), None)
                 st = {"m": torch.zeros(hi - lo, dtype=f.data.dtype, device=f.data.device),
                       "v": torch.zeros(hi - lo, dtype=f.data.dtype, device=f.data.device), "step": 0, "key": key, "slice": (lo, hi)}
+                if prev is not None:                  # engine rebuilt (checkpoint loaded mid-run): the optimisation continues
+                    st["m"].copy_(prev["m"])
+                    st["v"].copy_(prev["v"])
+                    st["step"] = prev["step"]
                 self._flat_state = {k: v for k, v in self._flat_state.items() if v.get("key") != key}
                 self._flat_state[id(f)] = st
             return st

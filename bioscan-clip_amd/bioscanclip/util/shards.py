@@ -184,11 +184,14 @@ class ShardLoader:
         if slot["cap_img"] < nbytes:
             slot["cap_img"] = int(nbytes * 1.25) + 4096
             slot["img_host"] = torch.empty(slot["cap_img"], dtype=torch.uint8).pin_memory()
-            slot["img_dev"] = torch.empty(slot["cap_img"], dtype=torch.uint8, device=self.device)
+            with torch.cuda.stream(self.stream):    # the staging buffer belongs to the stream that writes and reads it: a block
+                # of the default stream's pool could still be in use by queued kernels of the training step
+                slot["img_dev"] = torch.empty(slot["cap_img"], dtype=torch.uint8, device=self.device)
         if slot["cap_dna"] < dna_len + 1:
             slot["cap_dna"] = int(dna_len * 1.25) + 1024
             slot["dna_host"] = torch.empty(slot["cap_dna"], dtype=torch.uint8).pin_memory()
-            slot["dna_dev"] = torch.empty(slot["cap_dna"], dtype=torch.uint8, device=self.device)
+            with torch.cuda.stream(self.stream):
+                slot["dna_dev"] = torch.empty(slot["cap_dna"], dtype=torch.uint8, device=self.device)
         img_np, dna_np = slot["img_host"].numpy(), slot["dna_host"].numpy()
         sizes, off, doffs = [], 0, [0]
         for (o, h, w), i in zip(rows, idx):
@@ -282,8 +285,9 @@ class ShardLoader:
             k, b, out = item
             cur = torch.cuda.current_stream(dev)
             cur.wait_event(out["ready"])
-            for t in (out["image"], out["dna"], *[x for x in out["text"] if x is not None]):
-                t.record_stream(cur)
+            for t in (out["image"], out["dna"], out["label"], *[x for x in out["text"] if x is not None]):
+                if torch.is_tensor(t):       # every tensor allocated on the loader's stream and consumed on the caller's
+                    t.record_stream(cur)
             self.last_params, self.last_indices = out["params"], b
             yield (out["processid"], out["image"], out["dna"], out["text"][0], out["text"][1], out["text"][2], out["label"])
         th.join()

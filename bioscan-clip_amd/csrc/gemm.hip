@@ -181,7 +181,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int m, int n, void* C, i
         *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (size_t)m * ldc + n) = v;
     } else if constexpr (EPI == BSCLIP_EPI_GELU_BF16) {
         // the same table-driven GELU as the 256x256 kernel (table read from global memory here: 8 KB, cache-resident), so a
-        // row's result does not depend on which tile shape its batch size selects (tests/test_configs_gpu.py)
+        // row's result does not depend on which tile shape its batch size selects (tests/test_70_configs_gpu.py)
         f32x2 g0, d0, g1, d1;
         gelu_lut2(reinterpret_cast<const char*>(g_gelu_lut), f32x2{v[0], v[1]}, g0, d0);
         gelu_lut2(reinterpret_cast<const char*>(g_gelu_lut), f32x2{v[2], v[3]}, g1, d1);
@@ -1350,7 +1350,7 @@ extern "C" int bsclip_gemm_pers_diag(const void* A, int lda, const void* B, int 
     e.n_total = N;
     e.diag = diag;
     const int tiles_m = ceil_div(M, 256), tiles_n = N / 256, nt = tiles_m * tiles_n;
-    e.pers_gw = tiles_n | (getenv("BSCLIP_PERS_ABL") && atoi(getenv("BSCLIP_PERS_ABL")) == 1 ? 0x100 : 0);
+    e.pers_gw = tiles_n | (getenv("BSCLIP_PERS_ABL") && atoi(getenv("BSCLIP_PERS_ABL")) == 1 ? 0x40000000 : 0);
     const dim3 grid(nt < workgroups ? nt : workgroups), block(512);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t* a = static_cast<const bf16_t*>(A);

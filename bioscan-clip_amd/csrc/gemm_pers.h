@@ -41,8 +41,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(const bf16_t* __restr
                                                             const bf16_t* __restrict__ B, int ldb, void* __restrict__ C,
                                                             int ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e) {
     static_assert(pers_supported(EPI), "persistent kernel: epilogue not instantiated");
-    const int gw = e.pers_gw & 0xff;             // column tiles per super-column, divides tiles_n
-    const bool abl_st = DIAG && (e.pers_gw & 0x100);   // diagnostic build: leave the output stores out
+    const int gw = e.pers_gw & 0x3fffffff;       // column tiles per super-column, divides tiles_n (any tiles_n: the flag sits in bit 30)
+    const bool abl_st = DIAG && (e.pers_gw & 0x40000000);   // diagnostic build: leave the output stores out
     const int tiles_m = ntiles / tiles_n;
     if constexpr (epi_is_resid(EPI)) BSCLIP_DROP_RESOLVE(e.drop);
     constexpr int SET1 = 98304, SPARE = 65536, HALF = 16384, B_OFF = 32768;

@@ -9,7 +9,7 @@ weights can be fed to (a) the imported reference modules (``oracle/gen_golden.py
 only), (b) this restatement, (c) the HIP engine.
 
 Pinning: ``oracle/gen_golden.py`` runs the *imported reference* (`/root/reference`) on seeded inputs
-and stores its outputs under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file
+and stores its outputs under ``tests/golden/``; ``tests/test_01_oracle_golden.py`` checks this file
 against those fixtures.  The third-party arithmetic the reference delegates to (timm 0.6.13 ViT,
 HF transformers 4.29.2 BERT) is restated from its published semantics:
 the BERT half is pinned through the HF classes the reference really calls (transformers 5.15 here),

@@ -4,7 +4,7 @@ Restates ``make_prediction`` (reference scripts/inference_and_eval.py:414-445). 
 dependencies that are not vendored under /root/reference: scikit-learn ``preprocessing.normalize(norm="l2", axis=1)`` (rows
 divided by their L2 norm, zero rows left as they are) and faiss ``IndexFlatIP`` (pinned only as "faiss" in the reference's
 requirements; exhaustive inner-product search, results per query sorted by decreasing score).  scikit-learn is importable
-here and ``topk_ip`` is checked against its ``normalize`` in tests/test_oracle_golden.py; faiss is absent, so the search half
+here and ``topk_ip`` is checked against its ``normalize`` in tests/test_01_oracle_golden.py; faiss is absent, so the search half
 is "parity unpinned" against faiss itself and anchored on its published definition (brute-force float32 inner products).
 The accuracy helpers are pinned against the reference's own functions through tests/golden/retrieval.json
 (oracle/gen_golden.py).

@@ -200,3 +200,18 @@ def test_shipped_model_configs_carry_the_reference_values():
         assert bool(cfg.get("disable_lora", False)) == ft and cfg.get("lr_scheduler") == sched, rel
         if lrc is not None:
             assert {k: float(v) for k, v in cfg["lr_config"].items()} == lrc, rel
+
+
+def test_product_package_is_oracle_free():
+    """The oracle is test infrastructure: nothing under the product package may import it (the smoke checker that does lives at
+    the repo root, next to __graft_entry__.py)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bioscan-clip_amd")
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    hits = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py") and pat.search(open(os.path.join(d, f)).read()):
+                hits.append(os.path.join(d, f))
+    assert not hits, hits

@@ -175,7 +175,7 @@ def test_get_feature_and_label_matches_oracle():
         assert got.dtype == np.float64 and got.shape == (6, 768)
         assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
         err = np.linalg.norm(got - r.numpy()) / np.linalg.norm(r.numpy())
-        assert err <= 2e-2, (key, err)  # TOL_EMB_F32 of test_encoders_gpu.py
+        assert err <= 2e-2, (key, err)  # TOL_EMB_F32 of test_20_encoders_gpu.py
     assert split["averaged_feature"].shape == (6, 768) and split["concatenated_feature"].shape == (6, 1536)
     assert split["all_key_features"].shape == (18, 768) and len(split["all_key_features_label"]) == 18
     # a model without a text tower returns (None, None, None) for it, as the reference does

@@ -7,7 +7,7 @@
 The CPU oracle cannot run B = 256 in seconds, so the encoders are held to a size-independent property instead: samples are
 independent (LayerNorm only, no batch statistics), hence rows 0..7 of a B-sample forward equal the 8-sample forward of the
 same samples, and with a cotangent that is zero outside those rows the trainable gradients are equal too.  The 8-sample run
-is the shape the golden fixtures pin (tests/test_encoders_gpu.py); the large run takes different kernels (tile shapes, grids,
+is the shape the golden fixtures pin (tests/test_20_encoders_gpu.py); the large run takes different kernels (tile shapes, grids,
 workspace strides), so the comparison is not vacuous.
 """
 import pytest

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 from oracle import refcpu, synth  # noqa: E402
 from helpers import load_golden  # noqa: E402
-import test_encoders_gpu as T  # noqa: E402
+import test_20_encoders_gpu as T  # noqa: E402
 from bioscanclip.model.loss_func import ContrastiveLoss  # noqa: E402
 
 g = load_golden("trajectory_id")

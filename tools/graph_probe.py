@@ -10,7 +10,7 @@ import bioscanclip.model.simple_clip as sc
 sc._TOWER_STREAMS = (sys.argv[1] if len(sys.argv) > 1 else "1") == "1"
 with_text = (sys.argv[2] if len(sys.argv) > 2 else "0") == "1"
 train = (sys.argv[3] if len(sys.argv) > 3 else "1") == "1"
-from test_graph_gpu import _build
+from test_30_graph_gpu import _build
 from oracle import synth
 from bioscanclip.hip.graph import GraphedStep
 from bioscanclip.hip.optim import FusedAdamW

@@ -1,12 +1,12 @@
 """Runs the same training step with the tower streams on and off and lists every gradient tensor that is not bitwise equal
 between runs (how the shared lora_grad workspace race was found).  Diagnostic; the pytest version is
-tests/test_encoders_gpu.py::test_tower_streams_join_before_gradients_are_read."""
+tests/test_20_encoders_gpu.py::test_tower_streams_join_before_gradients_are_read."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "bioscan-clip_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch
-import test_encoders_gpu as T
+import test_20_encoders_gpu as T
 from oracle import synth
 import bioscanclip.model.simple_clip as sc
 from bioscanclip.model.loss_func import ContrastiveLoss
