@@ -56,6 +56,8 @@ SIGNATURES = {
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, F, U, I, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
+    "bsclip_attn_fwd2": (I, [P, I, I, I, I, P, F, P, P, I, P, F, U, P]),
+    "bsclip_attn_bwd2": (I, [P, I, P, I, P, P, I, P, I, I, I, P, F, P, I, F, U, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, I, I, P]),
     "bsclip_mask_to_bias": (I, [P, I, P, P]),
     "bsclip_vit_cls_rows": (I, [P, I, P, P, I, I, I, P]),
@@ -110,6 +112,7 @@ DIAG_SIGNATURES = {
     "bsclip_gemm_duo_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, P]),
     "bsclip_gemm_pers_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, I, P]),
     "bsclip_attn_bwd_diag": (I, [P, I, P, I, P, I, I, I, F, P, I, P, P]),
+    "bsclip_attn_bwd2_diag": (I, [P, I, P, I, P, P, I, P, I, I, I, F, P, I, P, P]),
 }
 DIAG_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libbsclip_hip_diag.so")
 

@@ -14,135 +14,22 @@
 // row-major image with ds_read_b64_tr_b16 -- no second LDS copy, no 2-byte scatter writes.
 // Backward runs two phases in one launch: query-owner waves produce delta = rowsum(P.dP) and dQ, then key-owner waves
 // produce dK/dV, so nothing is accumulated across waves (no atomics, bitwise reproducible).
-#include <math.h>
-
-#include <type_traits>
-
-#include "common.h"
+#include "attn_common.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 zero16() {
-    f32x16 z;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.f;
-    return z;
-}
-// registers [8*s2, 8*s2+8) of an accumulator tile -> bf16x8 operand fragment (element j = register 8*s2 + j)
-__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
-    u32x4 u;
-    u[0] = pack_bf2(x[8 * s2 + 0], x[8 * s2 + 1]);
-    u[1] = pack_bf2(x[8 * s2 + 2], x[8 * s2 + 3]);
-    u[2] = pack_bf2(x[8 * s2 + 4], x[8 * s2 + 5]);
-    u[3] = pack_bf2(x[8 * s2 + 6], x[8 * s2 + 7]);
-    return __builtin_bit_cast(bf16x8, u);
-}
-
-constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-constexpr int ROWB = 128;  // bytes per row of a row-major [rows][64] bf16 tile
-constexpr int ATT_WAVES = 4;  // waves per workgroup; wave w owns 32-row blocks w, w+4, ...
-
-// Row-major tile, 16-B chunk index XOR-swizzled with (row>>1)&7: conflict-free ds_read_b128 for the 32x32x16 A operand.
-__device__ __forceinline__ int rm_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-// Stage a [S][64] bf16 matrix (row stride ld elements) into a row-major, XOR-swizzled LDS tile of SP rows with LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, every piece in flight at once; the register-staged version issued its
-// 7 loads per thread one HBM round trip after the other: 11 us per K+V staging, a fifth of the backward kernel).
-// One wave-instruction fills 1 KiB = 8 rows; the swizzle is applied on the source side (LDS destination is lane-linear).
-// Rows >= S repeat row S-1: padded keys / queries always carry probability 0, so their content only has to be finite.
-// The caller waits (vmcnt(0)) and synchronises.
-template <int SP>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int S, char* dst_rm, int wave,
-                                           int lane) {
-    const int r8 = lane >> 3, pc = lane & 7;
-#pragma unroll
-    for (int c = 0; c < (SP / 8 + ATT_WAVES - 1) / ATT_WAVES; ++c) {
-        const int chunk = wave + ATT_WAVES * c;
-        if (chunk < SP / 8) {
-            const int row = 8 * chunk + r8;
-            const int lc = pc ^ ((row >> 1) & 7);
-            glds16(src + (size_t)min(row, S - 1) * ld + lc * 8, dst_rm + chunk * 1024);
-        }
-    }
-}
-__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// A-operand fragment of a row-major tile: rows r0 + (lane&31), k = 16*ks + 8*(lane>>5) + j
-__device__ __forceinline__ bf16x8 frag_rm(const char* tile, int r0, int ks, int lane) {
-    return *reinterpret_cast<const bf16x8*>(tile + rm_off(r0 + (lane & 31), 2 * ks + (lane >> 5)));
-}
-// TRANSPOSED A-operand fragment of the same row-major tile, for the accumulator-as-B product: MFMA row = tile COLUMN
-// d0 + (lane&31); element j is tile ROW c0 + 8*(j>>2) + 4*(lane>>5) + (j&3) (the k order of pack8()).
-// ds_read_b64_tr_b16 (verified on hardware by tools/probe/tr_probe.py): within each 16-lane group, lane 4q+p supplies
-// the address of row q / columns 4p..4p+3 of a 4x16 block and lane i receives column i of the 4 rows.  Group
-// gi = lane>>4 serves columns d0 + 16*(gi&1) + [0,16) and rows c0 + 4*(gi>>1) + [0,4)  (gi>>1 == lane>>5).
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int d0, int c0, int lane) {
-    const int gi = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    const int row = c0 + 4 * (gi >> 1) + q;
-    const int col = d0 + 16 * (gi & 1) + 4 * pp;  // 4 consecutive bf16 = 8 B inside one 16-B chunk
-    const char* p0 = tile + rm_off(row, col >> 3) + (col & 7) * 2;
-    const char* p1 = tile + rm_off(row + 8, col >> 3) + (col & 7) * 2;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-// B-operand fragment straight from global: row (clamped) of a [S][64] matrix, k = 16*ks + 8*(lane>>5) + j
-__device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, int ld, int row, int ks, int lane) {
-    return *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + ks * 16 + 8 * (lane >> 5));
-}
-// accumulator row index of register r for lane half h (C/D map of the 32x32 MFMA)
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// store a [64 (d) x 32 (token on lane)] result held as 2 accumulator tiles into out[token][col0 + d]
-__device__ __forceinline__ void store_dt(const f32x16 (&acc)[2], float mul, bf16_t* out_row, int lane) {
-    const int h = lane >> 5;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 o;
-            o.x = pack_bf2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
-            o.y = pack_bf2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
-            *reinterpret_cast<uint2*>(out_row + 32 * dt + 8 * g + 4 * h) = o;
-        }
-}
-
-// keep-factors (0 or 1/(1-p)) of the 4 consecutive keys idx .. idx+3 of one query row (idx % 4 == 0): two hashes
-__device__ __forceinline__ f32x4 keep4(const DropCfg& d, unsigned idx) {
-    const unsigned b0 = drop_pair_bits(d, idx), b1 = drop_pair_bits(d, idx + 2);
-    f32x4 k;
-    k[0] = (b0 & 0xffffU) >= d.thr16 ? d.scale : 0.f;
-    k[1] = (b0 >> 16) >= d.thr16 ? d.scale : 0.f;
-    k[2] = (b1 & 0xffffU) >= d.thr16 ? d.scale : 0.f;
-    k[3] = (b1 >> 16) >= d.thr16 ? d.scale : 0.f;
-    return k;
-}
-// Dropout element index of P[q, key] for head-instance bh: ((bh * S + q) * SP + key), SP = padded length (multiple of
-// 32), so a lane's 4 consecutive keys share two hash pairs.
-
-// TAIL = number of valid rows of the LAST 32-row key / query tile (S - 32 (NB - 1)), as a template parameter for the production
-// sequence lengths (197 and 133 both leave 5) and 32 ("treat the tile as full") for every other S.  An accumulator register r of
-// a 32x32 tile holds row (r & 3) + 8 (r >> 2) + 4 h: the 4-register group g = r >> 2 covers rows [8g, 8g + 8), so in the last
-// tile only the first ceil(TAIL / 8) groups can hold a non-zero probability and only the first ceil(TAIL / 16) 16-deep k-steps
-// of a product over that tile's rows contribute.  Skipping the rest is decided at compile time (the tile loops are unrolled) --
-// round 2's attempt with wave-uniform RUNTIME branches cost the schedule more than it saved.  S = 197 pads to 224 rows (29 %
-// more tile pairs than needed), S = 133 to 160 (45 %): this removes the VALU share and a quarter of the MFMAs of that padding.
-template <int TAIL> constexpr int tail_groups() { return TAIL >= 32 ? 4 : (TAIL + 7) / 8; }
-template <int TAIL> constexpr int tail_ksteps() { return TAIL > 16 ? 2 : 1; }
-
-template <int NB, bool DROP, int TAIL = 32>
+// V2 (the forward half of attn_sweep.hip's backward): instead of the log-sum-exp the kernel leaves, per query row, what lets
+// the backward take delta = rowsum(P dP) from the forward's OUTPUT without losing the softmax-backward cancellation:
+//   stats[row] = (nm2, inv, rZ, 0):  e_k = exp2(s_k * scale2 + nm2), inv = 1 / sum_k e_k, rZ = sum_k e_k / Z' with
+//   Z' = sum over kept keys of pd_k / keep_scale + sum over dropped keys of e_k,  pd_k = bf16(e_k * keep_k) -- the operand the
+//   P.V product really used -- so that sum_k dS_k = 0 holds to f32 rounding for dS_k = inv pd_k (dP_k - delta / keep_scale),
+//   delta = (dO . O) rZ;  and O itself to 16 mantissa bits: ctx = bf16(O), ctx_lo = bf16(O - ctx).
+template <int NB, bool DROP, int TAIL = 32, bool V2 = false>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S,
                                                                    int heads, const float* __restrict__ key_bias,
                                                                    float scale, bf16_t* __restrict__ ctx, int ld_ctx,
-                                                                   float* __restrict__ lse, DropCfg drop, int nqb) {
+                                                                   float* __restrict__ lse, DropCfg drop, int nqb,
+                                                                   bf16_t* __restrict__ ctx_lo = nullptr) {
     constexpr int SP = NB * 32;
     BSCLIP_DROP_RESOLVE(drop);
     __shared__ __attribute__((aligned(16))) char smem[2 * SP * ROWB + SP * 4];
@@ -217,6 +104,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
             }
         }
         sum += __shfl_xor(sum, 32, 64);
+        float sumx = 0.f, zacc = 0.f;   // V2: sum of e_k * keep_k before rounding, sum of the rounded operand pd_k
         if constexpr (DROP) {  // HF: dropout on the normalised probabilities (the row sum above is taken before it)
             const unsigned base = ((unsigned)(b * heads + hd) * S + (unsigned)qrow) * SP + 4 * h;
 #pragma unroll
@@ -226,7 +114,10 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
                     if (g >= (kt == NB - 1 ? tail_groups<TAIL>() : 4)) continue;
                     const f32x4 k4 = keep4(drop, base + 32 * kt + 8 * g);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) p[kt][4 * g + i] *= k4[i];
+                    for (int i = 0; i < 4; ++i) {
+                        p[kt][4 * g + i] *= k4[i];
+                        if constexpr (V2) sumx += p[kt][4 * g + i];
+                    }
                 }
         }
 
@@ -238,12 +129,27 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
             for (int s2 = 0; s2 < 2; ++s2) {
                 if (s2 >= (kt == NB - 1 ? tail_ksteps<TAIL>() : 2)) continue;   // keys past the sequence carry probability 0
                 const bf16x8 pb = pack8(p[kt], s2);
+                if constexpr (V2) {
+                    const u32x4 pw = __builtin_bit_cast(u32x4, pb);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) zacc = bf_pair_sum(pw[i], zacc);
+                }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_tr(sV, 32 * dt, 32 * kt + 16 * s2, lane), pb, o[dt]);
             }
 
         const int q = q0 + (lane & 31);
-        if (q < S) {
+        if constexpr (V2) {
+            zacc += __shfl_xor(zacc, 32, 64);
+            if constexpr (DROP) sumx += __shfl_xor(sumx, 32, 64);
+            const float inv = 1.0f / sum;
+            const float zp = DROP ? sum + (zacc - sumx) / drop.scale : zacc;
+            if (q < S) {
+                store_dt_hilo(o, inv, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, ctx_lo + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
+                if (h == 0)
+                    *reinterpret_cast<f32x4*>(lse + (((size_t)b * heads + hd) * S + q) * 4) = f32x4{nm2, inv, sum / zp, 0.f};
+            }
+        } else if (q < S) {
             store_dt(o, 1.0f / sum, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
             if (h == 0) lse[((size_t)b * heads + hd) * S + q] = (__log2f(sum) - nm2) * LN2;  // natural-log LSE
         }
@@ -531,6 +437,47 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
         switch ((S + 31) / 32) {
             ATTN_FWD_CASE(1) ATTN_FWD_CASE(2) ATTN_FWD_CASE(3) ATTN_FWD_CASE(4) ATTN_FWD_CASE(5) ATTN_FWD_CASE(6)
             ATTN_FWD_CASE(7)
+        }
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+#define ATTN_FWD2_LAUNCH(NBV, DR, TL)                                                                           \
+    hipLaunchKernelGGL((attn_fwd_kernel<NBV, DR, TL, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
+                       static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale, static_cast<bf16_t*>(ctx), ld_ctx, \
+                       stats, drop, nqb, static_cast<bf16_t*>(ctx_lo))
+#define ATTN_FWD2_CASE(NBV)                                                                                     \
+    case NBV:                                                                                                   \
+        if (drop.thr16) ATTN_FWD2_LAUNCH(NBV, true, 32);                                                        \
+        else ATTN_FWD2_LAUNCH(NBV, false, 32);                                                                  \
+        break;
+
+// Forward for the key-owner-sweep backward (bsclip_attn_bwd2): same attention, but instead of the log-sum-exp it leaves
+// stats[B, heads, S, 4] = (nm2, inv, rZ, 0) and the output to 16 mantissa bits (ctx = bf16(O), ctx_lo = bf16(O - ctx), both
+// with row stride ld_ctx) -- see attn_fwd_kernel's V2 note.
+extern "C" int bsclip_attn_fwd2(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale,
+                                void* ctx, void* ctx_lo, int ld_ctx, float* stats, float dropout_p, uint32_t dropout_seed,
+                                void* stream) {
+    BSCLIP_REQUIRE(qkv && ctx && ctx_lo && stats, "bsclip_attn_fwd2: null pointer");
+    BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_fwd2: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
+    BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_ctx >= heads * 64 && ld_ctx % 4 == 0,
+                   "bsclip_attn_fwd2: ld_qkv=%d ld_ctx=%d", ld_qkv, ld_ctx);
+    BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_fwd2: dropout_p=%f", dropout_p);
+    BSCLIP_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "bsclip_attn_fwd2: stats must be 16-byte aligned");
+    const int nqb = (S + 31) / 32;
+    const DropCfg drop = make_drop(dropout_p, dropout_seed);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (S == 197) {
+        if (drop.thr16) ATTN_FWD2_LAUNCH(7, true, 5);
+        else ATTN_FWD2_LAUNCH(7, false, 5);
+    } else if (S == 133) {
+        if (drop.thr16) ATTN_FWD2_LAUNCH(5, true, 5);
+        else ATTN_FWD2_LAUNCH(5, false, 5);
+    } else {
+        switch ((S + 31) / 32) {
+            ATTN_FWD2_CASE(1) ATTN_FWD2_CASE(2) ATTN_FWD2_CASE(3) ATTN_FWD2_CASE(4) ATTN_FWD2_CASE(5) ATTN_FWD2_CASE(6)
+            ATTN_FWD2_CASE(7)
         }
     }
     BSCLIP_LAUNCH_CHECK();

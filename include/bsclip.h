@@ -143,6 +143,11 @@ int bsclip_gemm_pers_diag(const void* A, int lda, const void* B, int ldb, void* 
  * diag[B*heads*4*8]; tools/attn_phases.py */
 int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
                          int heads, float scale, void* dqkv, int ld_dqkv, unsigned long long* diag, void* stream);
+/* the key-owner-sweep backward (bsclip_attn_bwd2; S = 197 or 133, no mask, no dropout) with per-wave section stamps,
+ * diag[B*heads*(NB+1)*8], NB = ceil(S / 32) key-owner waves + the dQ wave; tools/attn_sweep_phases.py */
+int bsclip_attn_bwd2_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo,
+                          int ld_ctx, const float* stats, int B, int S, int heads, float scale, void* dqkv, int ld_dqkv,
+                          unsigned long long* diag, void* stream);
 #endif
 
 /* ---- LayerNorm (timm norm1/norm2/norm eps 1e-6; HF BertLayerNorm eps 1e-12) ------------------------------------
@@ -193,6 +198,19 @@ int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const 
 int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
                     int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
                     float dropout_p, uint32_t dropout_seed, void* stream);
+
+/* Round 4: the same attention with a backward that forms every product once (csrc/attn_sweep.hip: key-owner waves sweep the query
+ * blocks, a dQ wave follows; 20 MFMAs + 16 exp per 32x32 tile pair instead of 32 + 32).  delta = rowsum(P . dP) is taken from
+ * the forward's OUTPUT, which therefore leaves O to 16 mantissa bits -- ctx = bf16(O) (the out-projection's operand, as before)
+ * and ctx_lo = bf16(O - ctx), same layout -- and per query row stats[B, heads, S, 4] f32 = (nm2, inv, rZ, 0): e_k = exp2(s_k
+ * scale log2e + nm2), inv = 1 / sum_k e_k, rZ = sum_k e_k / Z' where Z' sums the bf16-ROUNDED operands of the P.V product
+ * (dropped keys: their e_k), so that sum_k dS_k = 0 holds to f32 rounding with delta = (dctx . O) rZ.  stats 16-byte aligned.
+ * No q_rows form (every query row carries a gradient); argument meaning otherwise as bsclip_attn_fwd / bsclip_attn_bwd. */
+int bsclip_attn_fwd2(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, void* ctx,
+                     void* ctx_lo, int ld_ctx, float* stats, float dropout_p, uint32_t dropout_seed, void* stream);
+int bsclip_attn_bwd2(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo, int ld_ctx,
+                     const float* stats, int B, int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
+                     float dropout_p, uint32_t dropout_seed, void* stream);
 
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column

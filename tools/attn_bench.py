@@ -1,4 +1,4 @@
-"""Times bsclip_attn_fwd / bsclip_attn_bwd at the step's shapes (B=256: ViT S=197 no dropout, DNA S=133 dropout 0.1)."""
+"""Times bsclip_attn_fwd / bsclip_attn_bwd (two-phase backward) and bsclip_attn_fwd2 / bsclip_attn_bwd2 (key-owner sweep) at the step's shapes (B=256: ViT S=197 no dropout, DNA S=133 dropout 0.1)."""
 import os
 import sys
 
@@ -17,9 +17,13 @@ for name, S, p in (("vit", 197, 0.0), ("dna", 133, 0.1), ("dna-nodrop", 133, 0.0
     dqkv = torch.empty(B * S, 3 * H, device="cuda", dtype=torch.bfloat16)
     lse = torch.empty(B, heads, S, device="cuda")
     drop = (p, 1234) if p else None
+    ctx_lo = torch.empty_like(ctx)
+    stats = torch.empty(B, heads, S, 4, device="cuda")
     res = {}
     for what, fn in (("fwd", lambda: ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse, dropout=drop)),
-                     ("bwd", lambda: ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv, dropout=drop))):
+                     ("bwd", lambda: ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv, dropout=drop)),
+                     ("fwd2", lambda: ops.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats, dropout=drop)),
+                     ("bwd2", lambda: ops.attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, 0.125, dqkv, dropout=drop))):
         fn()
         best = 1e9
         for _ in range(3):
@@ -33,4 +37,5 @@ for name, S, p in (("vit", 197, 0.0), ("dna", 133, 0.1), ("dna-nodrop", 133, 0.0
         res[what] = best
     fl = 4.0 * B * heads * S * S * 64
     print(f"{name:11s} S={S} p={p}: fwd {res['fwd']*1e3:7.1f} us ({fl/res['fwd']/1e9:6.1f} TF)   "
-          f"bwd {res['bwd']*1e3:7.1f} us ({2.5*fl/res['bwd']/1e9:6.1f} TF at 5 products)", flush=True)
+          f"bwd {res['bwd']*1e3:7.1f} us ({2.5*fl/res['bwd']/1e9:6.1f} TF at 5 products)   |  sweep pair: fwd2 {res['fwd2']*1e3:7.1f} us   "
+          f"bwd2 {res['bwd2']*1e3:7.1f} us ({2.5*fl/res['bwd2']/1e9:6.1f} TF)", flush=True)

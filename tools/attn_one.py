@@ -17,7 +17,11 @@ ctx = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
 dqkv = torch.empty(B * S, 3 * H, device="cuda", dtype=torch.bfloat16)
 lse = torch.empty(B, heads, S, device="cuda")
 drop = (p, 1234) if p else None
+ctx_lo = torch.empty_like(ctx)
+stats = torch.empty(B, heads, S, 4, device="cuda")
 for _ in range(3):
     ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse, dropout=drop)
     ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv, dropout=drop)
+    ops.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats, dropout=drop)                 # the key-owner-sweep pair
+    ops.attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, 0.125, dqkv, dropout=drop)
 torch.cuda.synchronize()
