@@ -4,14 +4,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]; configs[2] adds the text tower with --text): LoRA ViT-B/16 + LoRA BarcodeBERT,
-bf16 MFMA GEMMs with f32 accumulation, local batch 256 per GPU, synthetic 224x224 images + 133-token barcodes
-resident in HBM, InfoNCE over the (all-gathered, for N > 1) batch, backward, gradient all-reduce, fused AdamW.
+Workload: what BASELINE.json's metric names -- Image + DNA + Text (configs[2]'s per-GPU shape: LoRA ViT-B/16 + LoRA BarcodeBERT +
+LoRA BERT-small), bf16 MFMA GEMMs with f32 accumulation, local batch 256 per GPU, synthetic 224x224 images + 133-token barcodes
++ 20-token texts resident in HBM, InfoNCE over the (all-gathered, for N > 1) batch, backward, gradient all-reduce, fused AdamW.
+--no-text runs configs[1] (Image + DNA, the configuration north_star's 40 % target is stated on); the default single-GPU line
+carries that configuration (and configs[4]'s fp8 shape) as `extra`, measured in the same run on the same number of steps.
 One "step" = zero_grad + forward + loss + backward + (all-reduce) + optimizer step; nothing is skipped or cached.
 
 One JSON line is printed by rank 0 (contract in the task statement).  Besides the required keys:
-  roofline      -- the dominant kernel (the fc1+GELU bf16 MFMA GEMM instantiation, 25 launches per step) timed live with HIP
+  roofline      -- the LOWEST-fraction GEMM family of the step (fc1 + bias + GELU, 24 launches per step) timed live with HIP
                    events on the launch stream, in the same launch mix as the step.
+  roofline_families -- every kernel family that takes more than 2 % of the step (the GEMM families by epilogue, attention forward /
+                   backward), each timed live in its own launch mix: TFLOP/s and fraction of the dense bf16 MFMA peak.
   step_roofline -- algorithmic FLOPs of the whole step (118.3 GFLOP per I+D pair) / measured step time
                    against the dense bf16 MFMA peak.
   cpu_baseline  -- the CPU oracle (a port; the reference's Python cannot travel to the GPU box) timed on the host
@@ -135,8 +139,105 @@ def time_dominant_gemm(B, device, reps=4):
                             "%.1f MB (A + W bf16, gelu bf16, gelu' 8-bit)" % (sum(((M * K + N * K) * 2.0 + 3.0 * M * N) * c for M, N, K, c in shapes)
                                                                              / launches / 1e6),
             "kernel": "gemm_nt_pers_kernel<2 = EPI_GELU_BF16, true, false, true> (fc1 + bias + GELU; 24 launches per step)",
+            "kernel_role": "the LOWEST-fraction GEMM family of the step (its two-output GELU epilogue); the largest family by time is the "
+                           "bias-free dX GEMMs -- every family: roofline_families",
             "launch_mix_MNK_count": [list(x) for x in shapes],
             "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "avg_launch_ms": round(mean_ms, 4)}
+
+
+def time_families(B, device, reps=3):
+    """Live HIP-event timing of every kernel family above 2 % of the step, each in the launch mix the I+D step has at local batch B
+    (ViT rows B*197, BarcodeBERT rows B*133; the text tower's launches are latency-sized and left out): algorithmic FLOPs per launch
+    / mean launch time against the dense bf16 MFMA peak.  Attention: 4 S^2 64 FLOP per head forward, 2.5 x that backward (5 products)."""
+    from bioscanclip.hip import ops
+    from bioscanclip.hip.lib import EPI_BF16, EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_BF16
+    Mv, Md = B * 197, B * 133
+
+    def gemm_family(shapes, epi, bias):
+        bufs = []
+        for M, N, K, _ in shapes:
+            a = torch.randn(M, K, device=device).bfloat16()
+            w = (torch.randn(N, K, device=device) * 0.03).bfloat16()
+            kw = {"bias": torch.randn(N, device=device)} if bias else {}
+            out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+            if epi == EPI_RESID_BF16:
+                kw["resid"] = torch.randn(M, N, device=device).bfloat16()
+            if epi in (EPI_GELU_BF16, EPI_DGELU_BF16):
+                kw["aux"] = torch.randint(0, 256, (M, N), device=device, dtype=torch.uint8)
+            bufs.append((a, w, out, kw))
+
+        def mix():
+            for (M, N, K, cnt), (a, w, out, kw) in zip(shapes, bufs):
+                for _ in range(cnt):
+                    ops.gemm(a, w, out, epi, **kw)
+        n = sum(c for *_, c in shapes)
+        return mix, n, sum(2.0 * M * N * K * c for M, N, K, c in shapes) / n
+
+    def attn_family(bwd):
+        bufs = []
+        for S, p, cnt in ((197, 0.0, 11), (133, 0.1, 12)):   # the 12th ViT block runs the token-0 form: a different, cheap launch
+            qkv = (torch.randn(B * S, 2304, device=device) * 0.5).bfloat16()
+            ctx = torch.empty(B * S, 768, device=device, dtype=torch.bfloat16)
+            lse = torch.empty(B, 12, S, device=device)
+            dctx = torch.randn(B * S, 768, device=device).bfloat16()
+            dqkv = torch.empty(B * S, 2304, device=device, dtype=torch.bfloat16)
+            drop = (p, 1234) if p else None
+            ops.attn_fwd(qkv, B, S, 12, 0.125, ctx, lse, dropout=drop)
+            bufs.append((S, qkv, ctx, lse, dctx, dqkv, drop, cnt))
+
+        def mix():
+            for S, qkv, ctx, lse, dctx, dqkv, drop, cnt in bufs:
+                for _ in range(cnt):
+                    if bwd:
+                        ops.attn_bwd(qkv, dctx, lse, B, S, 12, 0.125, dqkv, dropout=drop)
+                    else:
+                        ops.attn_fwd(qkv, B, S, 12, 0.125, ctx, lse, dropout=drop)
+        n = sum(b[-1] for b in bufs)
+        fl = sum(4.0 * B * 12 * b[0] * b[0] * 64 * b[-1] for b in bufs) / n * (2.5 if bwd else 1.0)
+        return mix, n, fl
+
+    fams = [
+        ("qkv + bias (K = 768 + 64: LoRA rides in K)", *gemm_family([(Mv, 2304, 832, 12), (Md, 2304, 832, 12)], EPI_BF16, True)),
+        ("fc1 + bias + GELU (+ 8-bit gelu')", *gemm_family([(Mv, 3072, 768, 11), (Md, 3072, 768, 12), (Md, 768, 768, 1)], EPI_GELU_BF16, True)),
+        ("out-projection / fc2 + bias + residual", *gemm_family([(Mv, 768, 768, 11), (Mv, 768, 3072, 11), (Md, 768, 768, 12), (Md, 768, 3072, 12)],
+                                                               EPI_RESID_BF16, True)),
+        ("dfc2 x gelu' (dX of fc2)", *gemm_family([(Mv, 3072, 768, 11), (Md, 3072, 768, 12)], EPI_DGELU_BF16, False)),
+        ("bias-free dX (dfc1, dproj, dqkv)", *gemm_family([(Mv, 768, 3072, 11), (Mv, 768, 768, 11), (Mv, 768, 2304, 11), (Md, 768, 3072, 12),
+                                                         (Md, 768, 768, 12), (Md, 768, 2304, 12)], EPI_BF16, False)),
+        ("attention forward (S = 197; S = 133 with dropout)", *attn_family(False)),
+        ("attention backward", *attn_family(True)),
+    ]
+    out = []
+    for name, mix, n, flops in fams:
+        mix()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            mix()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / (reps * n) * 1e3
+        tf = flops / (us * 1e-6) / 1e12
+        out.append({"family": name, "launches_per_step": n, "gflop_per_launch": round(flops / 1e9, 2), "avg_launch_us": round(us, 1),
+                    "ms_per_step": round(us * n / 1e3, 3), "tflops": round(tf, 1), "frac_of_bf16_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4)})
+        torch.cuda.empty_cache()
+    return out
+
+
+def thread_cpu_seconds():
+    """{tid: (name, user + system CPU seconds)} of every thread of this process (/proc/self/task): who burns the host."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            with open(f"/proc/self/task/{tid}/stat") as f:
+                raw = f.read()
+            name = raw[raw.index("(") + 1:raw.rindex(")")]
+            fields = raw[raw.rindex(")") + 2:].split()
+            out[int(tid)] = (name, (int(fields[11]) + int(fields[12])) / tick)
+    except Exception:   # noqa: BLE001
+        pass
+    return out
 
 
 def usable_cores():
@@ -203,13 +304,15 @@ def cpu_baseline(seconds_budget=20.0):
                       f"{t_total:.1f} s, torch CPU threads={cores}, {cpu}"}
 
 
-def side_measurement(device, with_text, fp8, B, steps=8):
+def side_measurement(device, with_text, fp8, B, steps=20, parity=False):
     """ms/step of another BASELINE configuration's per-GPU shape on this one GPU (same step, same launch path: captured
     hipGraph), reported as extra keys of the line so that they are driver-run numbers too: configs[2]'s I+D+T at local batch 256
     and configs[4]'s fp8 trunks at its own local batch 512."""
     from bioscanclip.hip.graph import GraphedStep
     from bioscanclip.hip.optim import FusedAdamW
     from bioscanclip.model.loss_func import ContrastiveLoss
+    from bioscanclip.hip import engine as _engine
+    prev = _engine.set_parity_mode(True) if parity else None   # f32 residual / residual-gradient streams (BSCLIP_PARITY=1)
     model = build_model(with_text, device)
     if fp8:
         from bioscanclip.hip.engine import set_precision
@@ -227,10 +330,16 @@ def side_measurement(device, with_text, fp8, B, steps=8):
         loss = g(image, dna, text, label)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    per = GFLOP_PER_TRIPLE_IDT if with_text else GFLOP_PER_PAIR_ID
+    nmod = 3 if with_text else 2
+    tflop = (per * B + (nmod * (nmod - 1) // 2) * 3 * 2.0 * B * B * 768 / 1e9) / 1e3
     out = {"ms_per_step": round(ms, 3), "paired_samples_per_s": round(B / (ms * 1e-3), 1), "local_batch": B, "steps": steps,
-           "final_loss": round(loss.item(), 5)}
+           "final_loss": round(loss.item(), 5),
+           "step_roofline_frac": round(tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4), "algorithmic_tflop_per_gpu_step": round(tflop, 3)}
     del g, opt, model
     torch.cuda.empty_cache()
+    if prev is not None:
+        _engine.GRAD_STREAM_BF16, _engine.RESID_STREAM_BF16 = prev
     return out
 
 
@@ -246,15 +355,17 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="local (per-GPU) batch")
-    ap.add_argument("--text", action="store_true", help="add the BERT-small text tower (BASELINE configs[2])")
+    ap.add_argument("--text", action="store_true", help="(default) Image + DNA + Text: what BASELINE.json's metric names (configs[2]'s per-GPU shape)")
+    ap.add_argument("--no-text", action="store_true", help="Image + DNA only (BASELINE configs[1], the shape of north_star's 40 %% target)")
     ap.add_argument("--fp8", action="store_true", help="fp8 e4m3 frozen-trunk GEMMs for ViT + BarcodeBERT (BASELINE configs[4])")
     ap.add_argument("--full-ft", action="store_true", help="disable_lora: true -- train every parameter (SURVEY 8f-4; not a BASELINE config)")
     ap.add_argument("--lr", type=float, default=None, help="AdamW lr (default 1e-3; 1e-6 with --full-ft, the reference's full fine-tuning base lr: random-init towers on noise images collapse under larger steps, tools/ft_dynamics_probe.py)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (I+D+T at B=256, fp8 trunks at B=512) the "
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (configs[1] I+D at B=256, fp8 trunks at B=512) the "
                     "default single-GPU line carries as extra keys")
     a = ap.parse_args()
+    a.text = not a.no_text
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -340,11 +451,24 @@ def main():
     for _ in range(a.warmup):
         loss = step()
 
+    def park(ev, nap=2e-4):
+        """Wait for a HIP event WITHOUT burning a core.  Every synchronising call of this runtime spins -- torch.cuda.synchronize(),
+        and (measured, round 4) hipEventSynchronize on an event created with hipEventBlockingSync too: the enqueue thread showed
+        100 % CPU either way, and a second runtime thread beside it.  Round 3's 38.8 ms of host CPU per 38.1 ms step was that spin;
+        the enqueue of a replayed step itself costs well under a millisecond.  So: poll hipEventQuery between short sleeps."""
+        while not ev.query():
+            time.sleep(nap)
+
+    def wait_idle():
+        ev = torch.cuda.Event()
+        ev.record()
+        park(ev)
+
     def fence():
-        torch.cuda.synchronize()
+        wait_idle()
         if world > 1 or force_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        wait_idle()
 
     # the engine clock the chip actually runs at over the timed steps (per-XCD s_memtime against the 100 MHz real-time counter):
     # sampled just outside the timed region, so the K steps are timed exactly as before
@@ -352,14 +476,29 @@ def main():
     clk0, clk1 = torch.zeros(32, dtype=torch.int64, device=device), torch.zeros(32, dtype=torch.int64, device=device)
     _ops.clock_probe(clk0)
     fence()
+    # The host stays at most two steps ahead of the device (as train_epoch does by reading the loss one step late): with an
+    # unbounded run-ahead the K launches are enqueued in microseconds and the thread then sits in the runtime's queue back-pressure
+    # -- a spin.  The throttle polls an event between sleeps: the GPU never idles (a step is always queued behind the running one).
+    ring = [torch.cuda.Event() for _ in range(3)]
+    th0 = thread_cpu_seconds()
     t0 = time.perf_counter()
     c0 = time.process_time()
-    for _ in range(a.steps):
+    tc0 = time.thread_time()
+    for i in range(a.steps):
+        if i >= 2:
+            park(ring[(i - 2) % 3], nap=1e-3)
         loss = step()
-    host_cpu_s = time.process_time() - c0   # CPU time spent enqueueing (all threads of this process)
+        ring[i % 3].record()
     t_enq = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - c0   # CPU time of every thread of this process over the timed region (enqueue + waits)
+    main_cpu_s = time.thread_time() - tc0   # ... and of this (the enqueueing) thread alone
+    th1 = thread_cpu_seconds()
+    busiest = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], th1[t][0], t) for t in th1), reverse=True)[:4]
+    if rank == 0:
+        print("[bench] busiest threads over the timed steps (CPU s, name, tid): " +
+              ", ".join(f"{d:.2f} {n} {t}{' (enqueue thread)' if t == os.getpid() else ''}" for d, n, t in busiest), file=sys.stderr, flush=True)
     _ops.clock_probe(clk1)
     torch.cuda.synchronize()
     clock_ghz = _ops.engine_clock_ghz(clk0, clk1)
@@ -417,15 +556,31 @@ def main():
                               "frac_of_peak_at_measured_clock": None if clock_ghz is None else
                               round(achieved / (PEAK_BF16_TFLOPS * clock_ghz / 2.4), 4)},
         }
+        out["host"] = {"cpu_ms_per_step_all_threads": round(host_cpu_s / a.steps * 1e3, 3),
+                       "cpu_ms_per_step_enqueue_thread": round(main_cpu_s / a.steps * 1e3, 3),
+                       "enqueue_wall_ms_per_step": round(t_enq / a.steps * 1e3, 3),
+                       "note": "the enqueueing thread sleeps between hipEventQuery polls (at most two steps queued ahead); what is left is "
+                               "the HIP / ROCr runtime's own helper threads"}
         out["roofline"] = time_dominant_gemm(B, device)
-        if world == 1 and not force_dist and not (a.no_extras or a.text or a.fp8 or a.full_ft or nodrop or B != 256):
+        if world == 1 and not (a.fp8 or a.full_ft or a.no_extras):
+            try:
+                out["roofline_families"] = time_families(B, device)
+            except Exception as exc:   # noqa: BLE001
+                out["roofline_families"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and not force_dist and not (a.no_extras or a.no_text or a.fp8 or a.full_ft or nodrop or B != 256):
             # the other single-GPU-measurable BASELINE shapes, so that they are driver-run numbers
             graphed = None
             del opt, model
             torch.cuda.empty_cache()
             try:
-                out["extra"] = {"configs[2] per-GPU shape (I+D+T, bf16, local batch 256)": side_measurement(device, True, False, 256),
-                                "configs[4] per-GPU shape (fp8 trunks, I+D, local batch 512)": side_measurement(device, False, True, 512)}
+                out["extra"] = {"configs[1] (I+D, bf16, local batch 256: the shape of north_star's 40 % target)":
+                                side_measurement(device, False, False, 256, steps=a.steps),
+                                "configs[4] per-GPU shape (fp8 trunks, I+D, local batch 512)": side_measurement(device, False, True, 512, steps=a.steps)}
+                pm = side_measurement(device, True, False, 256, steps=a.steps, parity=True)
+                out["parity_mode_ms_per_step"] = pm["ms_per_step"]
+                out["parity_mode"] = ("BSCLIP_PARITY=1: f32 residual and residual-gradient streams + split-bf16 patch embedding, same workload "
+                                      "as the headline (what the default's bf16 streams buy: headline ms_per_step vs this); trunk GEMM and "
+                                      "attention operands stay bf16 in both (DESIGN.md 4)")
             except Exception as exc:   # noqa: BLE001 - the headline line must not die with a side measurement
                 out["extra"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(f"[bench] gpu: {ms:.2f} ms/step, {out['value']} pairs/s; host enqueue wall {t_enq / a.steps * 1e3:.2f} ms/step, "

@@ -14,6 +14,7 @@ more than one rank the step is a set of per-tower captured graphs (forward_k | l
 all-gather and all-reduce issued eagerly from that tower's stream between them (``GraphedDistStep``).
 """
 import os
+import time
 
 import torch
 
@@ -73,7 +74,16 @@ def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimize
     model.train()
     graphed = _graphed_step(model, optimizer, criterion, device)
     ring = torch.zeros(4, dtype=torch.float32, device=device) if graphed is not None else None
+    # one HIP event per ring slot: the host sleeps between hipEventQuery polls until the step it wants to read has finished.
+    # Every synchronising call of this runtime spin-waits (``.item()``, hipEventSynchronize -- blocking-sync events included:
+    # bench.py measured 100 % of a core either way): a core per rank burnt for the whole epoch, eight of them on an 8-GPU node.
+    done = [torch.cuda.Event() for _ in range(4)] if graphed is not None else None
     pending = None   # (step, lr) whose loss sits in ring[step % 4] and has not been read yet
+
+    def read(slot):
+        while not done[slot].query():
+            time.sleep(5e-4)
+        return ring[slot].item()
 
     def report(step, value, lr):
         if show:
@@ -87,11 +97,12 @@ def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimize
         if graphed is not None and graphed.accepts(image, dna, text, label):
             loss = graphed(image, dna, text, label)              # device scalar, overwritten by the next replay ...
             ring[step % 4].copy_(loss.detach())                  # ... so it is parked in this step's slot
+            done[step % 4].record()
             lr = optimizer.param_groups[0]["lr"]
             if scheduler is not None:
                 scheduler.step()
             if pending is not None:                              # read the PREVIOUS step's loss: the host stays one step ahead
-                value = ring[pending[0] % 4].item()
+                value = read(pending[0] % 4)
                 running += value
                 report(pending[0], value, pending[1])
             pending = (step, lr)
@@ -109,7 +120,7 @@ def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimize
         if scheduler is not None:
             scheduler.step()
         if pending is not None:
-            value = ring[pending[0] % 4].item()
+            value = read(pending[0] % 4)
             running += value
             report(pending[0], value, pending[1])
             pending = None
@@ -117,7 +128,7 @@ def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimize
         running += value
         report(step, value, lr)
     if pending is not None:
-        value = ring[pending[0] % 4].item()
+        value = read(pending[0] % 4)
         running += value
         report(pending[0], value, pending[1])
 

@@ -41,6 +41,28 @@ RESID_STREAM_BF16 = os.environ.get("BSCLIP_RESID_STREAM", "bf16").lower() != "f3
 PATCH_SPLIT = os.environ.get("BSCLIP_PATCH_SPLIT", "1") != "0"
 
 
+# BSCLIP_PARITY=1 / set_parity_mode(True): the most exact configuration this build has -- f32 residual stream, f32
+# residual-gradient stream, split-bf16 patch embedding -- at the price bench.py reports as `parity_mode_ms_per_step`.  It is NOT
+# north_star's 1e-3: every trunk GEMM and the attention products still take bf16 operands (DESIGN.md 4 prices the split-bf16
+# form of those: 3 x the MFMA work of the step and hi / lo outputs from every producer kernel -- not built).
+if os.environ.get("BSCLIP_PARITY", "0") == "1":
+    GRAD_STREAM_BF16 = RESID_STREAM_BF16 = False
+    PATCH_SPLIT = True
+
+
+def set_parity_mode(on, model=None):
+    """Switch the streams at run time (engines built afterwards pick it up; pass ``model`` to have its engines rebuilt at the next
+    forward).  Returns the previous (grad_stream_bf16, resid_stream_bf16) pair."""
+    global GRAD_STREAM_BF16, RESID_STREAM_BF16
+    prev = (GRAD_STREAM_BF16, RESID_STREAM_BF16)
+    GRAD_STREAM_BF16 = RESID_STREAM_BF16 = not on
+    if model is not None:
+        for m in model.modules():
+            if getattr(m, "_engine", None) is not None:
+                m._engine = None
+    return prev
+
+
 _WS_GEN = itertools.count(1)   # every workspace gets a unique, never reused number (hip/graph.py keys captured graphs on it)
 
 

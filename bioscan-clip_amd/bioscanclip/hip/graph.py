@@ -171,6 +171,8 @@ class GraphedDistStep(GraphedStep):
         self.towers = None
         self.gL = self.gC = None
 
+    _ORDER = {"text": 0, "dna": 1, "image": 2}    # issue order of the collectives: by the towers' duration, shortest first
+
     def n_graphs(self):
         return 0 if self.towers is None else sum((t.gF is not None) + (t.gB is not None) for t in self.towers) + 2
 
@@ -267,11 +269,15 @@ class GraphedDistStep(GraphedStep):
         label = self.static[3]
         main = torch.cuda.current_stream()
         works = [dist.all_gather_into_tensor(self.labels_full, label.contiguous(), group=self.group, async_op=True)]
-        for t in self.towers:
+        for t in self.towers:                   # longest tower first
             t.stream.wait_stream(main)
             with torch.cuda.stream(t.stream):
                 t.gF.replay()
-                # issued with the tower's stream current: the collective is ordered behind this tower only
+        # The process group runs its collectives on ONE stream, in issue order: a gather issued behind the image tower's would wait
+        # for the image tower (tools/dist_overlap_probe.py, round 4: the text tower's gather, ready at 3.8 ms, completed at 18.0).
+        # So they are issued shortest tower first -- each with its tower's stream current, i.e. ordered behind that tower only.
+        for t in sorted(self.towers, key=lambda t: self._ORDER[t.name]):
+            with torch.cuda.stream(t.stream):
                 works.append(dist.all_gather_into_tensor(t.full, t.emb.detach(), group=self.group, async_op=True))
         for w in works:
             w.wait()                            # RCCL: `main` waits for the collective's stream; gloo (tests): the host does
@@ -285,7 +291,9 @@ class GraphedDistStep(GraphedStep):
             t.stream.wait_stream(main)
             with torch.cuda.stream(t.stream):
                 t.gB.replay()
-                if t.flat is not None:
+        for t in sorted(self.towers, key=lambda t: self._ORDER[t.name]):    # shortest backward first, as above; same order on every rank
+            if t.gB is not None and t.flat is not None:
+                with torch.cuda.stream(t.stream):
                     t.work = dist.all_reduce(t.flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for t in self.towers:
             if t.work is not None:

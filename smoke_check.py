@@ -43,8 +43,9 @@ def run_smoke():
     q_dna = ((do.detach().cpu() - qd).norm() / qd.norm()).item()
     print(f"smoke: loss {loss.item():.6f} (oracle {ref_loss.item():.6f}), rel err vs f32 oracle: img {e_img:.2e} dna {e_dna:.2e} "
           f"loss {e_loss:.2e} params-after-step {e_par:.2e}; vs bf16-rounding-aware oracle: img {q_img:.2e} dna {q_dna:.2e}")
-    # 2x the values measured on MI355X in round 3 (1.07e-2, 5.8e-3, 8.1e-4, 9.5e-3; round 2: 1.6e-2, 4.4e-3, 5.7e-4, 1.1e-2): bf16
+    # 1.3x the values the driver's round-3 smoke measured on MI355X (1.05e-2, 5.42e-3, 1.36e-3, 8.93e-3; the step is bitwise
+    # reproducible, round 3 allowed 2x): bf16
     # operands and a bf16 residual stream against an all-f32 oracle on peaked attention; against the oracle that
-    # rounds at the same points the embeddings agree to a few 1e-3 (measured 6.8e-3 / 2.4e-3)
-    assert e_img < 2.2e-2 and e_dna < 1.2e-2 and e_loss < 1.7e-3 and e_par < 1.9e-2, "HIP step disagrees with the CPU oracle"
-    assert q_img < 1.4e-2 and q_dna < 5e-3, "HIP step disagrees with the bf16-rounding-aware oracle"
+    # rounds at the same points the embeddings agree to a few 1e-3 (measured 6.77e-3 / 2.54e-3)
+    assert e_img < 1.37e-2 and e_dna < 7.1e-3 and e_loss < 1.8e-3 and e_par < 1.17e-2, "HIP step disagrees with the CPU oracle"
+    assert q_img < 8.8e-3 and q_dna < 3.3e-3, "HIP step disagrees with the bf16-rounding-aware oracle"

@@ -8,7 +8,7 @@ error (scores are O(3-10)).  Three distances are measured per encoder (normwise 
   * HIP vs the f32 oracle / the reference's golden vectors: what north_star's "1e-3" is about.  A single bf16-operand GEMM
     is already at 2.4e-3..5.3e-3 (patch embed, tools/vit_bisect.py), 12 layers land at 1e-2..2e-2; the bf16-rounding-aware
     oracle sits at the SAME distance from f32 at every sub-layer, i.e. this is the price of the prescribed
-    operand dtype, not of the kernels.  Tolerances below are <= 2x the measured values.
+    operand dtype, not of the kernels.  Tolerances below are 1.3x the measured values (round 3: 2x).
   * HIP vs the oracle that rounds where the kernels round (emulate_bf16=True).
   * that oracle vs ITSELF with f64 instead of f32 accumulation (same rounding points, different last bits): the
     resolution of the emulation.  Values near a bf16 rounding boundary flip, the softmax amplifies the flips, and the two
@@ -28,12 +28,15 @@ from helpers import check_summary, load_golden, rel_err  # noqa: E402
 from oracle import refcpu, synth  # noqa: E402
 
 NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)  # parity = deterministic path
-# (embedding vs f32 oracle / golden, worst trainable-gradient tensor vs f32 oracle / golden): 2x the measured values
+# (embedding vs f32 oracle / golden, worst trainable-gradient tensor vs f32 oracle / golden)
 # (gpurun_out/parity.jsonl, copied into DESIGN.md 4)
 # round 3 (bf16 residual stream + split-bf16 patch embedding), measured: dna_L2 7.2e-3 / 2.4e-2, dna_L12 1.5e-2 / 6.1e-2,
 # txt_L4 4.5e-3 / 2.1e-2, vit_L2 9.1e-3 / 1.9e-2, vit_L12 1.7e-2 / 7.2e-2 (round 2: vit_L12 2.1e-2 / 9.3e-2, tolerance 4.3e-2 / 1.9e-1)
-TOL = {"dna_L2": (1.4e-2, 4.7e-2), "dna_L12": (3e-2, 1.2e-1), "txt_L4": (9e-3, 4.2e-2),
-       "vit_L2": (1.9e-2, 4e-2), "vit_L12": (3.4e-2, 1.45e-1)}
+# round 4: the kernels are bitwise reproducible, so a box-to-box band is not needed: tolerances are 1.3 x the measured values
+# (gpurun_out/parity.jsonl of the round-4 suite run: dna_L2 7.18e-3 / 2.27e-2, dna_L12 9.37e-3 / 6.55e-2, txt_L4 4.49e-3 / 2.21e-2,
+# vit_L2 9.44e-3 / 2.06e-2, vit_L12 1.70e-2 / 6.84e-2); round 3 allowed 2 x
+TOL = {"dna_L2": (9.4e-3, 3.0e-2), "dna_L12": (1.22e-2, 8.6e-2), "txt_L4": (5.9e-3, 2.9e-2),
+       "vit_L2": (1.23e-2, 2.7e-2), "vit_L12": (2.22e-2, 8.9e-2)}
 SELF_FACTOR = 1.5   # HIP-vs-emulating-oracle <= SELF_FACTOR x (emulating oracle f32-accumulate vs f64-accumulate)
 
 
@@ -143,6 +146,47 @@ def test_vit_encoder(depth):
     fn = lambda s, emulate=False, f64=False: refcpu.vit_encoder(s, image.double() if f64 else image, emulate_bf16=emulate)
     _compare_encoder(f"vit_L{depth}", m, "image_encoder.", sd, image.cuda(), fn, f"vit.cot.{depth}",
                      (f"vit.out.{depth}", load_golden("encoders")[f"vit_L{depth}"]))
+
+
+@pytest.mark.parametrize("which", ["vit", "dna"])
+def test_parity_mode_against_the_f32_oracle(which, monkeypatch):
+    """BSCLIP_PARITY=1 (hip/engine.py set_parity_mode): f32 residual and residual-gradient streams, gated at 1.3 x its own measured
+    distance to the f32 oracle at depth 12 (round 4: ViT 1.22e-2 / worst gradient 4.46e-2 -- closer than the default's 1.70e-2 /
+    6.84e-2; BarcodeBERT 1.25e-2 / 3.89e-2 -- the embedding is NOT closer than the default's 0.94e-2, the gradients are: at this
+    level the distance is the bf16 GEMM / attention operands', which both configurations share, not the streams').
+    bench.py prices the mode (`parity_mode_ms_per_step`)."""
+    from bioscanclip.hip import engine
+    from bioscanclip.model import arch
+    monkeypatch.setattr(engine, "RESID_STREAM_BF16", False)
+    monkeypatch.setattr(engine, "GRAD_STREAM_BF16", False)
+    if which == "vit":
+        from bioscanclip.model.image_encoder import LoRA_ViT_timm
+        m, prefix, seed = LoRA_ViT_timm(arch.VisionTransformerParams(depth=12), r=4, num_classes=768), "image_encoder.", 13
+        x, _, _, _ = synth.synth_batch(2, seed=23)
+        fn, cot, name = (lambda s: refcpu.vit_encoder(s, x)), "vit.cot.12", "vit_L12"
+    else:
+        from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+        m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=12, **NODROP)), r=4, num_classes=768)
+        prefix, seed = "dna_encoder.", 11
+        _, x, _, _ = synth.synth_batch(2, seed=21)
+        fn, cot, name = (lambda s: refcpu.barcode_bert_encoder(s, x)), "dna.cot.12", "dna_L12"
+    sd = _load(m, prefix, seed)
+    m.to("cuda").train()
+    y = m(x.cuda())
+    w = synth.synth_tensor(cot, y.shape, seed=5)
+    (y * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    ws = m._engine.ws
+    assert ws["resid_bf16"] is False and ws["grad_bf16"] is False
+    sdo, keys, yo = _oracle_grads(sd, fn)
+    (yo * w).sum().backward()
+    named = dict(m.named_parameters())
+    e = rel_err(y, yo)
+    worst = max(rel_err(named[k[len(prefix):]].grad, sdo[k].grad) for k in keys)
+    _log({"test": f"parity_mode_{name}", "emb_vs_f32_oracle": e, "worst_grad": worst})
+    tol_e, tol_g = {"vit_L12": (1.59e-2, 5.8e-2), "dna_L12": (1.62e-2, 5.1e-2)}[name]
+    assert e < tol_e and worst < tol_g, (e, worst)
+    assert worst < TOL[name][1] / 1.3, worst    # in both towers the gradients are closer than the default configuration's
 
 
 def _build_clip(with_text, seed):

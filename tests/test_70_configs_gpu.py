@@ -53,10 +53,15 @@ def _run(model, image, dna, text, cot, n_keep):
     return [o.detach()[:n_keep].clone() for o in outs], grads
 
 
-@pytest.mark.parametrize("B,with_text", [(256, False), (256, True), (1024, False)])
-def test_large_batch_equals_small_batch_on_shared_rows(B, with_text):
+@pytest.mark.parametrize("B,with_text,fp8", [(256, False, False), (256, True, False), (1024, False, False),
+                                             (1024, True, False),      # configs[3]: local batch 1 024 WITH the text tower
+                                             (512, False, True)])      # configs[4]: fp8 trunks at their own local batch 512
+def test_large_batch_equals_small_batch_on_shared_rows(B, with_text, fp8):
     n = 8
     model = _towers(with_text)
+    if fp8:   # activations quantised with scale 1, weights per output row: nothing depends on the batch, rows stay independent
+        from bioscanclip.hip.engine import set_precision
+        set_precision(model, "fp8")
     image, dna, text, _ = synth.synth_batch(n, seed=71, with_text=with_text)
     # the other B - n samples: more synthetic samples, tiled (their content only has to be valid input)
     fill_i, fill_d, fill_t, _ = synth.synth_batch(56, seed=72, with_text=with_text)

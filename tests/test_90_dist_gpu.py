@@ -274,7 +274,7 @@ def test_rccl_collectives_at_world_size_one():
         # both legs enqueue eagerly (the captured-graph path reads AdamW's lr / step from device memory, a second, separately
         # tested form of the same update): the only difference left is the collectives
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--text", "--batch", "16", "--steps", "3", "--warmup", "3",
-                            "--no-graph", "--no-cpu-baseline"], env=e, capture_output=True, text=True, timeout=800)
+                            "--no-graph", "--no-cpu-baseline", "--no-extras"], env=e, capture_output=True, text=True, timeout=800)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = json.loads(r.stdout.strip().splitlines()[-1])
     # same seeds, same batch, dropout masks keyed on (seed, call count, rank 0): the collectives must not change the numbers
@@ -283,14 +283,14 @@ def test_rccl_collectives_at_world_size_one():
     # (ProcessGroupNCCL = RCCL) issued between the replays.  AdamW reads (lr, step) from device memory there (bias corrections formed
     # on the device): the same update to 1e-7, so the loss after 6 steps agrees to rounding, not bit for bit
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--text", "--batch", "16", "--steps", "3", "--warmup", "3",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=800)
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-2000:]
     g = json.loads(r.stdout.strip().splitlines()[-1])
     assert "per-tower captured hipGraphs" in g["config"]["launch_path"], g["config"]
     assert "capture failed" not in r.stderr
     # the graph leg runs 1 + 3 (eager, capture, first replay) + 3 + 3 = 10 steps: the eager comparison takes as many
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--text", "--batch", "16", "--steps", "3", "--warmup", "6",
-                        "--no-graph", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=800)
+                        "--no-graph", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-2000:]
     e10 = json.loads(r.stdout.strip().splitlines()[-1])
     assert abs(g["config"]["final_loss"] - e10["config"]["final_loss"]) < 1e-4 * abs(e10["config"]["final_loss"]), (g, e10)
