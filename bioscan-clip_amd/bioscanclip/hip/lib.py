@@ -113,6 +113,7 @@ DIAG_SIGNATURES = {
     "bsclip_gemm_pers_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, I, P]),
     "bsclip_attn_bwd_diag": (I, [P, I, P, I, P, I, I, I, F, P, I, P, P]),
     "bsclip_attn_bwd2_diag": (I, [P, I, P, I, P, P, I, P, I, I, I, F, P, I, P, P]),
+    "bsclip_attn_bwd_pers_diag": (I, [P, I, P, I, P, P, I, P, I, I, I, F, P, I, P, P]),
 }
 DIAG_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libbsclip_hip_diag.so")
 

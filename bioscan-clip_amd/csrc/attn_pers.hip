@@ -1,0 +1,501 @@
+// Attention backward, key-owner sweep (attn_sweep.hip) made PERSISTENT: one workgroup per CU walks (batch, head) items and the
+// next item's tiles arrive while the current one is swept (round 4).  Production sequence lengths only (S = 197 / 133, no key mask);
+// everything else stays on attn_sweep.hip / attn.hip.
+//
+// Why: a (batch, head) item is ~150 KB of loads for ~9 us of matrix / vector work, and one sweep workgroup fills a CU (LDS,
+// registers), so nothing else hides its load phase: measured 8 us of loading + 9 us of sweeping per item in the one-item-per-
+// workgroup kernel (profiles/r04_b_attn_sweep_phases.log).  Here the loads of item n+1 are in flight during the sweep of item n.
+//
+// Waves: NB key owners (wave w = 32 keys: K_w, V_w as MFMA B operands, dK_w^T / dV_w^T in 64 accumulators) + one dQ wave.
+// LDS   (S = 197: 158 KB):  Q[2] | dO[2]  (double-buffered by item, RW = 8 ceil(S / 8) rows of 128 B, XOR-swizzled 16-B chunks)
+//                           K           (single: only the dQ wave reads it, once per item, into registers)
+//                           dS^T ring   (RING slots of NB tiles [32 keys][32 q] bf16, 64-B rows, 8-B columns XOR (key >> 1) & 7;
+//                                        the last tile holds 8 rows: S - 32 (NB - 1) <= 8 valid keys)
+//                           statistics  (nm2, inv, delta [, -inv delta] per query row, double-buffered by item)
+// Who brings what:  key owners -- Q / dO of item n+1 by LDS-DMA (issued after the item barrier, confirmed at their block NB-3), their
+//                   own K / V fragments of item n+1 by global loads during their last block, and -- wave w for query block w -- the
+//                   O fragments and row statistics of item n+1, from which it forms delta ON THE MATRIX PIPE during block NB-2:
+//                   delta_q = diag(dO O^T)_q rZ_q, 8 MFMAs per 32 rows (O_hi and O_lo into one accumulator), the diagonal picked
+//                   out of the accumulator tile -- no vector-ALU dot products, no LDS copy of O;
+//                   dQ wave -- K of item n+1 by LDS-DMA (after it has taken K^T of item n into registers).
+// Hand-offs are monotonic LDS counters (key owners -> dQ wave: dS tiles of a block; dQ wave -> key owners: slot consumed; key owners
+// -> key owners: prefetched tiles landed) plus ONE workgroup barrier per item.  Every spin is bounded: on a timeout
+// the workgroup poisons its first output element with NaN and runs to the end (no wave is left waiting).
+#include "attn_common.h"
+
+namespace {
+
+constexpr int PT_TILE = 2048;   // a full dS^T tile: 32 keys x 64 B
+
+__device__ __forceinline__ int ds_off(int key, int c8) { return key * 64 + ((c8 ^ ((key >> 1) & 7)) << 3); }
+
+// transposed fragment of a swizzled dS^T tile (see frag_tr_lin): MFMA row = tile COLUMN (query) lane & 31, element j = tile ROW
+// (key) c0 + 8 (j >> 2) + 4 (lane >> 5) + (j & 3); HALF: rows c0 + 8 .. are not stored (the 8-row tail tile) and read as zero
+template <bool HALF>
+__device__ __forceinline__ bf16x8 frag_ds(const char* tile, int c0, int lane) {
+    const int gi = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row = c0 + 4 * (gi >> 1) + q;
+    const int c8 = 4 * (gi & 1) + pp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + ds_off(row, c8)));
+    s16x4 hi = {0, 0, 0, 0};
+    if constexpr (!HALF)
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + ds_off(row + 8, c8)));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// store a [64 (d) x 32 (token on lane)] result held as 2 accumulator tiles into out[token][d] with 16-BYTE stores: a lane holds d =
+// 8g + 4h + (0..3) of its token, the other half of the wave (h ^ 1) the neighbouring four; v_permlane32_swap pairs the even / odd
+// register groups of the two halves so that every lane owns 8 consecutive d -- 4 stores per call instead of 8 (the 8-byte form
+// is store-ISSUE bound: every instruction touches 64 row segments; cdna_hip_programming.md T21)
+__device__ __forceinline__ void store_dt16(const f32x16 (&acc)[2], float mul, bf16_t* out_row, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            const int ge = 8 * gp, go = 8 * gp + 4;   // first registers of the even / odd group of the pair
+            const unsigned a0 = pack_bf2(acc[dt][ge + 0] * mul, acc[dt][ge + 1] * mul), a1 = pack_bf2(acc[dt][ge + 2] * mul, acc[dt][ge + 3] * mul);
+            const unsigned b0 = pack_bf2(acc[dt][go + 0] * mul, acc[dt][go + 1] * mul), b1 = pack_bf2(acc[dt][go + 2] * mul, acc[dt][go + 3] * mul);
+            const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            // h = 0: (own even group, partner's even group) = d 16 gp + 0..7;  h = 1: (partner's odd group, own odd group) = d 16 gp + 8..15
+            *reinterpret_cast<u32x4*>(out_row + 32 * dt + 16 * gp + 8 * h) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        }
+}
+
+// frag_tr with every row clamped to rmax: the last query / key block reaches past the RW rows a tile holds; those rows carry
+// probability 0, so which (finite) row stands in for them does not matter, reading past the tile would
+__device__ __forceinline__ bf16x8 frag_tr_c(const char* tile, int d0, int c0, int lane, int rmax) {
+    const int gi = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row0 = min(c0 + 4 * (gi >> 1) + q, rmax), row1 = min(c0 + 4 * (gi >> 1) + q + 8, rmax);
+    const int col = d0 + 16 * (gi & 1) + 4 * pp;
+    const char* p0 = tile + rm_off(row0, col >> 3) + (col & 7) * 2;
+    const char* p1 = tile + rm_off(row1, col >> 3) + (col & 7) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NB, int S, bool DROP, int RING, bool DIAG = false>
+__global__ __launch_bounds__((NB + 1) * 64) void attn_bwd_pers_kernel(
+    const bf16_t* __restrict__ qkv, int ld, const bf16_t* __restrict__ dctx, int ld_ctx, const bf16_t* __restrict__ ohi,
+    const bf16_t* __restrict__ olo, int ld_o, const float* __restrict__ stats, int heads, int nitems, float scale,
+    bf16_t* __restrict__ dqkv, int ld_d, DropCfg drop, unsigned long long* diag = nullptr) {
+    constexpr int NW = NB + 1, RW = (S + 7) / 8 * 8, NPIECE = RW / 8, TB = RW * ROWB, SP = NB * 32;
+    constexpr int TAILK = S - 32 * (NB - 1);
+    static_assert(TAILK >= 1 && TAILK <= 8, "the last key tile is stored as 8 rows");
+    static_assert(NB >= 4, "the prefetch confirmation sits at block NB - 3");
+    constexpr int SLOT = (NB - 1) * PT_TILE + 512, NARR = DROP ? 4 : 3;
+    constexpr int OFF_DO = 2 * TB, OFF_K = 4 * TB, OFF_DS = 5 * TB, OFF_ST = OFF_DS + RING * SLOT, OFF_DQ = OFF_ST + 2 * NARR * SP * 4;
+    constexpr int TOTAL = OFF_DQ + 4096;   // + the dQ wave's [32 q][64 d] staging tile (row-contiguous 16-byte stores)
+    static_assert(TOTAL <= 163840 - 128, "LDS budget");
+    BSCLIP_DROP_RESOLVE(drop);
+    __shared__ __attribute__((aligned(16))) char smem[TOTAL];
+    __shared__ unsigned cDone[RING], cCons, cPref, cFail;
+    float* sStat = reinterpret_cast<float*>(smem + OFF_ST);
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = heads * 64;
+    const int n_my = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1: the grid never exceeds nitems
+    const int G = n_my * NB;                                                              // query blocks this workgroup sweeps
+    const float scale2 = scale * LOG2E;
+    // diagnostic build: per-wave wall-clock stamps (100 MHz) of the workgroup's SECOND item; tools/attn_pers_phases.py
+    auto stamp = [&](int n, int i) {
+        if constexpr (DIAG) {
+            if (n == 1 && (threadIdx.x & 63) == 0) diag[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + i] = wall_clock64();
+        }
+    };
+
+    // bounded wait on a monotonic counter; after the first timeout every wait returns at once (the kernel then only has to END)
+    auto wait_ge = [&](unsigned* p, unsigned v) {
+        if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= v) return;
+        for (int it = 0; it < (1 << 21); ++it) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= v) return;
+            if ((it & 255) == 255 && __hip_atomic_load(&cFail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+        }
+        __hip_atomic_store(&cFail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto bump = [&](unsigned* p) {
+        if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto item_of = [&](int n) { return (int)blockIdx.x + n * (int)gridDim.x; };
+    auto qbase = [&](int item) { return qkv + (size_t)(item / heads) * S * ld + (item % heads) * 64; };
+    auto dobase = [&](int item) { return dctx + (size_t)(item / heads) * S * ld_ctx + (item % heads) * 64; };
+    // one LDS-DMA piece: 8 rows (1 KiB) of a [S][64] bf16 matrix into a swizzled row-major tile (rows >= S repeat row S - 1)
+    auto piece = [&](const bf16_t* src, int ldx, char* tile, int p) {
+        const int row = 8 * p + (lane >> 3);
+        const int sc = (lane & 7) ^ ((row >> 1) & 7);
+        glds16(src + (size_t)min(row, S - 1) * ldx + sc * 8, tile + p * 1024);
+    };
+    auto stat = [&](int n, int arr) { return sStat + ((n & 1) * NARR + arr) * SP; };
+
+    if (tid < RING) cDone[tid] = 0u;
+    if (tid == 32) cCons = 0u;
+    if (tid == 34) cPref = 0u;
+    if (tid == 35) cFail = 0u;
+
+    // ---------------- prologue: the first item's tiles, by every wave ----------------
+    {
+        const int it0 = item_of(0);
+#pragma unroll 1
+        for (int p = wave; p < 3 * NPIECE; p += NW) {
+            if (p < NPIECE) piece(qbase(it0), ld, smem, p);
+            else if (p < 2 * NPIECE) piece(dobase(it0), ld_ctx, smem + OFF_DO, p - NPIECE);
+            else piece(qbase(it0) + HW, ld, smem + OFF_K, p - 2 * NPIECE);
+        }
+    }
+
+    if (wave < NB) {
+        // =========================================== key owner: keys [32 wave, 32 wave + 32) ===========================================
+        const int key = wave * 32 + (lane & 31);
+        const int krow = min(key, S - 1);
+        const bool tailw = wave == NB - 1;
+        bf16x8 kf[4], vf[4];
+        {
+            const bf16_t* kb = qbase(item_of(0)) + HW;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kf[ks] = frag_global(kb, ld, krow, ks, lane);
+                vf[ks] = frag_global(kb + HW, ld, krow, ks, lane);
+            }
+        }
+        f32x16 bk16;   // padded keys (the tail wave's lanes past S) start their scores from -inf: probability exactly 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bk16[r] = key < S ? 0.f : -INFINITY;
+        // delta and row statistics of query block `wave` of one item: O fragments (hi, lo) + statistics are requested early ...
+        bf16x8 oh[4], ol[4];
+        f32x4 st4;
+        auto oloads = [&](int item) {
+            const int row = min(32 * wave + (lane & 31), S - 1);
+            const bf16_t* ph = ohi + (size_t)(item / heads) * S * ld_o + (item % heads) * 64;
+            const bf16_t* pl = olo + (size_t)(item / heads) * S * ld_o + (item % heads) * 64;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                oh[ks] = frag_global(ph, ld_o, row, ks, lane);
+                ol[ks] = frag_global(pl, ld_o, row, ks, lane);
+            }
+            st4 = *reinterpret_cast<const f32x4*>(stats + ((size_t)item * S + row) * 4);
+        };
+        // ... and turned into statistics once the item's dO tile is in LDS (buffer nn & 1)
+        auto delta_block = [&](int nn) {
+            const char* sDOx = smem + OFF_DO + (nn & 1) * TB;
+            const int arow = min(32 * wave + (lane & 31), RW - 1) - (lane & 31);
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 a = frag_rm(sDOx, arow, ks, lane);
+                acc = mfma32(a, oh[ks], acc);
+                acc = mfma32(a, ol[ks], acc);
+            }
+            // acc[r] on lane L = dO[row acc_row(r, h)] . O[row L & 31]: the diagonal element of query L & 31 sits on the lane whose
+            // half h equals bit 2 of the query index, in register (q & 3) + 4 (q >> 3)
+            const int ql = lane & 31, rstar = (ql & 3) + 4 * (ql >> 3);
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v = rstar == r ? acc[r] : v;
+            const float dsel = __shfl(v, ql + 32 * ((ql >> 2) & 1), 64);   // lanes 0..31: the diagonal of their own query row
+            if (lane < 32) {
+                const int row = 32 * wave + lane;
+                const bool ok = row < S;
+                const float delta = dsel * st4[2];
+                stat(nn, 0)[row] = ok ? st4[0] : -INFINITY;          // padded query rows: e = exp2(-inf) = 0
+                stat(nn, 1)[row] = ok ? st4[1] : 0.f;
+                stat(nn, 2)[row] = ok ? (DROP ? delta / drop.scale : delta) : 0.f;
+                if constexpr (DROP) stat(nn, 3)[row] = ok ? -st4[1] * delta : 0.f;
+            }
+        };
+        oloads(item_of(0));
+        stage_wait();
+        __syncthreads();                                                    // B_0: item 0 staged, counters initialised
+        delta_block(0);
+        BSCLIP_LDS_BARRIER();                                               // B_0': item 0's row statistics are in LDS
+#pragma unroll 1
+        for (int n = 0; n < n_my; ++n) {
+            const int item = item_of(n), b = item / heads, hd = item % heads;
+            const unsigned bh = (unsigned)item;
+            bf16_t* dqb = dqkv + (size_t)b * S * ld_d + hd * 64;
+            const char* sQ = smem + (n & 1) * TB;
+            const char* sDO = smem + OFF_DO + (n & 1) * TB;
+            const bool more = n + 1 < n_my;
+            stamp(n, 0);
+            // Q / dO of the next item go into the other buffers (free: every wave has passed this item's barrier) a few LDS-DMA
+            // pieces per block, not in one burst: a burst right behind the previous item's stores sat 3 us in the memory pipe's
+            // back-pressure (stamps, round 4) with every wave of the workgroup stalled behind it at the same time
+            constexpr int PB = (2 * NPIECE / NB + 1 + (NB - 4)) / (NB - 3);   // pieces per block so that blocks 0 .. NB-4 issue them all
+            const int itn = more ? item_of(n + 1) : item;
+            stamp(n, 1);
+            f32x16 dv[2] = {zero16(), zero16()}, dk[2] = {zero16(), zero16()};
+            const float* sNm2 = stat(n, 0);
+            const float* sInv = stat(n, 1);
+            const float* sDel = stat(n, 2);
+            const float* sNid = stat(n, NARR - 1);
+            // One query block.  LAST: the item's last block holds S - 32 (NB - 1) <= 8 valid rows -- only register group 0 (rows
+            // 0..3 | 4..7) can carry a probability, only the first 16-row k-step contributes to dK / dV: three quarters of the
+            // vector work and half of the transposed products are skipped at compile time.
+            auto block = [&](int c, auto lastc) {
+                constexpr bool LAST = decltype(lastc)::value;
+                constexpr int NG = LAST ? 1 : 4, NS2 = LAST ? 1 : 2;
+                asm volatile("" ::: "memory");   // the tiles are loop-invariant: keep LICM from hoisting fragment reads
+                const int g = n * NB + c, q0 = c * 32;
+                if (more && c <= NB - 4) {
+#pragma unroll 1
+                    for (int j = c * PB; j < (c + 1) * PB; ++j) {
+                        const int p = wave + NB * j;
+                        if (p < NPIECE) piece(qbase(itn), ld, smem + ((n + 1) & 1) * TB, p);
+                        else if (p < 2 * NPIECE) piece(dobase(itn), ld_ctx, smem + OFF_DO + ((n + 1) & 1) * TB, p - NPIECE);
+                    }
+                    if (c == (NB >= 6 ? 1 : 0)) oloads(itn);
+                }
+                // A rows of this block (clamped: the tiles hold RW rows, the last block's lanes past it read row RW - 1: their
+                // probability is 0 by the statistics, the operand only has to be finite)
+                const int arow = min(q0 + (lane & 31), RW - 1) - (lane & 31);   // frag_rm adds lane & 31 back
+                f32x16 s = zero16(), dp = zero16();
+                if (tailw) s = bk16;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = mfma32(frag_rm(sQ, arow, ks, lane), kf[ks], s);       // S[q, key]
+                    dp = mfma32(frag_rm(sDO, arow, ks, lane), vf[ks], dp);    // dP[q, key] = dO_q . V_key
+                }
+                if (LAST && more) {   // K_w / V_w are dead for this item: the next item's go straight into their registers,
+                    const bf16_t* kb = qbase(item_of(n + 1)) + HW;   // with the rest of this block (and the item barrier) to arrive
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        kf[ks] = frag_global(kb, ld, krow, ks, lane);
+                        vf[ks] = frag_global(kb + HW, ld, krow, ks, lane);
+                    }
+                }
+                if (c == 1) stamp(n, 3);
+                if (g >= RING) wait_ge(&cCons, (unsigned)(g - RING + 1));     // the ring slot's previous tenant has been consumed
+                if (c == 1) stamp(n, 4);
+                char* slot = smem + OFF_DS + (g % RING) * SLOT + wave * PT_TILE;
+                unsigned pw[8], dw[8];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    if (gq >= NG) {   // rows past the sequence: P = dS = 0
+                        pw[2 * gq] = pw[2 * gq + 1] = dw[2 * gq] = dw[2 * gq + 1] = 0u;
+                        if (!tailw || (lane & 31) < 8) *reinterpret_cast<uint2*>(slot + ds_off(lane & 31, 2 * gq + h)) = uint2{0u, 0u};
+                        continue;
+                    }
+                    const int r0 = q0 + 8 * gq + 4 * h;
+                    const f32x4 n4 = *reinterpret_cast<const f32x4*>(sNm2 + r0);
+                    const f32x4 i4 = *reinterpret_cast<const f32x4*>(sInv + r0);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + r0);
+                    f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (DROP) z4 = *reinterpret_cast<const f32x4*>(sNid + r0);
+                    float e[4], kp[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        e[i] = __builtin_amdgcn_exp2f(fmaf(s[4 * gq + i], scale2, n4[i]));
+                        kp[i] = 1.f;
+                        if constexpr (DROP) {
+                            const int q = min(r0 + i, S - 1);
+                            kp[i] = drop_factor(drop, (bh * S + (unsigned)q) * SP + (unsigned)key);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned w = DROP ? pack_bf2(e[2 * j] * kp[2 * j], e[2 * j + 1] * kp[2 * j + 1]) : pack_bf2(e[2 * j], e[2 * j + 1]);
+                        const float t0 = bf_lo(w) * i4[2 * j], t1 = bf_hi(w) * i4[2 * j + 1];
+                        float ds0 = t0 * (dp[4 * gq + 2 * j] - d4[2 * j]), ds1 = t1 * (dp[4 * gq + 2 * j + 1] - d4[2 * j + 1]);
+                        if constexpr (DROP) {
+                            ds0 = kp[2 * j] != 0.f ? ds0 : e[2 * j] * z4[2 * j];
+                            ds1 = kp[2 * j + 1] != 0.f ? ds1 : e[2 * j + 1] * z4[2 * j + 1];
+                        }
+                        pw[2 * gq + j] = pack_bf2(t0, t1);
+                        dw[2 * gq + j] = pack_bf2(ds0, ds1);
+                    }
+                    // dS^T[key][q0 + 8 gq + 4h .. + 3]: 8 B at column 2 gq + h of this key's row (the tail tile stores keys 0..7 only)
+                    if (!tailw || (lane & 31) < 8)
+                        *reinterpret_cast<uint2*>(slot + ds_off(lane & 31, 2 * gq + h)) = uint2{dw[2 * gq], dw[2 * gq + 1]};
+                }
+                bump(&cDone[g % RING]);   // release: this wave's tile of block g is written
+#pragma unroll
+                for (int s2 = 0; s2 < NS2; ++s2) {
+                    const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]});
+                    const bf16x8 dsb = __builtin_bit_cast(bf16x8, u32x4{dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]});
+                    // transposed reads of rows q0 + 16 s2 + [0, 16) (the last block's rows past RW - 1: clamped, their P = dS = 0)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dv[dt] = mfma32(frag_tr_c(sDO, 32 * dt, q0 + 16 * s2, lane, RW - 1), pb, dv[dt]);   // dV^T += dO^T P
+                        dk[dt] = mfma32(frag_tr_c(sQ, 32 * dt, q0 + 16 * s2, lane, RW - 1), dsb, dk[dt]);   // dK^T += Q^T dS
+                    }
+                }
+                if (c == 0) stamp(n, 2);
+                if (c == NB - 3) stamp(n, 5);
+                if (c == NB - 3 && more) {   // the pieces requested at the top of the item have had NB - 3 blocks: confirm them
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    bump(&cPref);
+                }
+                if (c == NB - 3) stamp(n, 6);
+                if (c == NB - 2 && more) {   // every key owner has confirmed: the next item's dO tile is whole
+                    wait_ge(&cPref, (unsigned)(NB * (n + 1)));
+                    delta_block(n + 1);      // visible to the others after the item barrier
+                }
+                if (c == NB - 2) stamp(n, 7);
+            };
+#pragma unroll 1
+            for (int c = 0; c < NB - 1; ++c) block(c, std::false_type{});
+            block(NB - 1, std::true_type{});
+            stamp(n, 8);
+            if (key < S) {
+                store_dt16(dk, scale, dqb + (size_t)key * ld_d + HW, lane);
+                store_dt16(dv, 1.0f, dqb + (size_t)key * ld_d + 2 * HW, lane);
+            }
+            stamp(n, 9);
+            if (more) BSCLIP_LDS_BARRIER();
+            stamp(n, 10);                            // B_{n+1} (the compiler waits for kf / vf at their first use)
+        }
+    } else {
+        // =========================================== dQ wave ===========================================
+        stage_wait();
+        __syncthreads();                                                    // B_0
+        BSCLIP_LDS_BARRIER();                                               // B_0'
+        bf16x8 ktf[NB][2][2];
+        auto load_ktf = [&]() {   // K^T fragments of the item whose K sits in LDS (rows past RW: clamped, their dS is 0)
+#pragma unroll
+            for (int kt = 0; kt < NB; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (kt == NB - 1 && s2 == 1) continue;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) ktf[kt][s2][dt] = frag_tr_c(smem + OFF_K, 32 * dt, 32 * kt + 16 * s2, lane, RW - 1);
+                }
+        };
+        load_ktf();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // K^T is in registers: the K region may be overwritten
+        constexpr int KPS = (NPIECE + NB - 4) / (NB - 3);                   // K pieces per step: all issued during steps 0 .. NB-4
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+            const int n = g / NB, c = g % NB;
+            const int item = item_of(n), b = item / heads, hd = item % heads;
+            bf16_t* dqb = dqkv + (size_t)b * S * ld_d + hd * 64;
+            if (c == 0 && n > 0) {
+                // K of this item: its last pieces went out at step NB - 4 of the previous item; since then the steps NB-3, NB-2
+                // (4 stores each) and NB-1 (1 store: 5 valid rows) -- 9 younger operations, a count never larger than the truth
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                load_ktf();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (c <= NB - 4 && n + 1 < n_my) {   // K of the next item, a few pieces per step (the K region is free: K^T sits in registers)
+                const bf16_t* kb = qbase(item_of(n + 1)) + HW;
+#pragma unroll 1
+                for (int p = c * KPS; p < min((c + 1) * KPS, NPIECE); ++p) piece(kb, ld, smem + OFF_K, p);
+            }
+            // ---- dQ of block g ----
+            if (c == 0) stamp(n, 0);
+            if (c == 1) stamp(n, 2);
+            wait_ge(&cDone[g % RING], (unsigned)(NB * (g / RING + 1)));
+            if (c == 0) stamp(n, 1);
+            if (c == 1) stamp(n, 3);
+            const char* tiles = smem + OFF_DS + (g % RING) * SLOT;
+            f32x16 dq[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int kt = 0; kt < NB; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (kt == NB - 1 && s2 == 1) continue;
+                    if (s2 == 0 && (kt & 1) == 0) asm volatile("" ::: "memory");   // at most two key tiles' dS fragments in flight (registers)
+                    const bf16x8 dsb = kt == NB - 1 ? frag_ds<true>(tiles + kt * PT_TILE, 0, lane)
+                                                    : frag_ds<false>(tiles + kt * PT_TILE, 16 * s2, lane);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(ktf[kt][s2][dt], dsb, dq[dt]);   // dQ^T += K^T dS^T
+                }
+            if (lane == 0) __hip_atomic_store(&cCons, (unsigned)(g + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ---- stores of block g: through a [32 q][64 d] LDS tile, so that every store instruction writes whole 128-byte rows
+            // (16 B per lane, 8 rows per instruction) instead of 64 scattered 8-byte segments ----
+            {
+                char* stg = smem + OFF_DQ;
+                const int ql = lane & 31;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        uint2 o;
+                        o.x = pack_bf2(dq[dt][4 * gq + 0] * scale, dq[dt][4 * gq + 1] * scale);
+                        o.y = pack_bf2(dq[dt][4 * gq + 2] * scale, dq[dt][4 * gq + 3] * scale);
+                        *reinterpret_cast<uint2*>(stg + ql * 128 + (((4 * dt + gq) ^ (ql & 7)) << 4) + 8 * h) = o;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own writes, read back below
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 8 * i + (lane >> 3), ch = lane & 7;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+                    if (c * 32 + row < S) *reinterpret_cast<u32x4*>(dqb + (size_t)(c * 32 + row) * ld_d + ch * 8) = v;
+                }
+                asm volatile("" ::: "memory");
+            }
+            if (c == 1) stamp(n, 4);
+            if (c == NB - 1) stamp(n, 9);
+            if (c == NB - 1 && n + 1 < n_my) BSCLIP_LDS_BARRIER();          // B_{n+1}
+            if (c == NB - 1) stamp(n, 10);
+        }
+    }
+    // a timed-out hand-off: make the failure visible (tests compare every output element) instead of silently wrong
+    if (__hip_atomic_load(&cFail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) && tid == 0)
+        dqkv[(size_t)(item_of(0) / heads) * S * ld_d + (item_of(0) % heads) * 64] = 0x7FC0;
+}
+
+}  // namespace
+
+#define ATTN_PERS_LAUNCH(NBV, SV, DR, RG)                                                                                   \
+    hipLaunchKernelGGL((attn_bwd_pers_kernel<NBV, SV, DR, RG>), dim3(grid), dim3((NBV + 1) * 64), 0, s,                      \
+                       static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_dctx,                   \
+                       static_cast<const bf16_t*>(ctx), static_cast<const bf16_t*>(ctx_lo), ld_ctx, stats, heads, B * heads,  \
+                       scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop)
+
+// internal (attn_sweep.hip dispatches here for S = 197 / 133 without a key mask); returns false when the shape is not covered
+bool bsclip_attn_bwd_pers_launch(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo,
+                                 int ld_ctx, const float* stats, int B, int S, int heads, float scale, void* dqkv, int ld_dqkv,
+                                 const DropCfg& drop, hipStream_t s) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (cus <= 0) cus = 256;
+    }
+    const int grid = B * heads < cus ? B * heads : cus;
+    if (S == 197) {
+        if (drop.thr16) return false;   // a fourth statistics array does not fit beside the tiles at S = 197 (timm's ViT has no attention dropout)
+        ATTN_PERS_LAUNCH(7, 197, false, 2);
+        return true;
+    }
+    if (S == 133) {
+        if (drop.thr16) ATTN_PERS_LAUNCH(5, 133, true, 4);
+        else ATTN_PERS_LAUNCH(5, 133, false, 4);
+        return true;
+    }
+    return false;
+}
+
+#ifdef BSCLIP_DIAG
+// Diagnostic build of the persistent kernel (S = 197 / 133, no dropout): per-wave stamps of each workgroup's second item,
+// diag[grid * (NB + 1) * 16]; tools/attn_pers_phases.py
+extern "C" int bsclip_attn_bwd_pers_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo,
+                                         int ld_ctx, const float* stats, int B, int S, int heads, float scale, void* dqkv, int ld_dqkv,
+                                         unsigned long long* diag, void* stream) {
+    BSCLIP_REQUIRE(qkv && dctx && ctx && ctx_lo && stats && dqkv && diag, "bsclip_attn_bwd_pers_diag: null pointer");
+    BSCLIP_REQUIRE(S == 197 || S == 133, "bsclip_attn_bwd_pers_diag: S=%d (197 or 133)", S);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DropCfg drop = make_drop(0.f, 0);
+    const int grid = B * heads < 256 ? B * heads : 256;
+    if (S == 197)
+        hipLaunchKernelGGL((attn_bwd_pers_kernel<7, 197, false, 2, true>), dim3(grid), dim3(512), 0, s, static_cast<const bf16_t*>(qkv),
+                           ld_qkv, static_cast<const bf16_t*>(dctx), ld_dctx, static_cast<const bf16_t*>(ctx),
+                           static_cast<const bf16_t*>(ctx_lo), ld_ctx, stats, heads, B * heads, scale, static_cast<bf16_t*>(dqkv), ld_dqkv,
+                           drop, diag);
+    else
+        hipLaunchKernelGGL((attn_bwd_pers_kernel<5, 133, false, 4, true>), dim3(grid), dim3(384), 0, s, static_cast<const bf16_t*>(qkv),
+                           ld_qkv, static_cast<const bf16_t*>(dctx), ld_dctx, static_cast<const bf16_t*>(ctx),
+                           static_cast<const bf16_t*>(ctx_lo), ld_ctx, stats, heads, B * heads, scale, static_cast<bf16_t*>(dqkv), ld_dqkv,
+                           drop, diag);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+#endif  // BSCLIP_DIAG

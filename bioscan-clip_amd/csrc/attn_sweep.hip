@@ -16,6 +16,8 @@
 // same pd_k is re-formed here bit for bit (same score accumulation, same exp2 argument) and
 //     dS_k = inv pd_k (dP_k - delta / keep_scale)   (kept keys),     dS_k = - inv e_k delta   (dropped keys)
 // sums to inv [ (dO . O) / inv - delta Z' ] = 0 by the definition of Z' (attn_fwd_kernel, V2).
+#include <stdlib.h>
+
 #include "attn_common.h"
 
 namespace {
@@ -312,6 +314,12 @@ __global__ __launch_bounds__((NB + 1) * 64) void attn_bwd_sweep_kernel(
 
 }  // namespace
 
+// attn_pers.hip: the persistent form (next item's tiles prefetched under the current sweep) for the production sequence lengths
+bool bsclip_attn_bwd_pers_launch(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo,
+                                 int ld_ctx, const float* stats, int B, int S, int heads, float scale, void* dqkv, int ld_dqkv,
+                                 const DropCfg& drop, hipStream_t s);
+static const bool g_attn_pers = !(getenv("BSCLIP_ATTN_PERS") && atoi(getenv("BSCLIP_ATTN_PERS")) == 0);   // A/B switch
+
 #define ATTN_SWEEP_LAUNCH(NBV, DR)                                                                                      \
     hipLaunchKernelGGL((attn_bwd_sweep_kernel<NBV, DR>), dim3(B * heads), dim3((NBV + 1) * 64), 0, s,                    \
                        static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_dctx,               \
@@ -338,6 +346,11 @@ extern "C" int bsclip_attn_bwd2(const void* qkv, int ld_qkv, const void* dctx, i
     BSCLIP_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "bsclip_attn_bwd2: stats must be 16-byte aligned");
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g_attn_pers && !key_bias &&
+        bsclip_attn_bwd_pers_launch(qkv, ld_qkv, dctx, ld_dctx, ctx, ctx_lo, ld_ctx, stats, B, S, heads, scale, dqkv, ld_dqkv, drop, s)) {
+        BSCLIP_LAUNCH_CHECK();
+        return BSCLIP_OK;
+    }
     switch ((S + 31) / 32) {
         ATTN_SWEEP_CASE(1) ATTN_SWEEP_CASE(2) ATTN_SWEEP_CASE(3) ATTN_SWEEP_CASE(4) ATTN_SWEEP_CASE(5) ATTN_SWEEP_CASE(6)
         ATTN_SWEEP_CASE(7)

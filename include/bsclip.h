@@ -148,6 +148,11 @@ int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_c
 int bsclip_attn_bwd2_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo,
                           int ld_ctx, const float* stats, int B, int S, int heads, float scale, void* dqkv, int ld_dqkv,
                           unsigned long long* diag, void* stream);
+/* the persistent form of the same (csrc/attn_pers.hip): per-wave stamps of each workgroup's second item, diag[grid * (NB+1) * 16];
+ * tools/attn_pers_phases.py */
+int bsclip_attn_bwd_pers_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo,
+                              int ld_ctx, const float* stats, int B, int S, int heads, float scale, void* dqkv, int ld_dqkv,
+                              unsigned long long* diag, void* stream);
 #endif
 
 /* ---- LayerNorm (timm norm1/norm2/norm eps 1e-6; HF BertLayerNorm eps 1e-12) ------------------------------------

@@ -323,7 +323,9 @@ def test_attention_fwd_bwd(ops, B, S, heads, masked):
 
 @pytest.mark.parametrize("B,S,heads,masked", [(3, 197, 12, False), (2, 133, 12, False), (5, 20, 8, True),
                                               (2, 64, 2, False), (1, 33, 1, False), (2, 7, 3, True),
-                                              (2, 224, 2, True), (3, 1, 2, False), (1, 193, 1, True)])
+                                              (2, 224, 2, True), (3, 1, 2, False), (1, 193, 1, True),
+                                              # more (batch, head) items than CUs: the persistent kernel walks 2 items per workgroup
+                                              (30, 197, 12, False), (26, 133, 12, False), (44, 197, 12, False)])
 def test_attention_sweep_fwd_bwd(ops, B, S, heads, masked):
     """bsclip_attn_fwd2 / bsclip_attn_bwd2 (key-owner sweep, delta from the forward's 16-bit output): same bars as the two-phase
     kernels against the f32 torch reference, the same ctx bit for bit, and dqkv within bf16 rounding of the two-phase result."""

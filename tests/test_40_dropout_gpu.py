@@ -165,7 +165,8 @@ def test_attention_dropout_fwd_bwd(ops, B, S, heads, masked):
         assert rel_err(dqkv[:, sl].float(), gq[:, sl]) < 3e-2, name
 
 
-@pytest.mark.parametrize("B,S,heads,masked", [(2, 64, 2, False), (3, 20, 8, True), (2, 133, 3, False), (2, 197, 3, False)])
+@pytest.mark.parametrize("B,S,heads,masked", [(2, 64, 2, False), (3, 20, 8, True), (2, 133, 3, False), (2, 197, 3, False),
+                                              (25, 133, 12, False)])     # 300 items: the persistent kernel, 2 per workgroup
 def test_attention_sweep_dropout_matches_two_phase(ops, B, S, heads, masked):
     """bsclip_attn_fwd2 / bwd2 with attention-probs dropout: the same (seed, element) masks as the two-phase kernels -- the
     forward output is identical bit for bit -- and a gradient that agrees with theirs (which the test above holds to torch
