@@ -340,11 +340,12 @@ ev = torch.cuda.Event()
 ev.record()
 torch.cuda.synchronize()
 stop, polls, errors = threading.Event(), [0], []
-def poll():                      # what ProcessGroupNCCL's watchdog does with the Work objects it still lists
+def poll():                      # what ProcessGroupNCCL's watchdog does with the Work objects it still lists -- 2 000 x as often
     while not stop.is_set():
         try:
             ev.query()
             polls[0] += 1
+            time.sleep(5e-5)     # leave the GIL to the capturing thread (a bare spin made the capture take 90 s)
         except Exception as exc:  # noqa: BLE001
             errors.append(repr(exc))
             return
