@@ -63,13 +63,23 @@ class SimpleCLIP(nn.Module):
                 side = _tower_stream(k, cur.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side), forked_from(cur):
-                    # global-batch loss: this modality's all-gather starts here, ordered behind this tower's stream only
-                    y = start_gather(l2_normalize(enc(x)))
+                    y = l2_normalize(enc(x))
                 if not torch.cuda.is_current_stream_capturing():   # a capture's private pool owns the tensor's lifetime
                     y.record_stream(cur)
                 outs[k] = (y, side)
             else:
-                outs[k] = (start_gather(l2_normalize(enc(x))), None)
+                outs[k] = (l2_normalize(enc(x)), None)
+        # global-batch loss: every modality's all-gather starts here, each ordered behind ITS tower's stream only -- and issued
+        # shortest tower first (text, DNA, image): the process group runs its collectives on one stream in issue order, so a gather
+        # issued behind the image tower's would wait for the image tower (tools/dist_overlap_probe.py)
+        for k in (2, 0, 1):
+            if outs[k] is not None:
+                y, side = outs[k]
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        start_gather(y)
+                else:
+                    start_gather(y)
         for k in range(3):
             if outs[k] is not None:
                 y, side = outs[k]

@@ -39,8 +39,16 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr int ROWB = 128;  // bytes per row of a row-major [rows][64] bf16 tile
 constexpr int ATT_WAVES = 4;  // waves per workgroup; wave w owns 32-row blocks w, w+4, ...
 
-// Row-major tile, 16-B chunk index XOR-swizzled with (row>>1)&7: conflict-free ds_read_b128 for the 32x32x16 A operand.
-__device__ __forceinline__ int rm_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// Row-major tile of 128-byte rows, the 16-B chunk index XOR-swizzled with tile_sw(row).  Two rows share one 256-byte bank row; with
+// t = row >> 1 the swizzle is the bijection t -> (t >> 1) | ((t & 1) << 2) of 0..7 (round 3 used t itself):
+//   * ds_read_b128 (frag_rm): a 16-lane service group reads one chunk column of rows {0-3, 12-15, 20-27} (+ the analogous sets): the 8
+//     rows of one parity have 8 different t mod 8, hence 8 different chunk positions -- conflict-free, as before;
+//   * ds_read_b64_tr_b16 (frag_tr): a 32-lane group reads 4 aligned chunks of rows c0 .. c0 + 3; rows c0 and c0 + 2 share the half bank
+//     row and have t = 2u, 2u + 1: their swizzles differ in bit 2, so the two 4-chunk groups land in different halves of the row.
+//     With the identity they differed in bit 0 only -- the same four positions, a 2-way conflict on every transposing read (21 % of the
+//     LDS-active cycles of the attention kernels: profiles/r04_b_attn_pmc.txt).
+__device__ __forceinline__ int tile_sw(int row) { return ((row >> 2) & 3) | (((row >> 1) & 1) << 2); }
+__device__ __forceinline__ int rm_off(int row, int chunk) { return row * ROWB + ((chunk ^ tile_sw(row)) << 4); }
 
 // Stage a [S][64] bf16 matrix (row stride ld elements) into a row-major, XOR-swizzled LDS tile of SP rows with LDS-DMA
 // (global_load_lds_dwordx4: no staging registers, every piece in flight at once; the register-staged version issued its
@@ -57,7 +65,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int l
         const int chunk = wave + NWAVES * c;
         if (chunk < SP / 8) {
             const int row = 8 * chunk + r8;
-            const int lc = pc ^ ((row >> 1) & 7);
+            const int lc = pc ^ tile_sw(row);
             glds16(src + (size_t)min(row, S - 1) * ld + lc * 8, dst_rm + chunk * 1024);
         }
     }

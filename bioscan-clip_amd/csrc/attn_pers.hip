@@ -130,7 +130,7 @@ __global__ __launch_bounds__((NB + 1) * 64) void attn_bwd_pers_kernel(
     // one LDS-DMA piece: 8 rows (1 KiB) of a [S][64] bf16 matrix into a swizzled row-major tile (rows >= S repeat row S - 1)
     auto piece = [&](const bf16_t* src, int ldx, char* tile, int p) {
         const int row = 8 * p + (lane >> 3);
-        const int sc = (lane & 7) ^ ((row >> 1) & 7);
+        const int sc = (lane & 7) ^ tile_sw(row);
         glds16(src + (size_t)min(row, S - 1) * ldx + sc * 8, tile + p * 1024);
     };
     auto stat = [&](int n, int arr) { return sStat + ((n & 1) * NARR + arr) * SP; };

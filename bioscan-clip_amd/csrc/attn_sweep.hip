@@ -178,7 +178,7 @@ __global__ __launch_bounds__((NB + 1) * 64) void attn_bwd_sweep_kernel(
                 for (int pi = 0; pi < 2; ++pi) {
                     const int p = 2 * wave + pi;                       // 0-3: Q rows 8 (p & 3) .., 4-7: dO rows
                     const int chunk = 4 * xb + (p & 3), row = 8 * chunk + (lane >> 3);
-                    const int sc = (lane & 7) ^ ((row >> 1) & 7);
+                    const int sc = (lane & 7) ^ tile_sw(row);
                     if (p < 4) glds16(qb + (size_t)min(row, S - 1) * ld + sc * 8, sQ + chunk * 1024);
                     else glds16(dob + (size_t)min(row, S - 1) * ld_ctx + sc * 8, sDO + chunk * 1024);
                 }
