@@ -45,17 +45,27 @@ PATCH_SPLIT = os.environ.get("BSCLIP_PATCH_SPLIT", "1") != "0"
 # residual-gradient stream, split-bf16 patch embedding -- at the price bench.py reports as `parity_mode_ms_per_step`.  It is NOT
 # north_star's 1e-3: every trunk GEMM and the attention products still take bf16 operands (DESIGN.md 4 prices the split-bf16
 # form of those: 3 x the MFMA work of the step and hi / lo outputs from every producer kernel -- not built).
-if os.environ.get("BSCLIP_PARITY", "0") == "1":
+# BSCLIP_PARITY=2 / set_parity_mode(2): the EXACT forward (round 4, csrc/exact.hip) -- every trunk GEMM on split-bf16 operands
+# (hi + lo, K tripled: exact to ~2^-16 on the bf16 matrix cores), LoRA folded into the weight in f32, exact-erf GELU in f32,
+# attention in f32 on the vector ALU, f32 streams.  Embeddings within 1e-3 of the f32 reference at depth 12 (measured 2e-5 on the
+# CPU emulation before it was built, tests/test_20_encoders_gpu.py holds the GPU path to it); the backward is the default one on the
+# bf16 copies of this forward's activations.  LoRA-regime ViT / BERT engines only (fp8 and full fine-tuning keep their own paths).
+EXACT_FORWARD = False
+if os.environ.get("BSCLIP_PARITY", "0") in ("1", "2"):
     GRAD_STREAM_BF16 = RESID_STREAM_BF16 = False
     PATCH_SPLIT = True
+    EXACT_FORWARD = os.environ.get("BSCLIP_PARITY") == "2"
 
 
 def set_parity_mode(on, model=None):
-    """Switch the streams at run time (engines built afterwards pick it up; pass ``model`` to have its engines rebuilt at the next
-    forward).  Returns the previous (grad_stream_bf16, resid_stream_bf16) pair."""
-    global GRAD_STREAM_BF16, RESID_STREAM_BF16
+    """Switch at run time: 0 / False = default, 1 / True = f32 streams, 2 = f32 streams + the exact forward.  Engines built
+    afterwards pick it up; pass ``model`` to have its engines rebuilt at the next forward.  Returns the previous
+    (grad_stream_bf16, resid_stream_bf16) pair (restore with the module attributes; EXACT_FORWARD is reset by passing 0 / 1)."""
+    global GRAD_STREAM_BF16, RESID_STREAM_BF16, EXACT_FORWARD
     prev = (GRAD_STREAM_BF16, RESID_STREAM_BF16)
-    GRAD_STREAM_BF16 = RESID_STREAM_BF16 = not on
+    level = int(on)
+    GRAD_STREAM_BF16 = RESID_STREAM_BF16 = level == 0
+    EXACT_FORWARD = level == 2
     if model is not None:
         for m in model.modules():
             if getattr(m, "_engine", None) is not None:
@@ -206,6 +216,25 @@ class EncoderEngineBase:
 
     fp8 = False
 
+    # ------------------------------------------------------------------------------ exact forward (BSCLIP_PARITY=2)
+    def exact(self):
+        return EXACT_FORWARD and not self.fp8 and not self.full_ft
+
+    def _ex_weight(self, w_f32, lora=None):
+        """[hi | hi | lo] rows of a frozen f32 weight (LoRA folded in f32 when given: refreshed by the caller every step)."""
+        w = w_f32.detach().to(self.device, F32).contiguous()
+        dst = torch.empty(w.shape[0], 3 * w.shape[1], dtype=BF16, device=self.device)
+        if lora is None:
+            ops.split3_weight(w, dst)
+        return w, dst
+
+    def _ex_gemm(self, a_f32, w3, out, epi, scratch, M=None, **kw):
+        """out = epilogue(a_f32 @ W^T) with both operands split: a_f32 f32 [M, K] (row stride free) -> [hi | lo | hi] in ``scratch``."""
+        M = a_f32.shape[0] if M is None else M
+        K = w3.shape[1] // 3
+        a3 = ops.split3_rows(a_f32, scratch, M=M, K=K)
+        return ops.gemm(a3, w3, out, epi, M=M, K=3 * K, **kw)
+
     def _pack_fp8(self, lay, w_qkv, w_fc1, w_fc2, dev):
         """BASELINE configs[4]: the frozen QKV / fc1 / fc2 weights as OCP fp8 e4m3 with one scale per output row (row amax
         -> 448); activations are quantised with scale 1 by their producers (LayerNorm, GELU epilogue), so a GEMM's
@@ -249,6 +278,7 @@ class ViTEngine(EncoderEngineBase):
                 base = q
                 qv.append(None)
             lay.waug, lay.wqkv_t, lay.b_qkv = _pack_qkv(base.weight, base.bias, H, dev)
+            lay.src = (base.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight)   # f32 masters (exact forward)
             lay.ln1 = (_f32(blk.norm1.weight, dev), _f32(blk.norm1.bias, dev))
             lay.ln2 = (_f32(blk.norm2.weight, dev), _f32(blk.norm2.bias, dev))
             lay.w_proj, lay.w_proj_t, lay.b_proj = _pack_linear(blk.attn.proj, dev)
@@ -276,6 +306,12 @@ class ViTEngine(EncoderEngineBase):
         ws = {"B": B, "M": M, "gen": next(_WS_GEN)}
         ws["cols"] = z(B * 196, 3 * H if (PATCH_SPLIT and not self.full_ft) else H)
         rb = ws["resid_bf16"] = RESID_STREAM_BF16 and not self.full_ft and not self.fp8
+        if self.exact():
+            assert not rb and not GRAD_STREAM_BF16, "the exact forward runs on the f32 streams"
+            ws["y32"], ws["ctx32"], ws["cls32"] = z(M, H, dt=F32), z(M, H, dt=F32), z(B, H, dt=F32)
+            ws["qkv32"], ws["z32"] = z(M, 3 * H, dt=F32), z(M, FF, dt=F32)
+            ws["a3"] = z(M, 3 * FF)                                   # [hi | lo | hi] rows of the current GEMM's A operand
+            ws["whead3"] = z(self.out_dim, 3 * H)
         ws["x"] = [z(M, H, dt=BF16 if rb else F32) for _ in range(2 * L + 1)]   # residual stream after every sub-layer
         ws["h1"] = [z(M, H + KPAD) for _ in range(L)]                 # LN1 output + LoRA t (QKV operand)
         ws["st1"] = [z(M, 2, dt=F32) for _ in range(L)]
@@ -315,6 +351,49 @@ class ViTEngine(EncoderEngineBase):
         return ws
 
     # -------------------------------------------------------------------------------------------- forward
+    def _forward_exact(self, image, ws):
+        """BSCLIP_PARITY=2: the same block sequence with every Linear on split-bf16 operands, f32 attention, exact-erf GELU; the
+        tensors the (default) backward reads -- h1, qkv, lse, gelu' codes, LayerNorm statistics, the f32 residual stream -- are
+        written as that backward expects them."""
+        B, H, S, M, L, FF = image.shape[0], self.H, self.S, ws["M"], len(self.layers), self.FF
+        scale = 64 ** -0.5
+        x, a3, y32 = ws["x"], ws["a3"], ws["y32"]
+        for lay in self.layers:
+            if not hasattr(lay, "w3"):
+                lay.qkv32, lay.wqkv3 = self._ex_weight(lay.src[0], lora=True)
+                lay.w3 = [self._ex_weight(w)[1] for w in lay.src[1:]]   # proj, fc1, fc2
+        ops.im2col_patch16(image, ws["cols"])
+        ops.gemm(ws["cols"], self.w_patch3, x[0], EPI_PATCH_F32, bias=self.b_patch, resid=self.pos)
+        ops.vit_cls_rows(x[0], self.cls, self.pos, B, S, H)
+        tok0 = lambda t, w: t.view(B, S * w)[:, :w]
+        for l, lay in enumerate(self.layers):
+            has = self._lora_index[l] is not None
+            ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_bf16=ws["h1"][l], y_f32=y32, lora_a=self.lora_a(l),
+                              stats=ws["st1"][l])
+            ops.split3_weight(lay.qkv32, lay.wqkv3, lora_a=self.lora_a(l) if has else None, lora_b=self.lora_b(l) if has else None)
+            self._ex_gemm(y32, lay.wqkv3, ws["qkv32"], EPI_F32, a3, bias=lay.b_qkv)
+            ops.cast_f32_bf16(ws["qkv32"], ws["qkv"][l])
+            ops.attn_fwd_f32(ws["qkv32"], B, S, self.heads, scale, ws["ctx32"], ws["lse"][l])
+            if l == L - 1:   # token-0 rows only, as the default path (and as its backward expects)
+                self._ex_gemm(tok0(ws["ctx32"], H), lay.w3[0], tok0(x[2 * l + 1], H), EPI_RESID_F32, a3, bias=lay.b_proj,
+                              resid=tok0(x[2 * l], H))
+                ops.layernorm_fwd(tok0(x[2 * l + 1], H), lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2_c"], y_f32=ws["cls32"],
+                                  stats=ws["st_c"])
+                self._ex_gemm(ws["cls32"], lay.w3[1], ws["z32"], EPI_F32, a3, bias=lay.b_fc1)
+                g3 = ops.gelu_split3(ws["z32"], a3, codes=ws["z_c"], M=B)
+                ops.gemm(g3, lay.w3[2], tok0(x[2 * l + 2], H), EPI_RESID_F32, bias=lay.b_fc2, resid=tok0(x[2 * l + 1], H), M=B)
+                continue
+            self._ex_gemm(ws["ctx32"], lay.w3[0], x[2 * l + 1], EPI_RESID_F32, a3, bias=lay.b_proj, resid=x[2 * l])
+            ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2"], y_f32=y32, stats=ws["st2"][l])
+            self._ex_gemm(y32, lay.w3[1], ws["z32"], EPI_F32, a3, bias=lay.b_fc1)
+            g3 = ops.gelu_split3(ws["z32"], a3, codes=ws["z"][l])
+            ops.gemm(g3, lay.w3[2], x[2 * l + 2], EPI_RESID_F32, bias=lay.b_fc2, resid=x[2 * l + 1])
+        ops.layernorm_fwd(tok0(x[-1], H), self.ln_f[0], self.ln_f[1], 1e-6, y_bf16=ws["clsn"], y_f32=ws["cls32"], stats=ws["st_f"])
+        ops.split3_weight(self.extra(0), ws["whead3"])
+        out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
+        self._ex_gemm(ws["cls32"], ws["whead3"], out, EPI_F32, a3, bias=self.extra(1))
+        return out
+
     def forward(self, image):
         B = image.shape[0]
         ws = self._workspace(B)
@@ -322,6 +401,8 @@ class ViTEngine(EncoderEngineBase):
         scale = 64 ** -0.5
         self.refresh_lora_weights()
         ops.cast_f32_bf16(self.extra(0), self.w_head_bf)
+        if self.exact():
+            return self._forward_exact(image, ws)
         x = ws["x"]
         EPI_R, EPI_P = (EPI_RESID_BF16, EPI_PATCH_BF16) if ws["resid_bf16"] else (EPI_RESID_F32, EPI_PATCH_F32)
         ops.im2col_patch16(image, ws["cols"])
@@ -476,6 +557,7 @@ class BertEngine(EncoderEngineBase):
             w = torch.cat([qb.weight.detach(), k.weight.detach(), vb.weight.detach()], 0)
             b = torch.cat([qb.bias.detach(), k.bias.detach(), vb.bias.detach()], 0)
             lay.waug, lay.wqkv_t, lay.b_qkv = _pack_qkv(w, b, H, dev)
+            lay.src = (w, layer.attention.output.dense.weight, layer.intermediate.dense.weight, layer.output.dense.weight)   # f32 masters
             lay.w_o, lay.w_o_t, lay.b_o = _pack_linear(layer.attention.output.dense, dev)
             lay.ln_a = (_f32(layer.attention.output.LayerNorm.weight, dev), _f32(layer.attention.output.LayerNorm.bias, dev))
             lay.w_fc1, lay.w_fc1_t, lay.b_fc1 = _pack_linear(layer.intermediate.dense, dev)
@@ -489,6 +571,7 @@ class BertEngine(EncoderEngineBase):
         if head == "mlm_softmax_mean":
             tr, dec = head_modules
             self.w_tr, self.w_tr_t, self.b_tr = _pack_linear(tr.dense, dev)
+            self.src_tr = tr.dense.weight
             self.ln_t = (_f32(tr.LayerNorm.weight, dev), _f32(tr.LayerNorm.bias, dev))
             self.eps_t = float(tr.LayerNorm.eps)
             trainable = [dec.weight, dec.bias]
@@ -535,6 +618,12 @@ class BertEngine(EncoderEngineBase):
             ws["yb8"] = [z(M, H, dt=ops.FP8) for _ in range(L)]
             ws["t"] = [z(M, KPAD) for _ in range(L)]
             ws["ymb8"], ws["act8"] = z(M, H, dt=ops.FP8), z(M, FF, dt=ops.FP8)
+        if self.exact():
+            assert not rb and not GRAD_STREAM_BF16, "the exact forward runs on the f32 streams"
+            ws["ctx32"], ws["qkv32"], ws["z32"] = z(M, H, dt=F32), z(M, 3 * H, dt=F32), z(M, FF, dt=F32)
+            ws["a3"] = z(M, 3 * FF)
+            ws["whead3"] = z(self.out_dim, 3 * self.head_in)
+            ws["t32"], ws["mp32"] = z(M, H, dt=F32), z(B, H, dt=F32)
         ws["key_bias"] = None
         ws["kb_buf"] = z(B, S, dt=F32)
         # backward temporaries
@@ -604,6 +693,51 @@ class BertEngine(EncoderEngineBase):
             ops.counter_add(self._step_word, 1)
         ops.set_dropout_step(self._step_word)
 
+    def _forward_exact(self, ws, key_bias):
+        """BSCLIP_PARITY=2 (see ViTEngine._forward_exact): the layers after the embedding LayerNorm (which has just written the bf16
+        operand yb[0] and its f32 twin y) with every Linear on split-bf16 operands, f32 attention, exact-erf GELU; dropout sites and
+        seeds as in the default path."""
+        B, S, M, H, L, FF = ws["B"], ws["S"], ws["M"], self.H, len(self.layers), self.FF
+        a3 = ws["a3"]
+        for lay in self.layers:
+            if not hasattr(lay, "w3"):
+                lay.qkv32, lay.wqkv3 = self._ex_weight(lay.src[0], lora=True)
+                lay.w3 = [self._ex_weight(w)[1] for w in lay.src[1:]]   # attention output, intermediate, output
+        for l, lay in enumerate(self.layers):
+            has = self._lora_index[l] is not None
+            ops.split3_weight(lay.qkv32, lay.wqkv3, lora_a=self.lora_a(l) if has else None, lora_b=self.lora_b(l) if has else None)
+            self._ex_gemm(ws["y"], lay.wqkv3, ws["qkv32"], EPI_F32, a3, bias=lay.b_qkv)
+            ops.cast_f32_bf16(ws["qkv32"], ws["qkv"][l])
+            ops.attn_fwd_f32(ws["qkv32"], B, S, self.heads, 0.125, ws["ctx32"], ws["lse"][l], key_bias=key_bias,
+                             dropout=self._drop(ws, self.p_attn, l, 1))
+            self._ex_gemm(ws["ctx32"], lay.w3[0], ws["s1"][l], EPI_RESID_F32, a3, bias=lay.b_o, resid=ws["y"],
+                          dropout=self._drop(ws, self.p_hidden, l, 2))
+            ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ws["ymb"], y_f32=ws["ym"], stats=ws["sta"][l])
+            self._ex_gemm(ws["ym"], lay.w3[1], ws["z32"], EPI_F32, a3, bias=lay.b_fc1)
+            g3 = ops.gelu_split3(ws["z32"], a3, codes=ws["z"][l])
+            ops.gemm(g3, lay.w3[2], ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"],
+                     dropout=self._drop(ws, self.p_hidden, l, 3))
+            nxt = self.lora_a(l + 1) if l + 1 < L else self._zero_a
+            ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1], y_f32=ws["y"], lora_a=nxt,
+                              stats=ws["stb"][l])
+        out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
+        ops.split3_weight(self.extra(0), ws["whead3"])
+        if self.head == "mlm_softmax_mean":
+            if not hasattr(self, "w_tr3"):
+                self.w_tr3 = self._ex_weight(self.src_tr)[1]
+            self._ex_gemm(ws["y"], self.w_tr3, ws["z32"][:, :H], EPI_F32, a3, bias=self.b_tr)
+            ops.gelu_split3(ws["z32"][:, :H], None, codes=ws["tz"], g32=ws["t32"])          # the GELU feeds a LayerNorm: f32 out
+            ops.cast_f32_bf16(ws["t32"], ws["tg"])                                           # the backward's copy
+            ops.layernorm_fwd(ws["t32"], self.ln_t[0], self.ln_t[1], self.eps_t, y_bf16=ws["tn"], y_f32=ws["ym"], stats=ws["st_t"])
+            self._ex_gemm(ws["ym"], ws["whead3"], ws["logits"], EPI_F32, a3, bias=self.extra(1))
+            ops.softmax_meanpool_fwd(ws["logits"], B, S, out, ws["sm"])
+        else:
+            ops.meanpool_tokens_fwd(ws["y"], B, S, ws["mp"])                                 # the backward's bf16 copy
+            ops.meanpool_tokens_f32(ws["y"], B, S, ws["mp32"])
+            self._ex_gemm(ws["mp32"], ws["whead3"], out, EPI_F32, a3, bias=self.extra(1))
+        ops.set_dropout_step(None)
+        return out
+
     def forward(self, input_ids, token_type_ids=None, attention_mask=None):
         B, S = input_ids.shape
         ws = self._workspace(B, S)
@@ -637,6 +771,8 @@ class BertEngine(EncoderEngineBase):
                               lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0),
                               stats=ws["st_e"] if self.full_ft else None)
         ws["ids"], ws["type_ids"] = input_ids, token_type_ids
+        if self.exact():
+            return self._forward_exact(ws, key_bias)
         for l, lay in enumerate(self.layers):
             if f8:
                 ops.gemm_fp8(ws["yb8"][l], lay.w_qkv8, ws["qkv"][l], lay.s_qkv, lay.b_qkv, EPI_BF16, a_aug=ws["t"][l],

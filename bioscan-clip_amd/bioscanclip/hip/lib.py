@@ -58,6 +58,11 @@ SIGNATURES = {
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
     "bsclip_attn_fwd2": (I, [P, I, I, I, I, P, F, P, P, I, P, F, U, P]),
     "bsclip_attn_bwd2": (I, [P, I, P, I, P, P, I, P, I, I, I, P, F, P, I, F, U, P]),
+    "bsclip_split3_rows": (I, [P, I, I, I, P, I, P]),
+    "bsclip_split3_weight": (I, [P, I, I, I, P, P, I, P, I, P]),
+    "bsclip_gelu_split3": (I, [P, I, I, I, P, I, P, I, P, I, P]),
+    "bsclip_meanpool_tokens_f32": (I, [P, I, I, I, P, P]),
+    "bsclip_attn_fwd_f32": (I, [P, I, I, I, I, P, F, P, I, P, F, U, P]),
     "bsclip_im2col_patch16": (I, [P, I, P, I, I, P]),
     "bsclip_mask_to_bias": (I, [P, I, P, P]),
     "bsclip_vit_cls_rows": (I, [P, I, P, P, I, I, I, P]),

@@ -295,6 +295,69 @@ def attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, scale, dqkv, key_bias=
                                      _p(key_bias), float(scale), _p(dqkv), ld_d, dp, ds, _stream()))
 
 
+# ---- "exact" forward mode (BSCLIP_PARITY=2): split-bf16 operands for every trunk GEMM, f32 attention (csrc/exact.hip) ----
+def split3_rows(src, dst, M=None, K=None):
+    """f32 [M, K] -> bf16 [M, 3K] = [hi | lo | hi]: the A operand of a split-bf16 GEMM."""
+    M = src.shape[0] if M is None else M
+    K = src.shape[1] if K is None else K
+    _req(src.dtype == F32 and dst.dtype == BF16 and src.shape[0] >= M and src.shape[1] >= K and K % 4 == 0, "split3_rows: f32 [M, K]")
+    _req(dst.shape[0] >= M and dst.shape[1] >= 3 * K, "split3_rows: dst bf16 [M, 3K]")
+    check(_l.load().bsclip_split3_rows(_p(src), _rowmajor(src, "src"), M, K, _p(dst), _rowmajor(dst, "dst"), _stream()))
+    return dst[:M, :3 * K]
+
+
+def split3_weight(w, dst, lora_a=None, lora_b=None):
+    """f32 [N, K] (+ LoRA: W + B A on the q / v rows) -> bf16 [N, 3K] = [hi | hi | lo]: the B operand of a split-bf16 GEMM."""
+    N, K = w.shape
+    _req(w.dtype == F32 and w.is_contiguous() and dst.dtype == BF16 and dst.is_contiguous() and tuple(dst.shape) == (N, 3 * K),
+         "split3_weight: w f32 [N, K] -> dst bf16 [N, 3K]")
+    H = 0
+    if lora_a is not None:
+        H = K
+        _req(lora_a.dtype == F32 and lora_a.is_contiguous() and tuple(lora_a.shape) == (8, K) and N == 3 * K, "lora_a f32 [8, H], N = 3H")
+        _req(lora_b is not None and lora_b.dtype == F32 and lora_b.is_contiguous() and tuple(lora_b.shape) == (2, K, 4), "lora_b f32 [2,H,4]")
+    check(_l.load().bsclip_split3_weight(_p(w), K, N, K, _p(lora_a), _p(lora_b if lora_a is not None else None), H, _p(dst), 3 * K,
+                                         _stream()))
+    return dst
+
+
+def gelu_split3(z, dst=None, codes=None, g32=None, M=None):
+    """f32 pre-activation [M, N] -> exact GELU as bf16 [M, 3N] = [hi | lo | hi] (dst) and / or f32 [M, N] (g32), + the 8-bit gelu'
+    codes the backward reads."""
+    M = z.shape[0] if M is None else M
+    N = z.shape[1]
+    _req(z.dtype == F32 and N % 4 == 0 and (dst is not None or g32 is not None), "gelu_split3: z f32 [M, N], an output")
+    if dst is not None:
+        _req(dst.dtype == BF16 and dst.shape[0] >= M and dst.shape[1] >= 3 * N, "gelu_split3: dst bf16 [M, 3N]")
+    if g32 is not None:
+        _req(g32.dtype == F32 and g32.shape[0] >= M and g32.shape[1] >= N, "gelu_split3: g32 f32 [M, N]")
+    if codes is not None:
+        _req(codes.dtype == torch.uint8 and codes.shape[0] >= M and codes.shape[1] >= N, "gelu_split3: codes u8 [M, N]")
+    check(_l.load().bsclip_gelu_split3(_p(z), _rowmajor(z, "z"), M, N, _p(dst), 0 if dst is None else _rowmajor(dst, "dst"), _p(codes),
+                                       0 if codes is None else _rowmajor(codes, "codes"), _p(g32),
+                                       0 if g32 is None else _rowmajor(g32, "g32"), _stream()))
+    return None if dst is None else dst[:M, :3 * N]
+
+
+def meanpool_tokens_f32(x, B, S, out):
+    H = x.shape[1]
+    _req(x.dtype == F32 and x.is_contiguous() and x.shape[0] >= B * S and out.dtype == F32 and out.is_contiguous()
+         and out.shape[0] >= B and out.shape[1] == H, "meanpool_tokens_f32: x f32 [B*S,H], out f32 [B,H]")
+    check(_l.load().bsclip_meanpool_tokens_f32(_p(x), B, S, H, _p(out), _stream()))
+
+
+def attn_fwd_f32(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None):
+    ld_qkv, ld_ctx = _rowmajor(qkv, "qkv"), _rowmajor(ctx, "ctx")
+    _req(qkv.dtype == F32 and ctx.dtype == F32 and lse.dtype == F32, "attn_fwd_f32 dtypes")
+    _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64 and ctx.shape[0] >= B * S and ctx.shape[1] >= heads * 64
+         and lse.numel() >= B * heads * S, "attn_fwd_f32 shapes")
+    if key_bias is not None:
+        _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
+    dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
+    check(_l.load().bsclip_attn_fwd_f32(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), ld_ctx, _p(lse), dp, ds,
+                                        _stream()))
+
+
 def im2col_patch16(image, cols):
     B = image.shape[0]
     _req(image.dtype == F32 and image.is_contiguous() and tuple(image.shape[1:]) == (3, 224, 224), "image f32 [B,3,224,224]")

@@ -217,6 +217,29 @@ int bsclip_attn_bwd2(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx,
                      const float* stats, int B, int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
                      float dropout_p, uint32_t dropout_seed, void* stream);
 
+/* ---- "exact" forward mode (BSCLIP_PARITY=2; csrc/exact.hip): every trunk GEMM on split-bf16 operands, f32 attention -----------
+ * A bf16 MFMA GEMM is exact to ~2^-16 when both operands are carried as hi + lo (hi = bf16(x), lo = bf16(x - hi)) and the product is
+ * formed as hi.hi + lo.hi + hi.lo: ONE bsclip_gemm_bf16 call with K tripled, A rows [hi | lo | hi] against W rows [hi | hi | lo].
+ *   split3_rows:   src f32 [M, ld_src >= K] -> dst bf16 [M, ld_dst >= 3K] = [hi | lo | hi]   (K % 4 == 0)
+ *   split3_weight: w f32 [N, K] -> dst bf16 [N, 3K] = [hi | hi | lo]; with lora_a f32 [8, K] (A_q rows 0..3, A_v rows 4..7) and lora_b
+ *                  f32 [2, H, 4] the LoRA update is folded in f32 first (reference image_encoder.py:43-47, dna_encoder.py:47-49):
+ *                  rows [0, H) += B_q A_q, rows [2H, 3H) += B_v A_v  (N = 3H, K = H)
+ *   gelu_split3:   z f32 [M, N] -> exact (erf) GELU as bf16 [M, 3N] = [hi | lo | hi] (dst nullable) and / or as f32 [M, ld_g32] (g32
+ *                  nullable; the MLM transform's GELU feeds a LayerNorm, not a GEMM); codes (nullable) u8 [M, ld_codes]: the 8-bit
+ *                  gelu' side band the default backward reads
+ *   meanpool_tokens_f32: x f32 [B*S, H] -> out f32 [B, H], the mean over each sequence's S tokens (language_encoder.py:89)
+ *   attn_fwd_f32:  qkv f32 [B*S, ld_qkv] ([q | k | v], heads*64 each) -> ctx f32 [B*S, ld_ctx], lse f32 [B, heads, S]; f32 arithmetic
+ *                  on the vector ALU, the bf16 kernels' dropout masks; argument meaning as bsclip_attn_fwd.  The backward is
+ *                  bsclip_attn_bwd on the bf16 copies. */
+int bsclip_split3_rows(const float* src, int ld_src, int M, int K, void* dst, int ld_dst, void* stream);
+int bsclip_split3_weight(const float* w, int ld_w, int N, int K, const float* lora_a, const float* lora_b, int H, void* dst, int ld_dst,
+                         void* stream);
+int bsclip_gelu_split3(const float* z, int ld_z, int M, int N, void* dst, int ld_dst, void* codes, int ld_codes, float* g32, int ld_g32,
+                       void* stream);
+int bsclip_meanpool_tokens_f32(const float* x, int B, int S, int H, float* out, void* stream);
+int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, float* ctx, int ld_ctx,
+                        float* lse, float dropout_p, uint32_t dropout_seed, void* stream);
+
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column
  * order (c, ky, kx) = conv weight.flatten(1).  cls rows: x[b*197] = cls + pos[0].

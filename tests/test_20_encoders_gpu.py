@@ -189,6 +189,55 @@ def test_parity_mode_against_the_f32_oracle(which, monkeypatch):
     assert worst < TOL[name][1] / 1.3, worst    # in both towers the gradients are closer than the default configuration's
 
 
+@pytest.mark.parametrize("which", ["vit_L12", "dna_L12", "txt_L4", "vit_L2"])
+def test_exact_forward_meets_north_star_tolerance(which, monkeypatch):
+    """BSCLIP_PARITY=2 (hip/engine.py EXACT_FORWARD, csrc/exact.hip): every trunk GEMM on split-bf16 operands (hi + lo, K tripled),
+    LoRA folded in f32, exact-erf GELU, f32 attention, f32 streams.  north_star: "outputs (embeddings ...) match the reference CPU
+    path within 1e-3" -- here the embeddings of the full-depth encoders against the f32 oracle AND the golden fixtures the imported
+    reference produced, at 1e-3 (measured: see the log line / DESIGN.md 4).  The backward is the default one on the bf16 copies of
+    this forward's activations: its gradients are held to the default configuration's bar (and logged)."""
+    from bioscanclip.hip import engine
+    from bioscanclip.model import arch
+    monkeypatch.setattr(engine, "RESID_STREAM_BF16", False)
+    monkeypatch.setattr(engine, "GRAD_STREAM_BF16", False)
+    monkeypatch.setattr(engine, "EXACT_FORWARD", True)
+    gold_all = load_golden("encoders")
+    if which.startswith("vit"):
+        depth = int(which[5:])
+        from bioscanclip.model.image_encoder import LoRA_ViT_timm
+        m, prefix, seed = LoRA_ViT_timm(arch.VisionTransformerParams(depth=depth), r=4, num_classes=768), "image_encoder.", 13
+        x, _, _, _ = synth.synth_batch(2, seed=23)
+        fn, cot, hip_in, gkey = (lambda s: refcpu.vit_encoder(s, x)), f"vit.cot.{depth}", x.cuda(), f"vit.out.{depth}"
+    elif which == "dna_L12":
+        from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+        m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=12, **NODROP)), r=4, num_classes=768)
+        prefix, seed = "dna_encoder.", 11
+        _, x, _, _ = synth.synth_batch(2, seed=21)
+        fn, cot, hip_in, gkey = (lambda s: refcpu.barcode_bert_encoder(s, x)), "dna.cot.12", x.cuda(), "dna.out.12"
+    else:
+        from bioscanclip.model.language_encoder import LoRA_bert
+        m = LoRA_bert(arch.BertModelParams(arch.bert_small_config(**NODROP)), r=4, num_classes=768)
+        prefix, seed = "language_encoder.", 12
+        _, _, text, _ = synth.synth_batch(4, seed=22, with_text=True)
+        fn, cot, hip_in, gkey = (lambda s: refcpu.bert_text_encoder(s, text)), "txt.cot", {k: v.cuda() for k, v in text.items()}, "txt.out"
+    sd = _load(m, prefix, seed)
+    m.to("cuda").train()
+    y = m(hip_in)
+    assert m._engine.exact()
+    w = synth.synth_tensor(cot, y.shape, seed=5)
+    (y * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    sdo, keys, yo = _oracle_grads(sd, fn)
+    (yo * w).sum().backward()
+    named = dict(m.named_parameters())
+    e = rel_err(y, yo)
+    worst = max(rel_err(named[k[len(prefix):]].grad, sdo[k].grad) for k in keys)
+    _log({"test": f"exact_forward_{which}", "emb_vs_f32_oracle": e, "worst_grad": worst})
+    assert e < 1e-3, e                                                   # north_star's tolerance, on the embeddings
+    check_summary(gkey, y, gold_all[which]["out"], 1e-3, what=which + " exact ")   # ... and against the imported reference's own output
+    assert worst < TOL[which][1], worst                                  # gradients: the default backward, not worse than the default's bar
+
+
 def _build_clip(with_text, seed):
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
