@@ -49,3 +49,19 @@ def run_smoke():
     # rounds at the same points the embeddings agree to a few 1e-3 (measured 6.77e-3 / 2.54e-3)
     assert e_img < 1.37e-2 and e_dna < 7.1e-3 and e_loss < 1.8e-3 and e_par < 1.17e-2, "HIP step disagrees with the CPU oracle"
     assert q_img < 8.8e-3 and q_dna < 3.3e-3, "HIP step disagrees with the bf16-rounding-aware oracle"
+
+    # the exact forward (BSCLIP_PARITY=2: split-bf16 operands on every trunk GEMM, f32 attention, exact GELU): north_star's 1e-3
+    from bioscanclip.hip import engine
+    prev = engine.set_parity_mode(2, model)
+    try:
+        model.load_state_dict(sd)            # the step above moved the trainable tensors: back to the oracle's starting point
+        with torch.no_grad():
+            xi, xd, _ = model(image.cuda(), ids.cuda(), None)
+        torch.cuda.synchronize()
+        x_img = ((xi.cpu() - ri).norm() / ri.norm()).item()
+        x_dna = ((xd.cpu() - rd).norm() / rd.norm()).item()
+        print(f"smoke: exact forward (BSCLIP_PARITY=2) rel err vs f32 oracle: img {x_img:.2e} dna {x_dna:.2e}")
+        assert x_img < 1e-3 and x_dna < 1e-3, "exact forward misses north_star's 1e-3"
+    finally:
+        engine.set_parity_mode(0, model)
+        engine.GRAD_STREAM_BF16, engine.RESID_STREAM_BF16 = prev
