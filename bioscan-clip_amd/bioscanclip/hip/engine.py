@@ -235,6 +235,27 @@ class EncoderEngineBase:
         a3 = ops.split3_rows(a_f32, scratch, M=M, K=K)
         return ops.gemm(a3, w3, out, epi, M=M, K=3 * K, **kw)
 
+    def _ex_weight_t(self, w_f32):
+        """[hi | hi | lo] rows of the TRANSPOSE of a frozen f32 weight [N, K] -> bf16 [K, 3N]: the B operand of its dX GEMM."""
+        w = w_f32.detach().to(self.device, F32).contiguous()
+        N, K = w.shape
+        assert N % 64 == 0
+        return ops.split3_transpose(w, torch.empty(K * 3 * N, dtype=BF16, device=self.device), 1)
+
+    def _ex_dw(self, dy, x, gw, ws, M=None):
+        """gw[N, K] += dy[M, N]^T x[M, K], f32 operands split along the reduction (the M rows, zero-padded to a multiple of 64)."""
+        M = dy.shape[0] if M is None else M
+        a = ops.split3_transpose(dy, ws["t3a"], 0, R=M)
+        b = ops.split3_transpose(x, ws["t3b"], 1, R=M)
+        ops.gemm(a, b, gw, EPI_RESID_F32, resid=gw)
+
+    def _ex_backward_weights(self):
+        """Transposed split weights of the frozen Linears (once) and the buffer of the LoRA-folded QKV transpose (refilled every step)."""
+        for lay in self.layers:
+            if not hasattr(lay, "w3t"):
+                lay.w3t = [self._ex_weight_t(w) for w in lay.src[1:]]
+                lay.wqkvT3 = torch.empty(self.H * 9 * self.H, dtype=BF16, device=self.device)
+
     def _pack_fp8(self, lay, w_qkv, w_fc1, w_fc2, dev):
         """BASELINE configs[4]: the frozen QKV / fc1 / fc2 weights as OCP fp8 e4m3 with one scale per output row (row amax
         -> 448); activations are quantised with scale 1 by their producers (LayerNorm, GELU epilogue), so a GEMM's
@@ -308,10 +329,18 @@ class ViTEngine(EncoderEngineBase):
         rb = ws["resid_bf16"] = RESID_STREAM_BF16 and not self.full_ft and not self.fp8
         if self.exact():
             assert not rb and not GRAD_STREAM_BF16, "the exact forward runs on the f32 streams"
-            ws["y32"], ws["ctx32"], ws["cls32"] = z(M, H, dt=F32), z(M, H, dt=F32), z(B, H, dt=F32)
-            ws["qkv32"], ws["z32"] = z(M, 3 * H, dt=F32), z(M, FF, dt=F32)
+            # per layer, all f32: LN1 output, q | k | v, attention output, fc1 pre-activation -- what the exact backward reads
+            ws["y32s"], ws["ctx32s"] = [z(M, H, dt=F32) for _ in range(L)], [z(M, H, dt=F32) for _ in range(L)]
+            ws["qkv32s"] = [z(M, 3 * H, dt=F32) for _ in range(L)]
+            ws["z32s"] = [z(M if l < L - 1 else B, FF, dt=F32) for l in range(L)]
+            ws["y32"], ws["cls32"] = z(M, H, dt=F32), z(B, H, dt=F32)
             ws["a3"] = z(M, 3 * FF)                                   # [hi | lo | hi] rows of the current GEMM's A operand
             ws["whead3"] = z(self.out_dim, 3 * H)
+            Bq = _pad64(B)
+            ws["g32"], ws["dh32"], ws["dctx32"], ws["dqkv32"] = z(M, FF, dt=F32), z(M, H, dt=F32), z(M, H, dt=F32), z(M, 3 * H, dt=F32)
+            ws["dcls32"] = z(B, H, dt=F32)
+            ws["t3a"], ws["t3b"] = z(self.out_dim * 3 * Bq), z(H * 3 * Bq)         # dW operands of the head
+            ws["wheadT3"] = z(H * 3 * self.out_dim)
         ws["x"] = [z(M, H, dt=BF16 if rb else F32) for _ in range(2 * L + 1)]   # residual stream after every sub-layer
         ws["h1"] = [z(M, H + KPAD) for _ in range(L)]                 # LN1 output + LoRA t (QKV operand)
         ws["st1"] = [z(M, 2, dt=F32) for _ in range(L)]
@@ -352,12 +381,12 @@ class ViTEngine(EncoderEngineBase):
 
     # -------------------------------------------------------------------------------------------- forward
     def _forward_exact(self, image, ws):
-        """BSCLIP_PARITY=2: the same block sequence with every Linear on split-bf16 operands, f32 attention, exact-erf GELU; the
-        tensors the (default) backward reads -- h1, qkv, lse, gelu' codes, LayerNorm statistics, the f32 residual stream -- are
-        written as that backward expects them."""
+        """BSCLIP_PARITY=2: the same block sequence with every Linear on split-bf16 operands, f32 attention, exact-erf GELU; what
+        ``_backward_exact`` reads -- per layer the f32 LN1 output, q | k | v, attention output and fc1 pre-activation, the
+        LayerNorm statistics, lse, the f32 residual stream -- stays resident."""
         B, H, S, M, L, FF = image.shape[0], self.H, self.S, ws["M"], len(self.layers), self.FF
         scale = 64 ** -0.5
-        x, a3, y32 = ws["x"], ws["a3"], ws["y32"]
+        x, a3 = ws["x"], ws["a3"]
         for lay in self.layers:
             if not hasattr(lay, "w3"):
                 lay.qkv32, lay.wqkv3 = self._ex_weight(lay.src[0], lora=True)
@@ -368,25 +397,25 @@ class ViTEngine(EncoderEngineBase):
         tok0 = lambda t, w: t.view(B, S * w)[:, :w]
         for l, lay in enumerate(self.layers):
             has = self._lora_index[l] is not None
+            y32, qkv32, ctx32, z32 = ws["y32s"][l], ws["qkv32s"][l], ws["ctx32s"][l], ws["z32s"][l]
             ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_bf16=ws["h1"][l], y_f32=y32, lora_a=self.lora_a(l),
                               stats=ws["st1"][l])
             ops.split3_weight(lay.qkv32, lay.wqkv3, lora_a=self.lora_a(l) if has else None, lora_b=self.lora_b(l) if has else None)
-            self._ex_gemm(y32, lay.wqkv3, ws["qkv32"], EPI_F32, a3, bias=lay.b_qkv)
-            ops.cast_f32_bf16(ws["qkv32"], ws["qkv"][l])
-            ops.attn_fwd_f32(ws["qkv32"], B, S, self.heads, scale, ws["ctx32"], ws["lse"][l])
+            self._ex_gemm(y32, lay.wqkv3, qkv32, EPI_F32, a3, bias=lay.b_qkv)
+            ops.attn_fwd_f32(qkv32, B, S, self.heads, scale, ctx32, ws["lse"][l])
             if l == L - 1:   # token-0 rows only, as the default path (and as its backward expects)
-                self._ex_gemm(tok0(ws["ctx32"], H), lay.w3[0], tok0(x[2 * l + 1], H), EPI_RESID_F32, a3, bias=lay.b_proj,
+                self._ex_gemm(tok0(ctx32, H), lay.w3[0], tok0(x[2 * l + 1], H), EPI_RESID_F32, a3, bias=lay.b_proj,
                               resid=tok0(x[2 * l], H))
                 ops.layernorm_fwd(tok0(x[2 * l + 1], H), lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2_c"], y_f32=ws["cls32"],
                                   stats=ws["st_c"])
-                self._ex_gemm(ws["cls32"], lay.w3[1], ws["z32"], EPI_F32, a3, bias=lay.b_fc1)
-                g3 = ops.gelu_split3(ws["z32"], a3, codes=ws["z_c"], M=B)
+                self._ex_gemm(ws["cls32"], lay.w3[1], z32, EPI_F32, a3, bias=lay.b_fc1)
+                g3 = ops.gelu_split3(z32, a3, M=B)
                 ops.gemm(g3, lay.w3[2], tok0(x[2 * l + 2], H), EPI_RESID_F32, bias=lay.b_fc2, resid=tok0(x[2 * l + 1], H), M=B)
                 continue
-            self._ex_gemm(ws["ctx32"], lay.w3[0], x[2 * l + 1], EPI_RESID_F32, a3, bias=lay.b_proj, resid=x[2 * l])
-            ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2"], y_f32=y32, stats=ws["st2"][l])
-            self._ex_gemm(y32, lay.w3[1], ws["z32"], EPI_F32, a3, bias=lay.b_fc1)
-            g3 = ops.gelu_split3(ws["z32"], a3, codes=ws["z"][l])
+            self._ex_gemm(ctx32, lay.w3[0], x[2 * l + 1], EPI_RESID_F32, a3, bias=lay.b_proj, resid=x[2 * l])
+            ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2"], y_f32=ws["y32"], stats=ws["st2"][l])
+            self._ex_gemm(ws["y32"], lay.w3[1], z32, EPI_F32, a3, bias=lay.b_fc1)
+            g3 = ops.gelu_split3(z32, a3)
             ops.gemm(g3, lay.w3[2], x[2 * l + 2], EPI_RESID_F32, bias=lay.b_fc2, resid=x[2 * l + 1])
         ops.layernorm_fwd(tok0(x[-1], H), self.ln_f[0], self.ln_f[1], 1e-6, y_bf16=ws["clsn"], y_f32=ws["cls32"], stats=ws["st_f"])
         ops.split3_weight(self.extra(0), ws["whead3"])
@@ -453,6 +482,8 @@ class ViTEngine(EncoderEngineBase):
 
     # ------------------------------------------------------------------------------------------- backward
     def backward(self, dout):
+        if self.exact():
+            return self._backward_exact(dout)
         ws = self.ws
         B, M, H, S = ws["B"], ws["M"], self.H, self.S
         scale = 64 ** -0.5
@@ -516,6 +547,50 @@ class ViTEngine(EncoderEngineBase):
                                   dt=ws["dt"] if lb is not None else None,
                                   lora_a=self.lora_a(l) if lb is not None else None, dx_f32=None if g16 else dx, dx_bf16=dxb)
 
+
+    def _backward_exact(self, dout):
+        """BSCLIP_PARITY=2: the backward of ``_forward_exact`` with every gradient in f32 -- dX GEMMs on split operands against the
+        transposed split weights (LoRA folded: W + B A), exact gelu' from the f32 pre-activation, f32 attention backward, f32 LoRA
+        gradients, the head's dW on operands split along the batch."""
+        ws = self.ws
+        B, M, H, S, L = ws["B"], ws["M"], self.H, self.S, len(self.layers)
+        scale = 64 ** -0.5
+        self.flat.bind_grads()
+        self._ex_backward_weights()
+        x, dx, a3 = ws["x"], ws["dx"], ws["a3"]
+        tok0 = lambda t, w: t.view(B, S * w)[:, :w]
+        dout = dout.contiguous()
+        self._ex_dw(dout, ws["cls32"], self.extra(0, grad=True), ws)            # cls32 = the final LayerNorm's f32 output
+        ops.colsum(dout, B, self.out_dim, self.extra(1, grad=True))
+        self._ex_gemm(dout, ops.split3_transpose(self.extra(0), ws["wheadT3"], 1), ws["dcls32"], EPI_F32, a3)
+        dx.zero_()
+        dx_c = tok0(dx, H)
+        ops.layernorm_bwd(tok0(x[-1], H), ws["st_f"], self.ln_f[0], 0, g_gemm=ws["dcls32"], dx_f32=dx_c)
+        for l in range(L - 1, -1, -1):
+            lay = self.layers[l]
+            if l == L - 1:    # token-0 rows only (see backward)
+                self._ex_gemm(dx_c, lay.w3t[2], ws["g32"], EPI_F32, a3, M=B)
+                g3 = ops.dgelu_split3(ws["g32"], ws["z32s"][l], dst=a3, M=B)
+                ops.gemm(g3, lay.w3t[1], ws["dh32"], EPI_F32, M=B)
+                ops.layernorm_bwd(tok0(x[2 * l + 1], H), ws["st_c"], lay.ln2[0], 0, g_resid=dx_c, g_gemm=ws["dh32"], dx_f32=dx_c, M=B)
+                ws["dctx32"].zero_()
+                self._ex_gemm(dx_c, lay.w3t[0], tok0(ws["dctx32"], H), EPI_F32, a3, M=B)
+            else:
+                self._ex_gemm(dx, lay.w3t[2], ws["g32"], EPI_F32, a3)
+                g3 = ops.dgelu_split3(ws["g32"], ws["z32s"][l], dst=a3)
+                ops.gemm(g3, lay.w3t[1], ws["dh32"], EPI_F32)
+                ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh32"], dx_f32=dx)
+                self._ex_gemm(dx, lay.w3t[0], ws["dctx32"], EPI_F32, a3)
+            ops.attn_bwd_f32(ws["qkv32s"][l], ws["dctx32"], ws["ctx32s"][l], ws["lse"][l], B, S, self.heads, scale, ws["dqkv32"])
+            has = self._lora_index[l] is not None
+            if has:
+                ops.lora_grad_f32(ws["dqkv32"], ws["y32s"][l], M, H, self.lora_a(l), self.lora_b(l), self.lora_a(l, grad=True),
+                                  self.lora_b(l, grad=True))
+            if l > 0:  # nothing trainable sits below block 0
+                wt = ops.split3_transpose(lay.qkv32, lay.wqkvT3, 1, lora_a=self.lora_a(l) if has else None,
+                                          lora_b=self.lora_b(l) if has else None)
+                self._ex_gemm(ws["dqkv32"], wt, ws["dh32"], EPI_F32, a3)
+                ops.layernorm_bwd(x[2 * l], ws["st1"][l], lay.ln1[0], 0, g_resid=dx, g_gemm=ws["dh32"], dx_f32=dx)
 
 # ======================================================================================================= BERT
 class BertEngine(EncoderEngineBase):
@@ -620,10 +695,21 @@ class BertEngine(EncoderEngineBase):
             ws["ymb8"], ws["act8"] = z(M, H, dt=ops.FP8), z(M, FF, dt=ops.FP8)
         if self.exact():
             assert not rb and not GRAD_STREAM_BF16, "the exact forward runs on the f32 streams"
-            ws["ctx32"], ws["qkv32"], ws["z32"] = z(M, H, dt=F32), z(M, 3 * H, dt=F32), z(M, FF, dt=F32)
+            # per layer, all f32: the layer input (ys[l]; ys[L] = the last hidden state), q | k | v, attention output, intermediate
+            # pre-activation -- what the exact backward reads
+            ws["ys"] = [ws["y"]] + [z(M, H, dt=F32) for _ in range(L)]
+            ws["ctx32s"], ws["qkv32s"] = [z(M, H, dt=F32) for _ in range(L)], [z(M, 3 * H, dt=F32) for _ in range(L)]
+            ws["z32s"] = [z(M, FF, dt=F32) for _ in range(L)]
             ws["a3"] = z(M, 3 * FF)
             ws["whead3"] = z(self.out_dim, 3 * self.head_in)
             ws["t32"], ws["mp32"] = z(M, H, dt=F32), z(B, H, dt=F32)
+            ws["g32"], ws["dh32"], ws["dctx32"], ws["dqkv32"] = z(M, FF, dt=F32), z(M, H, dt=F32), z(M, H, dt=F32), z(M, 3 * H, dt=F32)
+            ws["dop32"] = z(M, H, dt=F32)                       # a dX GEMM's operand when it carries a dropout mask
+            ws["wheadT3"] = z(self.head_in * 3 * self.out_dim)
+            rows = _pad64(M if self.head == "mlm_softmax_mean" else B)   # the head's dW reduces over tokens (MLM decoder) or sequences
+            ws["t3a"], ws["t3b"] = z(self.out_dim * 3 * rows), z(self.head_in * 3 * rows)
+            if self.head == "mlm_softmax_mean":
+                ws["tz32"], ws["tn32"], ws["dlog32"] = z(M, H, dt=F32), z(M, H, dt=F32), z(M, self.out_dim, dt=F32)
         ws["key_bias"] = None
         ws["kb_buf"] = z(B, S, dt=F32)
         # backward temporaries
@@ -694,49 +780,100 @@ class BertEngine(EncoderEngineBase):
         ops.set_dropout_step(self._step_word)
 
     def _forward_exact(self, ws, key_bias):
-        """BSCLIP_PARITY=2 (see ViTEngine._forward_exact): the layers after the embedding LayerNorm (which has just written the bf16
-        operand yb[0] and its f32 twin y) with every Linear on split-bf16 operands, f32 attention, exact-erf GELU; dropout sites and
-        seeds as in the default path."""
+        """BSCLIP_PARITY=2 (see ViTEngine._forward_exact): the layers after the embedding LayerNorm (which has just written the f32
+        layer input ys[0]) with every Linear on split-bf16 operands, f32 attention, exact-erf GELU; dropout sites and seeds as in
+        the default path; what ``_backward_exact`` reads stays resident in f32."""
         B, S, M, H, L, FF = ws["B"], ws["S"], ws["M"], self.H, len(self.layers), self.FF
-        a3 = ws["a3"]
+        a3, ys = ws["a3"], ws["ys"]
         for lay in self.layers:
             if not hasattr(lay, "w3"):
                 lay.qkv32, lay.wqkv3 = self._ex_weight(lay.src[0], lora=True)
                 lay.w3 = [self._ex_weight(w)[1] for w in lay.src[1:]]   # attention output, intermediate, output
         for l, lay in enumerate(self.layers):
             has = self._lora_index[l] is not None
+            qkv32, ctx32, z32 = ws["qkv32s"][l], ws["ctx32s"][l], ws["z32s"][l]
             ops.split3_weight(lay.qkv32, lay.wqkv3, lora_a=self.lora_a(l) if has else None, lora_b=self.lora_b(l) if has else None)
-            self._ex_gemm(ws["y"], lay.wqkv3, ws["qkv32"], EPI_F32, a3, bias=lay.b_qkv)
-            ops.cast_f32_bf16(ws["qkv32"], ws["qkv"][l])
-            ops.attn_fwd_f32(ws["qkv32"], B, S, self.heads, 0.125, ws["ctx32"], ws["lse"][l], key_bias=key_bias,
+            self._ex_gemm(ys[l], lay.wqkv3, qkv32, EPI_F32, a3, bias=lay.b_qkv)
+            ops.attn_fwd_f32(qkv32, B, S, self.heads, 0.125, ctx32, ws["lse"][l], key_bias=key_bias,
                              dropout=self._drop(ws, self.p_attn, l, 1))
-            self._ex_gemm(ws["ctx32"], lay.w3[0], ws["s1"][l], EPI_RESID_F32, a3, bias=lay.b_o, resid=ws["y"],
+            self._ex_gemm(ctx32, lay.w3[0], ws["s1"][l], EPI_RESID_F32, a3, bias=lay.b_o, resid=ys[l],
                           dropout=self._drop(ws, self.p_hidden, l, 2))
             ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ws["ymb"], y_f32=ws["ym"], stats=ws["sta"][l])
-            self._ex_gemm(ws["ym"], lay.w3[1], ws["z32"], EPI_F32, a3, bias=lay.b_fc1)
-            g3 = ops.gelu_split3(ws["z32"], a3, codes=ws["z"][l])
+            self._ex_gemm(ws["ym"], lay.w3[1], z32, EPI_F32, a3, bias=lay.b_fc1)
+            g3 = ops.gelu_split3(z32, a3)
             ops.gemm(g3, lay.w3[2], ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"],
                      dropout=self._drop(ws, self.p_hidden, l, 3))
-            nxt = self.lora_a(l + 1) if l + 1 < L else self._zero_a
-            ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1], y_f32=ws["y"], lora_a=nxt,
-                              stats=ws["stb"][l])
+            ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1], y_f32=ys[l + 1],
+                              lora_a=self._zero_a, stats=ws["stb"][l])
         out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
         ops.split3_weight(self.extra(0), ws["whead3"])
         if self.head == "mlm_softmax_mean":
             if not hasattr(self, "w_tr3"):
                 self.w_tr3 = self._ex_weight(self.src_tr)[1]
-            self._ex_gemm(ws["y"], self.w_tr3, ws["z32"][:, :H], EPI_F32, a3, bias=self.b_tr)
-            ops.gelu_split3(ws["z32"][:, :H], None, codes=ws["tz"], g32=ws["t32"])          # the GELU feeds a LayerNorm: f32 out
-            ops.cast_f32_bf16(ws["t32"], ws["tg"])                                           # the backward's copy
-            ops.layernorm_fwd(ws["t32"], self.ln_t[0], self.ln_t[1], self.eps_t, y_bf16=ws["tn"], y_f32=ws["ym"], stats=ws["st_t"])
-            self._ex_gemm(ws["ym"], ws["whead3"], ws["logits"], EPI_F32, a3, bias=self.extra(1))
+            self._ex_gemm(ys[L], self.w_tr3, ws["tz32"], EPI_F32, a3, bias=self.b_tr)
+            ops.gelu_split3(ws["tz32"], None, g32=ws["t32"])                                # the GELU feeds a LayerNorm: f32 out
+            ops.layernorm_fwd(ws["t32"], self.ln_t[0], self.ln_t[1], self.eps_t, y_bf16=ws["tn"], y_f32=ws["tn32"], stats=ws["st_t"])
+            self._ex_gemm(ws["tn32"], ws["whead3"], ws["logits"], EPI_F32, a3, bias=self.extra(1))
             ops.softmax_meanpool_fwd(ws["logits"], B, S, out, ws["sm"])
         else:
-            ops.meanpool_tokens_fwd(ws["y"], B, S, ws["mp"])                                 # the backward's bf16 copy
-            ops.meanpool_tokens_f32(ws["y"], B, S, ws["mp32"])
+            ops.meanpool_tokens_f32(ys[L], B, S, ws["mp32"])
             self._ex_gemm(ws["mp32"], ws["whead3"], out, EPI_F32, a3, bias=self.extra(1))
         ops.set_dropout_step(None)
         return out
+
+    def _backward_exact(self, dout):
+        """BSCLIP_PARITY=2: the backward of ``_forward_exact`` in f32 (see ViTEngine._backward_exact); post-LN residuals and the
+        dropout sites as in ``backward``."""
+        ws = self.ws
+        B, S, M, H, L = ws["B"], ws["S"], ws["M"], self.H, len(self.layers)
+        self.flat.bind_grads()
+        self._begin_dropout(ws, advance=False)
+        self._ex_backward_weights()
+        a3, ys = ws["a3"], ws["ys"]
+        gw, gb = self.extra(0, grad=True), self.extra(1, grad=True)
+        dout = dout.contiguous()
+        wt_head = ops.split3_transpose(self.extra(0), ws["wheadT3"], 1)
+        if self.head == "mlm_softmax_mean":
+            if not hasattr(self, "w_tr3t"):
+                self.w_tr3t = self._ex_weight_t(self.src_tr)
+            ops.softmax_meanpool_bwd_f32(ws["logits"], ws["sm"], dout, B, S, ws["dlog32"])
+            self._ex_dw(ws["dlog32"], ws["tn32"], gw, ws)
+            ops.colsum(ws["dlog32"], M, self.out_dim, gb)
+            self._ex_gemm(ws["dlog32"], wt_head, ws["dh32"], EPI_F32, a3)                   # d tn
+            ops.layernorm_bwd(ws["t32"], ws["st_t"], self.ln_t[0], 0, g_gemm=ws["dh32"], dx_f32=ws["dop32"])
+            g3 = ops.dgelu_split3(ws["dop32"], ws["tz32"], dst=a3)
+            ops.gemm(g3, self.w_tr3t, ws["dh32"], EPI_F32)                                   # d (last hidden state)
+            g_resid, g_gemm = None, ws["dh32"]
+        else:
+            self._ex_dw(dout, ws["mp32"], gw, ws)
+            ops.colsum(dout, B, self.out_dim, gb)
+            self._ex_gemm(dout, wt_head, ws["dmp"], EPI_F32, a3)
+            ops.meanpool_tokens_bwd(ws["dmp"], B, S, ws["dyl"])
+            g_resid, g_gemm = ws["dyl"], None
+        for l in range(L - 1, -1, -1):
+            lay = self.layers[l]
+            drop_b, drop_a = self._drop(ws, self.p_hidden, l, 3), self._drop(ws, self.p_hidden, l, 2)
+            # a dX GEMM's operand carries the mask its Linear's forward output was dropped with; without dropout it IS the stream
+            ops.layernorm_bwd(ws["s2"][l], ws["stb"][l], lay.ln_b[0], 1, g_resid=g_resid, g_gemm=g_gemm, dx_f32=ws["ds"],
+                              dx_bf16=ws["dop32"] if drop_b else None, dropout=drop_b)
+            self._ex_gemm(ws["dop32"] if drop_b else ws["ds"], lay.w3t[2], ws["g32"], EPI_F32, a3)
+            g3 = ops.dgelu_split3(ws["g32"], ws["z32s"][l], dst=a3)
+            ops.gemm(g3, lay.w3t[1], ws["dh32"], EPI_F32)
+            ops.layernorm_bwd(ws["s1"][l], ws["sta"][l], lay.ln_a[0], 1, g_resid=ws["ds"], g_gemm=ws["dh32"], dx_f32=ws["ds1"],
+                              dx_bf16=ws["dop32"] if drop_a else None, dropout=drop_a)
+            self._ex_gemm(ws["dop32"] if drop_a else ws["ds1"], lay.w3t[0], ws["dctx32"], EPI_F32, a3)
+            ops.attn_bwd_f32(ws["qkv32s"][l], ws["dctx32"], ws["ctx32s"][l], ws["lse"][l], B, S, self.heads, 0.125, ws["dqkv32"],
+                             key_bias=ws["key_bias"], dropout=self._drop(ws, self.p_attn, l, 1))
+            has = self._lora_index[l] is not None
+            if has:
+                ops.lora_grad_f32(ws["dqkv32"], ys[l], M, H, self.lora_a(l), self.lora_b(l), self.lora_a(l, grad=True),
+                                  self.lora_b(l, grad=True))
+            if l > 0:  # embeddings are frozen: nothing to do below layer 0
+                wt = ops.split3_transpose(lay.qkv32, lay.wqkvT3, 1, lora_a=self.lora_a(l) if has else None,
+                                          lora_b=self.lora_b(l) if has else None)
+                self._ex_gemm(ws["dqkv32"], wt, ws["dh32"], EPI_F32, a3)
+                g_resid, g_gemm = ws["ds1"], ws["dh32"]
+        ops.set_dropout_step(None)
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None):
         B, S = input_ids.shape
@@ -818,6 +955,8 @@ class BertEngine(EncoderEngineBase):
         return out
 
     def backward(self, dout):
+        if self.exact():
+            return self._backward_exact(dout)
         ws = self.ws
         B, S, M, H, L = ws["B"], ws["S"], ws["M"], self.H, len(self.layers)
         scale = 0.125

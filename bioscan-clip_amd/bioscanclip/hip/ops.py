@@ -207,7 +207,8 @@ def layernorm_fwd_fp8(x, gamma, beta, eps, y_fp8, t_aug=None, y_f32=None, lora_a
 def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lora_a=None, dx_f32=None, dx_bf16=None,
                   M=None, dropout=None, in_dropout=None):
     """``g_resid`` / ``dx_f32`` are the residual-gradient stream in / out: f32, or bf16 (half the bytes; the dtype of each
-    tensor is passed on as ``resid_flags``).  ``dx_bf16`` is the next dX GEMM's operand (carries ``dropout``'s mask)."""
+    tensor is passed on as ``resid_flags``).  ``dx_bf16`` is the next dX GEMM's operand (carries ``dropout``'s mask); the exact
+    backward passes ``g_gemm`` and ``dx_bf16`` as f32 tensors."""
     ld_x = _rowmajor(x, "x")
     H = gamma.numel()
     M = x.shape[0] if M is None else M
@@ -219,7 +220,7 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
         _req(g_resid.dtype in (F32, BF16) and g_resid.shape[0] >= M and g_resid.shape[1] >= H, "g_resid must be f32 / bf16 [M,>=H]")
     if g_gemm is not None:
         ld_g = _rowmajor(g_gemm, "g_gemm")
-        _req(g_gemm.dtype == BF16 and g_gemm.shape[0] >= M and g_gemm.shape[1] >= H, "g_gemm must be bf16 [M,>=H]")
+        _req(g_gemm.dtype in (BF16, F32) and g_gemm.shape[0] >= M and g_gemm.shape[1] >= H, "g_gemm must be bf16 / f32 [M,>=H]")
     if dt is not None:
         _req(dt.dtype == F32 and dt.is_contiguous() and dt.numel() >= 8 * M, "dt must be f32 [M,8]")
         _req(lora_a is not None and tuple(lora_a.shape) == (8, H) and lora_a.dtype == F32 and lora_a.is_contiguous(),
@@ -229,7 +230,7 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
         _req(dx_f32.dtype in (F32, BF16) and dx_f32.shape[0] >= M and dx_f32.shape[1] >= H, "dx_f32 must be f32 / bf16 [M,>=H]")
     if dx_bf16 is not None:
         ld_dxb = _rowmajor(dx_bf16, "dx_bf16")
-        _req(dx_bf16.dtype == BF16 and dx_bf16.shape[0] >= M and dx_bf16.shape[1] >= H, "dx_bf16 too small")
+        _req(dx_bf16.dtype in (BF16, F32) and dx_bf16.shape[0] >= M and dx_bf16.shape[1] >= H, "dx_bf16 (bf16 / f32 operand) too small")
     check(_l.load().bsclip_layernorm_bwd(_p(x), ld_x, int(x.dtype == BF16), _p(stats), _p(gamma), M, H, _p(g_resid),
                                          ld_gr, _p(g_gemm), ld_g, _p(dt), _p(lora_a) if dt is not None else None,
                                          int(mode), _p(dx_f32), ld_dx, _p(dx_bf16), ld_dxb,
@@ -238,7 +239,9 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
                                          0.0 if in_dropout is None else float(in_dropout[0]),
                                          0 if in_dropout is None else int(in_dropout[1]) & 0xFFFFFFFF,
                                          (1 if g_resid is not None and g_resid.dtype == BF16 else 0)
-                                         | (2 if dx_f32 is not None and dx_f32.dtype == BF16 else 0), _stream()))
+                                         | (2 if dx_f32 is not None and dx_f32.dtype == BF16 else 0)
+                                         | (4 if g_gemm is not None and g_gemm.dtype == F32 else 0)
+                                         | (8 if dx_bf16 is not None and dx_bf16.dtype == F32 else 0), _stream()))
 
 
 def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, q_rows=0):
@@ -355,6 +358,81 @@ def attn_fwd_f32(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None)
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_attn_fwd_f32(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), ld_ctx, _p(lse), dp, ds,
+                                        _stream()))
+
+
+# ---- exact backward (BSCLIP_PARITY=2): f32 gradients, split operands on the dX / dW GEMMs (csrc/exact.hip) ----
+def dgelu_split3(dact, z, dst=None, out32=None, M=None):
+    """dact * gelu'(z), both f32 [M, N] -> bf16 [M, 3N] = [hi | lo | hi] (dst) and / or f32 (out32; may alias dact)."""
+    M = z.shape[0] if M is None else M
+    N = z.shape[1]
+    _req(z.dtype == F32 and dact.dtype == F32 and dact.shape[0] >= M and dact.shape[1] >= N and N % 4 == 0
+         and (dst is not None or out32 is not None), "dgelu_split3: dact, z f32 [M, N], an output")
+    if dst is not None:
+        _req(dst.dtype == BF16 and dst.shape[0] >= M and dst.shape[1] >= 3 * N, "dgelu_split3: dst bf16 [M, 3N]")
+    if out32 is not None:
+        _req(out32.dtype == F32 and out32.shape[0] >= M and out32.shape[1] >= N, "dgelu_split3: out32 f32 [M, N]")
+    check(_l.load().bsclip_dgelu_split3(_p(dact), _rowmajor(dact, "dact"), _p(z), _rowmajor(z, "z"), M, N, _p(dst),
+                                        0 if dst is None else _rowmajor(dst, "dst"), _p(out32),
+                                        0 if out32 is None else _rowmajor(out32, "out32"), _stream()))
+    return None if dst is None else dst[:M, :3 * N]
+
+
+def split3_transpose(src, dst_flat, order, R=None, lora_a=None, lora_b=None):
+    """src f32 [R, C] -> bf16 [C, 3 Rp] (Rp = R rounded up to 64; carved out of the flat bf16 buffer ``dst_flat``): row c is the
+    split of column c, order 0 = [hi | lo | hi], 1 = [hi | hi | lo]; lora_a / lora_b fold W + B A first (src = the [3H, H] QKV weight)."""
+    R = src.shape[0] if R is None else R
+    C = src.shape[1]
+    Rp = (R + 63) // 64 * 64
+    _req(src.dtype == F32 and src.shape[0] >= R and dst_flat.dtype == BF16 and dst_flat.is_contiguous()
+         and dst_flat.numel() >= C * 3 * Rp, "split3_transpose: src f32 [R, C], dst bf16 >= C * 3 * Rp")
+    H = 0
+    if lora_a is not None:
+        H = C
+        _req(src.is_contiguous() and R == 3 * C and lora_a.dtype == F32 and lora_a.is_contiguous() and tuple(lora_a.shape) == (8, C)
+             and lora_b is not None and lora_b.dtype == F32 and lora_b.is_contiguous() and tuple(lora_b.shape) == (2, C, 4),
+             "split3_transpose: LoRA fold needs src [3H, H], lora_a [8, H], lora_b [2, H, 4]")
+    dst = dst_flat.view(-1)[:C * 3 * Rp].view(C, 3 * Rp)
+    check(_l.load().bsclip_split3_transpose(_p(src), _rowmajor(src, "src"), R, C, Rp, int(order), _p(lora_a),
+                                            _p(lora_b if lora_a is not None else None), H, _p(dst), 3 * Rp, _stream()))
+    return dst
+
+
+def softmax_meanpool_bwd_f32(logits, stats, d_pooled, B, S, dlogits):
+    C = logits.shape[1]
+    _req(logits.dtype == F32 and logits.is_contiguous() and stats.dtype == F32 and d_pooled.dtype == F32 and d_pooled.is_contiguous()
+         and dlogits.dtype == F32 and dlogits.shape[0] >= B * S and dlogits.shape[1] >= C, "softmax_meanpool_bwd_f32: f32 tensors")
+    check(_l.load().bsclip_softmax_meanpool_bwd_f32(_p(logits), _p(stats), _p(d_pooled), B, S, C, _p(dlogits),
+                                                    _rowmajor(dlogits, "dlogits"), _stream()))
+
+
+_LG32_WS = {}
+
+
+def lora_grad_f32(dqkv, y, M, H, lora_a, lora_b, dA, dB):
+    """dA [8, H] += ..., dB [2, H, 4] += ... from f32 dqkv [M, >= 3H] and the f32 LayerNorm output y [M, >= H]."""
+    _req(dqkv.dtype == F32 and y.dtype == F32 and dqkv.shape[0] >= M and dqkv.shape[1] >= 3 * H and y.shape[0] >= M and y.shape[1] >= H,
+         "lora_grad_f32 shapes")
+    _req(all(t.dtype == F32 and t.is_contiguous() for t in (lora_a, lora_b, dA, dB)) and tuple(lora_a.shape) == (8, H)
+         and tuple(lora_b.shape) == (2, H, 4) and tuple(dA.shape) == (8, H) and tuple(dB.shape) == (2, H, 4), "lora_grad_f32: parameters")
+    key = (H, str(dqkv.device), torch.cuda.current_stream().cuda_stream)   # one workspace per launching stream (towers run concurrently)
+    ws = _LG32_WS.get(key)
+    if ws is None:
+        ws = _LG32_WS[key] = torch.empty(_l.load().bsclip_lora_grad_f32_workspace_floats(H), dtype=F32, device=dqkv.device)
+    check(_l.load().bsclip_lora_grad_f32(_p(dqkv), _rowmajor(dqkv, "dqkv"), _p(y), _rowmajor(y, "y"), M, H, _p(lora_a), _p(lora_b),
+                                         _p(dA), _p(dB), _p(ws), _stream()))
+
+
+def attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None):
+    _req(all(t.dtype == F32 for t in (qkv, dctx, ctx, lse, dqkv)), "attn_bwd_f32 dtypes")
+    _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64 and dqkv.shape[0] >= B * S and dqkv.shape[1] >= 3 * heads * 64
+         and ctx.shape[0] >= B * S and ctx.shape[1] >= heads * 64 and dctx.shape[0] >= B * S and dctx.shape[1] >= heads * 64
+         and lse.numel() >= B * heads * S, "attn_bwd_f32 shapes")
+    if key_bias is not None:
+        _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
+    dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
+    check(_l.load().bsclip_attn_bwd_f32(_p(qkv), _rowmajor(qkv, "qkv"), _p(dctx), _rowmajor(dctx, "dctx"), _p(ctx), _rowmajor(ctx, "ctx"),
+                                        _p(lse), B, S, heads, _p(key_bias), float(scale), _p(dqkv), _rowmajor(dqkv, "dqkv"), dp, ds,
                                         _stream()))
 
 

@@ -181,6 +181,353 @@ __global__ __launch_bounds__(AF_THREADS) void attn_fwd_f32_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------ exact backward
+// dst = split of (dact * gelu'(z)) as [hi | lo | hi] (the A operand of fc1's dX GEMM) and / or the same product in f32
+__global__ void dgelu_split3_kernel(const float* __restrict__ dact, int ldd_, const float* __restrict__ z, int ldz, int M, int N,
+                                    bf16_t* __restrict__ dst, int ldd, float* __restrict__ out32, int ldo) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = N / 4;
+    if (t >= (size_t)M * nq) return;
+    const int m = (int)(t / nq), n = (int)(t % nq) * 4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(z + (size_t)m * ldz + n);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dact + (size_t)m * ldd_ + n);
+    float d[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float cdf = 0.5f * (1.0f + erff(x[i] * 0.70710678118654752f));
+        d[i] = g[i] * fmaf(x[i] * 0.39894228040143268f, __expf(-0.5f * x[i] * x[i]), cdf);
+    }
+    if (dst != nullptr) {
+        uint2 hi, lo;
+        split2(d[0], d[1], hi.x, lo.x);
+        split2(d[2], d[3], hi.y, lo.y);
+        bf16_t* row = dst + (size_t)m * ldd;
+        *reinterpret_cast<uint2*>(row + n) = hi;
+        *reinterpret_cast<uint2*>(row + N + n) = lo;
+        *reinterpret_cast<uint2*>(row + 2 * N + n) = hi;
+    }
+    if (out32 != nullptr) *reinterpret_cast<f32x4*>(out32 + (size_t)m * ldo + n) = f32x4{d[0], d[1], d[2], d[3]};
+}
+
+// dst[c, :] = split of column c of src [R, C] over Rp >= R positions (zeros beyond R): the reduction dimension of a dW = dY^T X
+// GEMM (both operands transposed, order 0 = [hi | lo | hi], 1 = [hi | hi | lo]) or a frozen weight's transpose for a dX GEMM
+// (order 1; LoRA folded as in split3_weight_kernel when lora_a is given: src is then the [3H, H] QKV weight).
+// One workgroup: a 64 x 64 tile through LDS.
+__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ src, int ld, int R, int C, int Rp, int order,
+                                                               const float* __restrict__ lora_a, const float* __restrict__ lora_b,
+                                                               int H, bf16_t* __restrict__ dst, int ldd) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int r = r0 + (i >> 6), c = c0 + (i & 63);
+        float v = 0.f;
+        if (r < R && c < C) {
+            v = src[(size_t)r * ld + c];
+            if (lora_a != nullptr && (r < H || r >= 2 * H)) {
+                const int part = r < H ? 0 : 1, rr = r < H ? r : r - 2 * H;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v = fmaf(lora_b[((size_t)part * H + rr) * 4 + j], lora_a[(size_t)(4 * part + j) * C + c], v);
+            }
+        }
+        tile[i >> 6][i & 63] = v;
+    }
+    __syncthreads();
+    const int c = c0 + (tid >> 2), rs = (tid & 3) * 16;
+    if (c >= C) return;
+    ex_u32x4 hi[2], lo[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned h, l;
+        split2(tile[rs + 2 * j][tid >> 2], tile[rs + 2 * j + 1][tid >> 2], h, l);
+        hi[j >> 2][j & 3] = h;
+        lo[j >> 2][j & 3] = l;
+    }
+    bf16_t* row = dst + (size_t)c * ldd + r0 + rs;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        *reinterpret_cast<ex_u32x4*>(row + 8 * j) = hi[j];
+        *reinterpret_cast<ex_u32x4*>(row + Rp + 8 * j) = order ? hi[j] : lo[j];
+        *reinterpret_cast<ex_u32x4*>(row + 2 * Rp + 8 * j) = order ? lo[j] : hi[j];
+    }
+}
+
+// dlogits[b,t,c] = p_c (g_c - sum_j p_j g_j),  g = d_pooled[b] / S, in f32 (heads.hip's kernel rounds to bf16)
+template <int C>
+__global__ __launch_bounds__(256) void softmax_meanpool_bwd_f32_kernel(const float* __restrict__ logits, const float* __restrict__ stats,
+                                                                        const float* __restrict__ d_pooled, int M, int S,
+                                                                        float* __restrict__ dlogits, int ld_d) {
+    constexpr int NV = C / 256;
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (row >= M) return;
+    const int b = row / S;
+    const float m = stats[2 * (size_t)row], inv = 1.0f / stats[2 * (size_t)row + 1];
+    const float invS = 1.0f / (float)S;
+    f32x4 p[NV], g[NV];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(logits + (size_t)row * C + j * 256 + lane * 4);
+        g[j] = *reinterpret_cast<const f32x4*>(d_pooled + (size_t)b * C + j * 256 + lane * 4) * invS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            p[j][i] = __expf(v[i] - m) * inv;
+            dot += p[j][i] * g[j][i];
+        }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        *reinterpret_cast<f32x4*>(dlogits + (size_t)row * ld_d + j * 256 + lane * 4) = p[j] * (g[j] - dot);
+}
+
+// LoRA gradients in f32 from the f32 dq / dv and the f32 LayerNorm output y (the forward folds W + B A, so t = A y is rebuilt here):
+//   t = A y, u_q = B_q^T dq, u_v = B_v^T dv;   dA_q += u_q y^T, dA_v += u_v y^T, dB_q += dq t_q^T, dB_v += dv t_v^T
+// (reference lora_layer.py:16-39).  Workgroup = a strided set of rows, LGR at a time; thread = NV columns; partial sums per workgroup
+// [16 H] = dA [8, H] | dB [2, H, 4], reduced in a fixed order by slab_reduce_add.
+constexpr int LGR = 4;
+template <int H>
+__global__ __launch_bounds__(256) void lora_grad_f32_kernel(const float* __restrict__ dqkv, int ld, const float* __restrict__ y, int ldy,
+                                                            int M, const float* __restrict__ A, const float* __restrict__ Bm,
+                                                            float* __restrict__ partial) {
+    constexpr int NV = H / 256;
+    __shared__ float red[4][LGR * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float a[8][NV], bq[NV][4], bv[NV][4], accA[8][NV], accQ[NV][4], accV[NV][4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = tid + 256 * j;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a[i][j] = A[(size_t)i * H + c];
+            accA[i][j] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bq[j][i] = Bm[(size_t)c * 4 + i];
+            bv[j][i] = Bm[((size_t)H + c) * 4 + i];
+            accQ[j][i] = accV[j][i] = 0.f;
+        }
+    }
+    for (int r0 = blockIdx.x * LGR; r0 < M; r0 += gridDim.x * LGR) {
+        float yv[LGR][NV], dq[LGR][NV], dv[LGR][NV], s[LGR][16];
+#pragma unroll
+        for (int r = 0; r < LGR; ++r) {
+            const bool ok = r0 + r < M;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = tid + 256 * j;
+                yv[r][j] = ok ? y[(size_t)(r0 + r) * ldy + c] : 0.f;
+                dq[r][j] = ok ? dqkv[(size_t)(r0 + r) * ld + c] : 0.f;
+                dv[r][j] = ok ? dqkv[(size_t)(r0 + r) * ld + 2 * H + c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) t = fmaf(a[i][j], yv[r][j], t);
+                s[r][i] = wave_sum(t);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float uq = 0.f, uv = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    uq = fmaf(dq[r][j], bq[j][i], uq);
+                    uv = fmaf(dv[r][j], bv[j][i], uv);
+                }
+                s[r][8 + i] = wave_sum(uq);
+                s[r][12 + i] = wave_sum(uv);
+            }
+        }
+        __syncthreads();   // the previous iteration's reads of red are done
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < LGR; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[wave][r * 16 + i] = s[r][i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < LGR; ++r) {
+            float f[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) f[i] = (red[0][r * 16 + i] + red[1][r * 16 + i]) + (red[2][r * 16 + i] + red[3][r * 16 + i]);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) accA[i][j] = fmaf(f[8 + i], yv[r][j], accA[i][j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    accQ[j][i] = fmaf(dq[r][j], f[i], accQ[j][i]);
+                    accV[j][i] = fmaf(dv[r][j], f[4 + i], accV[j][i]);
+                }
+            }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * 16 * H;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = tid + 256 * j;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[(size_t)i * H + c] = accA[i][j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[8 * H + (size_t)c * 4 + i] = accQ[j][i];
+            out[8 * H + ((size_t)H + c) * 4 + i] = accV[j][i];
+        }
+    }
+}
+
+// f32 attention backward on the vector ALU, one workgroup per (batch, head), two phases over the same LDS:
+//   A  K, V resident; one query row per thread: delta = dO . O, p = exp(s - lse), dS = p (f dO.v - delta), dQ = scale dS K
+//   B  Q, dO resident; one key row per thread:  dV = (p f)^T dO, dK = scale dS^T Q
+// (f = the dropout factor of the probability, the same (seed, element) hash as every other attention kernel).
+template <bool DROP>
+__global__ __launch_bounds__(AF_THREADS) void attn_bwd_f32_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dctx,
+                                                                  int ld_d, const float* __restrict__ ctx, int ld_c,
+                                                                  const float* __restrict__ lse, int S, int heads,
+                                                                  const float* __restrict__ key_bias, float scale,
+                                                                  float* __restrict__ dqkv, int ld_g, DropCfg drop) {
+    BSCLIP_DROP_RESOLVE(drop);
+    __shared__ __attribute__((aligned(16))) float sA[AF_SMAX * 64];
+    __shared__ __attribute__((aligned(16))) float sB[AF_SMAX * 64];
+    __shared__ float sBias[AF_SMAX], sLse[AF_SMAX], sDelta[AF_SMAX];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, tid = threadIdx.x;
+    const int HW = heads * 64;
+    const float* qb = qkv + (size_t)b * S * ld + hd * 64;
+    const float* db = dctx + (size_t)b * S * ld_d + hd * 64;
+    const float* cb = ctx + (size_t)b * S * ld_c + hd * 64;
+    float* gb = dqkv + (size_t)b * S * ld_g + hd * 64;
+    const int SP = (S + 31) / 32 * 32;
+    const unsigned dhead = (unsigned)(b * heads + hd) * S;
+    for (int i = tid; i < S * 16; i += AF_THREADS) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        *reinterpret_cast<f32x4*>(sA + r * 64 + c) = *reinterpret_cast<const f32x4*>(qb + (size_t)r * ld + HW + c);
+        *reinterpret_cast<f32x4*>(sB + r * 64 + c) = *reinterpret_cast<const f32x4*>(qb + (size_t)r * ld + 2 * HW + c);
+    }
+    for (int k = tid; k < S; k += AF_THREADS) {
+        sBias[k] = key_bias ? key_bias[(size_t)b * S + k] : 0.f;
+        sLse[k] = lse[((size_t)b * heads + hd) * S + k];
+    }
+    __syncthreads();
+    for (int q = tid; q < S; q += AF_THREADS) {
+        float qv[64], dov[64], dq[64];
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qb + (size_t)q * ld + 4 * c);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(db + (size_t)q * ld_d + 4 * c);
+            const f32x4 o = *reinterpret_cast<const f32x4*>(cb + (size_t)q * ld_c + 4 * c);
+            d0 = fmaf(g[0], o[0], d0);
+            d1 = fmaf(g[1], o[1], d1);
+            d2 = fmaf(g[2], o[2], d2);
+            d3 = fmaf(g[3], o[3], d3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qv[4 * c + i] = v[i];
+                dov[4 * c + i] = g[i];
+                dq[4 * c + i] = 0.f;
+            }
+        }
+        const float delta = (d0 + d1) + (d2 + d3), lq = sLse[q];
+        sDelta[q] = delta;
+        const unsigned dbase = (dhead + (unsigned)q) * SP;
+        for (int k = 0; k < S; ++k) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(sA + k * 64 + 4 * c);
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(sB + k * 64 + 4 * c);
+                s0 = fmaf(qv[4 * c + 0], kv[0], s0);
+                s1 = fmaf(qv[4 * c + 1], kv[1], s1);
+                s2 = fmaf(qv[4 * c + 2], kv[2], s2);
+                s3 = fmaf(qv[4 * c + 3], kv[3], s3);
+                p0 = fmaf(dov[4 * c + 0], vv[0], p0);
+                p1 = fmaf(dov[4 * c + 1], vv[1], p1);
+                p2 = fmaf(dov[4 * c + 2], vv[2], p2);
+                p3 = fmaf(dov[4 * c + 3], vv[3], p3);
+            }
+            const float s = fmaf((s0 + s1) + (s2 + s3), scale, sBias[k]);
+            const float p = __expf(s - lq);
+            float dp = (p0 + p1) + (p2 + p3);
+            if constexpr (DROP) dp *= drop_factor(drop, dbase + (unsigned)k);
+            const float ds = p * (dp - delta);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(sA + k * 64 + 4 * c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dq[4 * c + i] = fmaf(ds, kv[i], dq[4 * c + i]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            *reinterpret_cast<f32x4*>(gb + (size_t)q * ld_g + 4 * c) =
+                f32x4{dq[4 * c] * scale, dq[4 * c + 1] * scale, dq[4 * c + 2] * scale, dq[4 * c + 3] * scale};
+    }
+    __syncthreads();
+    for (int i = tid; i < S * 16; i += AF_THREADS) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        *reinterpret_cast<f32x4*>(sA + r * 64 + c) = *reinterpret_cast<const f32x4*>(qb + (size_t)r * ld + c);
+        *reinterpret_cast<f32x4*>(sB + r * 64 + c) = *reinterpret_cast<const f32x4*>(db + (size_t)r * ld_d + c);
+    }
+    __syncthreads();
+    for (int k = tid; k < S; k += AF_THREADS) {
+        float kv[64], vv[64], dk[64], dv[64];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qb + (size_t)k * ld + HW + 4 * c);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qb + (size_t)k * ld + 2 * HW + 4 * c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kv[4 * c + i] = a[i];
+                vv[4 * c + i] = v[i];
+                dk[4 * c + i] = 0.f;
+                dv[4 * c + i] = 0.f;
+            }
+        }
+        const float bias = sBias[k];
+        for (int q = 0; q < S; ++q) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(sA + q * 64 + 4 * c);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(sB + q * 64 + 4 * c);
+                s0 = fmaf(qv[0], kv[4 * c + 0], s0);
+                s1 = fmaf(qv[1], kv[4 * c + 1], s1);
+                s2 = fmaf(qv[2], kv[4 * c + 2], s2);
+                s3 = fmaf(qv[3], kv[4 * c + 3], s3);
+                p0 = fmaf(g[0], vv[4 * c + 0], p0);
+                p1 = fmaf(g[1], vv[4 * c + 1], p1);
+                p2 = fmaf(g[2], vv[4 * c + 2], p2);
+                p3 = fmaf(g[3], vv[4 * c + 3], p3);
+            }
+            const float s = fmaf((s0 + s1) + (s2 + s3), scale, bias);
+            const float p = __expf(s - sLse[q]);
+            float f = 1.0f;
+            if constexpr (DROP) f = drop_factor(drop, (dhead + (unsigned)q) * SP + (unsigned)k);
+            const float pf = p * f;
+            const float ds = p * (f * ((p0 + p1) + (p2 + p3)) - sDelta[q]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(sA + q * 64 + 4 * c);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(sB + q * 64 + 4 * c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dk[4 * c + i] = fmaf(ds, qv[i], dk[4 * c + i]);
+                    dv[4 * c + i] = fmaf(pf, g[i], dv[4 * c + i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            *reinterpret_cast<f32x4*>(gb + (size_t)k * ld_g + HW + 4 * c) =
+                f32x4{dk[4 * c] * scale, dk[4 * c + 1] * scale, dk[4 * c + 2] * scale, dk[4 * c + 3] * scale};
+            *reinterpret_cast<f32x4*>(gb + (size_t)k * ld_g + 2 * HW + 4 * c) = f32x4{dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]};
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int bsclip_split3_rows(const float* src, int ld_src, int M, int K, void* dst, int ld_dst, void* stream) {
@@ -243,6 +590,84 @@ extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, i
     else
         hipLaunchKernelGGL((attn_fwd_f32_kernel<false>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale, ctx,
                            ld_ctx, lse, drop);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_dgelu_split3(const float* dact, int ld_dact, const float* z, int ld_z, int M, int N, void* dst, int ld_dst,
+                                   float* out32, int ld_out32, void* stream) {
+    BSCLIP_REQUIRE(dact && z && (dst || out32), "bsclip_dgelu_split3: null pointer");
+    BSCLIP_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld_dact >= N && ld_dact % 4 == 0 && ld_z >= N && ld_z % 4 == 0 &&
+                       (dst == nullptr || (ld_dst >= 3 * N && ld_dst % 4 == 0)) && (out32 == nullptr || (ld_out32 >= N && ld_out32 % 4 == 0)),
+                   "bsclip_dgelu_split3: M=%d N=%d ld_dact=%d ld_z=%d ld_dst=%d ld_out32=%d", M, N, ld_dact, ld_z, ld_dst, ld_out32);
+    const size_t n = (size_t)M * (N / 4);
+    hipLaunchKernelGGL(dgelu_split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dact, ld_dact,
+                       z, ld_z, M, N, static_cast<bf16_t*>(dst), ld_dst, out32, ld_out32);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_split3_transpose(const float* src, int ld_src, int R, int C, int Rp, int order, const float* lora_a,
+                                       const float* lora_b, int H, void* dst, int ld_dst, void* stream) {
+    BSCLIP_REQUIRE(src && dst, "bsclip_split3_transpose: null pointer");
+    BSCLIP_REQUIRE((lora_a == nullptr) == (lora_b == nullptr), "bsclip_split3_transpose: lora_a and lora_b go together");
+    BSCLIP_REQUIRE(R > 0 && C > 0 && Rp >= R && Rp % 64 == 0 && ld_src >= C && ld_dst >= 3 * Rp && ld_dst % 8 == 0 && (order == 0 || order == 1) &&
+                       (lora_a == nullptr || (R == 3 * H && C == H)) && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+                   "bsclip_split3_transpose: R=%d C=%d Rp=%d order=%d H=%d ld_src=%d ld_dst=%d", R, C, Rp, order, H, ld_src, ld_dst);
+    hipLaunchKernelGGL(split3_transpose_kernel, dim3(Rp / 64, (C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld_src, R,
+                       C, Rp, order, lora_a, lora_b, H, static_cast<bf16_t*>(dst), ld_dst);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_softmax_meanpool_bwd_f32(const float* logits, const float* stats, const float* d_pooled, int B, int S, int C,
+                                               float* dlogits, int ld_d, void* stream) {
+    BSCLIP_REQUIRE(logits && stats && d_pooled && dlogits && B > 0 && S > 0, "bsclip_softmax_meanpool_bwd_f32: bad args");
+    BSCLIP_REQUIRE(C == 768 && ld_d >= C && ld_d % 4 == 0, "bsclip_softmax_meanpool_bwd_f32: C=%d ld_d=%d", C, ld_d);
+    const int M = B * S;
+    hipLaunchKernelGGL((softmax_meanpool_bwd_f32_kernel<768>), dim3(ceil_div(M, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
+                       stats, d_pooled, M, S, dlogits, ld_d);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+constexpr int LG32_BLOCKS = 512;
+extern "C" int64_t bsclip_lora_grad_f32_workspace_floats(int H) { return (int64_t)LG32_BLOCKS * 16 * H; }
+
+extern "C" int bsclip_lora_grad_f32(const float* dqkv, int ld_dqkv, const float* y, int ld_y, int M, int H, const float* lora_a,
+                                    const float* lora_b, float* dA, float* dB, float* workspace, void* stream) {
+    BSCLIP_REQUIRE(dqkv && y && lora_a && lora_b && dA && dB && workspace, "bsclip_lora_grad_f32: null pointer");
+    BSCLIP_REQUIRE(M > 0 && (H == 768 || H == 512) && ld_dqkv >= 3 * H && ld_y >= H, "bsclip_lora_grad_f32: M=%d H=%d ld_dqkv=%d ld_y=%d", M,
+                   H, ld_dqkv, ld_y);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int blocks = min(LG32_BLOCKS, ceil_div(M, LGR));
+    if (H == 768)
+        hipLaunchKernelGGL((lora_grad_f32_kernel<768>), dim3(blocks), dim3(256), 0, s, dqkv, ld_dqkv, y, ld_y, M, lora_a, lora_b, workspace);
+    else
+        hipLaunchKernelGGL((lora_grad_f32_kernel<512>), dim3(blocks), dim3(256), 0, s, dqkv, ld_dqkv, y, ld_y, M, lora_a, lora_b, workspace);
+    BSCLIP_LAUNCH_CHECK();
+    bsclip_launch_slab_reduce_add(workspace, blocks, 16 * H, dA, dB, 8 * H, s);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx,
+                                   const float* lse, int B, int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv,
+                                   float dropout_p, uint32_t dropout_seed, void* stream) {
+    BSCLIP_REQUIRE(qkv && dctx && ctx && lse && dqkv, "bsclip_attn_bwd_f32: null pointer");
+    BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= AF_SMAX, "bsclip_attn_bwd_f32: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
+    BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 4 == 0 && ld_dqkv >= 3 * heads * 64 && ld_dqkv % 4 == 0 && ld_ctx >= heads * 64 &&
+                       ld_ctx % 4 == 0 && ld_dctx >= heads * 64 && ld_dctx % 4 == 0,
+                   "bsclip_attn_bwd_f32: ld_qkv=%d ld_dqkv=%d ld_ctx=%d ld_dctx=%d", ld_qkv, ld_dqkv, ld_ctx, ld_dctx);
+    BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_bwd_f32: dropout_p=%f", dropout_p);
+    const DropCfg drop = make_drop(dropout_p, dropout_seed);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (drop.thr16)
+        hipLaunchKernelGGL((attn_bwd_f32_kernel<true>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx, lse,
+                           S, heads, key_bias, scale, dqkv, ld_dqkv, drop);
+    else
+        hipLaunchKernelGGL((attn_bwd_f32_kernel<false>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx, lse,
+                           S, heads, key_bias, scale, dqkv, ld_dqkv, drop);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

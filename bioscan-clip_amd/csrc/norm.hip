@@ -170,15 +170,16 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ gamma, int M,
                                                                   const void* __restrict__ g_resid, int ld_gr,
-                                                                  const bf16_t* __restrict__ g_gemm, int ld_g,
+                                                                  const void* __restrict__ g_gemm, int ld_g,
                                                                   const float* __restrict__ dt,
                                                                   const float* __restrict__ lora_a, int mode,
                                                                   void* __restrict__ dx_res, int ld_dx,
-                                                                  bf16_t* __restrict__ dx_bf16, int ld_dxb,
+                                                                  void* __restrict__ dx_bf16, int ld_dxb,
                                                                   DropCfg drop, DropCfg in_drop, int resid_flags) {
     // resid_flags: bit 0 = g_resid is bf16, bit 1 = dx_res is bf16 (the residual-gradient stream kept in bf16: 2 instead of
     // 4 bytes per element read and written by every LayerNorm backward -- the kernel is HBM-bound)
-    const bool gr_bf16 = resid_flags & 1, dr_bf16 = resid_flags & 2;
+    // bit 2 = g_gemm is f32, bit 3 = the operand output ("dx_bf16") is f32: the exact backward (exact.hip) keeps both in f32
+    const bool gr_bf16 = resid_flags & 1, dr_bf16 = resid_flags & 2, gg_f32 = resid_flags & 4, op_f32 = resid_flags & 8;
     BSCLIP_DROP_RESOLVE(drop);
     BSCLIP_DROP_RESOLVE(in_drop);
     constexpr int NV = H / 256;
@@ -220,8 +221,12 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
                     res[j] = ld_stream(reinterpret_cast<const f32x4*>(static_cast<const float*>(g_resid) + (size_t)row * ld_gr + j * 256 + lane * 4));
             }
         }
-        if (g_gemm) {
-            const bf16_t* p = g_gemm + (size_t)row * ld_g;
+        if (g_gemm && gg_f32) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                dy[j] = ld_stream(reinterpret_cast<const f32x4*>(static_cast<const float*>(g_gemm) + (size_t)row * ld_g + j * 256 + lane * 4));
+        } else if (g_gemm) {
+            const bf16_t* p = static_cast<const bf16_t*>(g_gemm) + (size_t)row * ld_g;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const uint2 u = ld_stream(reinterpret_cast<const uint2*>(p + j * 256 + lane * 4));
@@ -274,10 +279,14 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
             if (dx_bf16) {
                 // gradient w.r.t. the output of the Linear whose forward result was dropped with this (p, seed)
                 if (drop.thr16) d = drop4(drop, (unsigned)row * H + j * 256 + lane * 4, d);
+                if (op_f32) {
+                    st_stream(static_cast<float*>(dx_bf16) + (size_t)row * ld_dxb + j * 256 + lane * 4, d);
+                    continue;
+                }
                 uint2 o;
                 o.x = pack_bf2(d[0], d[1]);
                 o.y = pack_bf2(d[2], d[3]);
-                st_stream(dx_bf16 + (size_t)row * ld_dxb + j * 256 + lane * 4, o);
+                st_stream(static_cast<bf16_t*>(dx_bf16) + (size_t)row * ld_dxb + j * 256 + lane * 4, o);
             }
         }
     }
@@ -396,8 +405,8 @@ extern "C" int bsclip_layernorm_fwd_fp8(const void* x, int ld_x, int x_bf16, int
 
 #define LN_BWD_LAUNCH(HH, XB, LO)                                                                                \
     hipLaunchKernelGGL((layernorm_bwd_kernel<HH, XB, LO>), dim3(ln_grid(M, LO ? 4 : 8)), dim3(LN_BLOCK), 0, s, x, ld_x, stats, \
-                       gamma, M, g_resid, ld_gr, static_cast<const bf16_t*>(g_gemm), ld_g, dt, lora_a, mode, dx_f32, \
-                       ld_dx, static_cast<bf16_t*>(dx_bf16), ld_dxb, drop, in_drop, resid_flags)
+                       gamma, M, g_resid, ld_gr, g_gemm, ld_g, dt, lora_a, mode, dx_f32, \
+                       ld_dx, dx_bf16, ld_dxb, drop, in_drop, resid_flags)
 
 extern "C" int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M,
                                     int H, const void* g_resid, int ld_gr, const void* g_gemm, int ld_g,
@@ -408,7 +417,7 @@ extern "C" int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const f
     BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_bwd: H=%d (supported: 768, 512)", H);
     BSCLIP_REQUIRE(g_resid || g_gemm, "bsclip_layernorm_bwd: no incoming gradient");
     BSCLIP_REQUIRE(mode == 0 || mode == 1, "bsclip_layernorm_bwd: mode=%d", mode);
-    BSCLIP_REQUIRE(resid_flags >= 0 && resid_flags <= 3, "bsclip_layernorm_bwd: resid_flags=%d", resid_flags);
+    BSCLIP_REQUIRE(resid_flags >= 0 && resid_flags <= 15, "bsclip_layernorm_bwd: resid_flags=%d", resid_flags);
     BSCLIP_REQUIRE((dt == nullptr) == (lora_a == nullptr), "bsclip_layernorm_bwd: dt and lora_a go together");
     BSCLIP_REQUIRE(!g_gemm || (ld_g >= H && ld_g % 4 == 0), "bsclip_layernorm_bwd: ld_g=%d", ld_g);
     BSCLIP_REQUIRE(!g_resid || (ld_gr >= H && ld_gr % 4 == 0), "bsclip_layernorm_bwd: ld_gr=%d", ld_gr);

@@ -229,8 +229,21 @@ int bsclip_attn_bwd2(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx,
  *                  gelu' side band the default backward reads
  *   meanpool_tokens_f32: x f32 [B*S, H] -> out f32 [B, H], the mean over each sequence's S tokens (language_encoder.py:89)
  *   attn_fwd_f32:  qkv f32 [B*S, ld_qkv] ([q | k | v], heads*64 each) -> ctx f32 [B*S, ld_ctx], lse f32 [B, heads, S]; f32 arithmetic
- *                  on the vector ALU, the bf16 kernels' dropout masks; argument meaning as bsclip_attn_fwd.  The backward is
- *                  bsclip_attn_bwd on the bf16 copies. */
+ *                  on the vector ALU, the bf16 kernels' dropout masks; argument meaning as bsclip_attn_fwd.
+ * The exact backward (BSCLIP_PARITY=2) keeps every gradient in f32 and runs its dX / dW GEMMs on split operands as well:
+ *   dgelu_split3:  dact f32 [M, N], z f32 [M, N] (fc1 pre-activation) -> dact * gelu'(z) as bf16 [M, 3N] = [hi | lo | hi] (dst nullable)
+ *                  and / or f32 [M, ld_out32] (out32 nullable)
+ *   split3_transpose: src f32 [R, C] -> dst bf16 [C, 3 Rp]: row c = the split of column c over Rp >= R positions (Rp % 64 == 0, zeros
+ *                  beyond R), order 0 = [hi | lo | hi], 1 = [hi | hi | lo].  With order 0 / 1 on dY / X it builds the two operands of a
+ *                  dW = dY^T X GEMM (the reduction runs over the R rows); with order 1 on a frozen weight [N, K] it builds W^T for the
+ *                  dX GEMM; lora_a / lora_b (nullable, R = 3H, C = H) fold W + B A as in split3_weight
+ *   softmax_meanpool_bwd_f32: bsclip_softmax_meanpool_bwd with f32 dlogits [B*S, ld_d]
+ *   lora_grad_f32: dA [8, H] += (B^T dq | B^T dv) y^T, dB [2, H, 4] += (dq | dv)^T (A y) from dqkv f32 [M, ld_dqkv] ([dq | dk | dv]) and
+ *                  the LayerNorm output y f32 [M, ld_y] (reference lora_layer.py:16-39); workspace:
+ *                  bsclip_lora_grad_f32_workspace_floats(H) floats; sums in a fixed order
+ *   attn_bwd_f32:  dqkv f32 [B*S, ld_dqkv] from qkv f32, dctx f32, the forward's ctx f32 (delta = dctx . ctx) and lse; f32 arithmetic on
+ *                  the vector ALU, the forward's dropout masks; argument meaning as bsclip_attn_bwd.
+ * bsclip_layernorm_bwd takes the f32 GEMM gradient / writes the f32 operand through resid_flags bits 2 / 3. */
 int bsclip_split3_rows(const float* src, int ld_src, int M, int K, void* dst, int ld_dst, void* stream);
 int bsclip_split3_weight(const float* w, int ld_w, int N, int K, const float* lora_a, const float* lora_b, int H, void* dst, int ld_dst,
                          void* stream);
@@ -239,6 +252,18 @@ int bsclip_gelu_split3(const float* z, int ld_z, int M, int N, void* dst, int ld
 int bsclip_meanpool_tokens_f32(const float* x, int B, int S, int H, float* out, void* stream);
 int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, float* ctx, int ld_ctx,
                         float* lse, float dropout_p, uint32_t dropout_seed, void* stream);
+int bsclip_dgelu_split3(const float* dact, int ld_dact, const float* z, int ld_z, int M, int N, void* dst, int ld_dst, float* out32,
+                        int ld_out32, void* stream);
+int bsclip_split3_transpose(const float* src, int ld_src, int R, int C, int Rp, int order, const float* lora_a, const float* lora_b, int H,
+                            void* dst, int ld_dst, void* stream);
+int bsclip_softmax_meanpool_bwd_f32(const float* logits, const float* stats, const float* d_pooled, int B, int S, int C, float* dlogits,
+                                    int ld_d, void* stream);
+int64_t bsclip_lora_grad_f32_workspace_floats(int H);
+int bsclip_lora_grad_f32(const float* dqkv, int ld_dqkv, const float* y, int ld_y, int M, int H, const float* lora_a, const float* lora_b,
+                         float* dA, float* dB, float* workspace, void* stream);
+int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx, const float* lse, int B,
+                        int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv, float dropout_p,
+                        uint32_t dropout_seed, void* stream);
 
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column

@@ -748,3 +748,136 @@ def test_clock_probe_reads_a_plausible_engine_clock(ops):
     assert len(seen) >= 1
     ticks = max(int(q1[x, 1] - q0[x, 1]) for x in seen)          # 100 MHz
     assert 0.3 * dt < ticks / 1e8 < 1.05 * dt + 1e-3, (ticks, dt)   # the probes run inside [t0, t0 + dt]; enqueue leads execution
+
+
+# ------------------------------------------------------------------------------ exact mode (BSCLIP_PARITY=2) kernels
+@pytest.mark.parametrize("B,S,heads,masked", [(3, 197, 12, False), (2, 133, 12, False), (5, 20, 8, True), (2, 224, 2, True),
+                                              (3, 1, 2, False), (2, 7, 3, True)])
+def test_exact_attention_fwd_bwd_f32(ops, B, S, heads, masked):
+    """bsclip_attn_fwd_f32 / bsclip_attn_bwd_f32 against autograd in f64: f32 arithmetic end to end, so the bar is 2e-5, not the
+    6e-3 / 1e-2 of the bf16 kernels (reference: timm Attention / HF BertSelfAttention)."""
+    H = heads * 64
+    qkv = dev(rnd(B * S, 3 * H + 64, seed=1))[:, :3 * H]
+    bias = None
+    if masked:
+        lens = torch.randint(1, S + 1, (B,), generator=torch.Generator().manual_seed(3))
+        m = (torch.arange(S)[None] < lens[:, None]).float()
+        bias = dev((1.0 - m) * torch.finfo(torch.float32).min)
+    scale = 0.125
+    ctx = torch.empty(B * S, H, device="cuda")
+    lse = torch.empty(B, heads, S, device="cuda")
+    ops.attn_fwd_f32(qkv, B, S, heads, scale, ctx, lse, key_bias=bias)
+    qf = qkv.double().reshape(B, S, 3 * H).requires_grad_(True)
+    ref, ref_lse = _attn_ref(qf, B, S, heads, scale, None if bias is None else bias.double())
+    assert rel_err(ctx, ref.float()) < TOL_F32 and rel_err(lse, ref_lse.float()) < 1e-6
+    dctx = dev(rnd(B * S, H, seed=2))
+    (gq,) = torch.autograd.grad(ref, qf, dctx.double())
+    gq = gq.reshape(B * S, 3 * H).float()
+    dqkv = torch.full((B * S, 3 * H), float("nan"), device="cuda")
+    ops.attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, scale, dqkv, key_bias=bias)
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        e = ((dqkv[:, sl] - gq[:, sl]).norm() / (gq[:, sl].norm() + 1e-5 * gq.norm())).item()   # S = 1: dq = dk = 0 in the reference
+        assert e < 3e-5, (name, e)
+
+
+def test_exact_attention_dropout_masks_are_the_bf16_kernels(ops):
+    """The f32 attention draws the (seed, element) masks of the bf16 kernels: with the same seed its output and gradients stay at
+    bf16 distance from theirs (a different mask on 10 % of the probabilities would be an O(0.3) difference), and its backward is
+    the exact derivative of its forward under that mask (central finite difference in the direction of a random perturbation)."""
+    B, S, heads = 2, 133, 4
+    H = heads * 64
+    qkv = dev(rnd(B * S, 3 * H, seed=4))
+    drop = (0.1, 0x1234567)
+    ctx, lse = torch.empty(B * S, H, device="cuda"), torch.empty(B, heads, S, device="cuda")
+    ops.attn_fwd_f32(qkv, B, S, heads, 0.125, ctx, lse, dropout=drop)
+    q16 = qkv.bfloat16()
+    ctx16, lse16 = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, S, device="cuda")
+    ops.attn_fwd(q16, B, S, heads, 0.125, ctx16, lse16, dropout=drop)
+    assert rel_err(ctx16.float(), ctx) < 1.5e-2
+    dctx = dev(rnd(B * S, H, seed=5))
+    dqkv = torch.empty(B * S, 3 * H, device="cuda")
+    ops.attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, 0.125, dqkv, dropout=drop)
+    dq16 = torch.empty(B * S, 3 * H, device="cuda", dtype=torch.bfloat16)
+    ops.attn_bwd(q16, dctx.bfloat16(), lse16, B, S, heads, 0.125, dq16, dropout=drop)
+    assert rel_err(dq16.float(), dqkv) < 3e-2
+    u = dev(rnd(B * S, 3 * H, seed=6))
+    h = 2e-2
+    cp, cm = torch.empty_like(ctx), torch.empty_like(ctx)
+    ops.attn_fwd_f32(qkv + h * u, B, S, heads, 0.125, cp, lse, dropout=drop)
+    ops.attn_fwd_f32(qkv - h * u, B, S, heads, 0.125, cm, lse, dropout=drop)
+    fd = (((cp - cm).double() * dctx.double()).sum() / (2 * h)).item()
+    an = (dqkv.double() * u.double()).sum().item()
+    assert abs(fd - an) < 2e-3 * abs(an), (fd, an)
+
+
+@pytest.mark.parametrize("H", [768, 512])
+def test_exact_lora_grad_f32(ops, H):
+    """bsclip_lora_grad_f32 against the f64 products (reference lora_layer.py:16-39: q += B_q (A_q y), v += B_v (A_v y)); adds to
+    what the gradient buffers hold."""
+    M = 1237
+    dqkv, y = dev(rnd(M, 3 * H + 8, seed=1))[:, :3 * H], dev(rnd(M, H, seed=2))
+    A, Bm = dev(rnd(8, H, seed=3, scale=0.05)), dev(rnd(2, H, 4, seed=4, scale=0.05))
+    dA, dB = dev(rnd(8, H, seed=5)), dev(rnd(2, H, 4, seed=6))
+    dA0, dB0 = dA.clone().double(), dB.clone().double()
+    ops.lora_grad_f32(dqkv, y, M, H, A, Bm, dA, dB)
+    yd, Ad, Bd = y.double(), A.double(), Bm.double()
+    dq, dv = dqkv[:, :H].double(), dqkv[:, 2 * H:].double()
+    t = yd @ Ad.t()                                              # [M, 8]
+    ref_dA = torch.cat([(dq @ Bd[0]).t() @ yd, (dv @ Bd[1]).t() @ yd], 0)
+    ref_dB = torch.stack([dq.t() @ t[:, :4], dv.t() @ t[:, 4:]], 0)
+    assert rel_err(dA.double() - dA0, ref_dA) < 1e-5 and rel_err(dB.double() - dB0, ref_dB) < 1e-5
+    again_A, again_B = dA0.float().clone(), dB0.float().clone()
+    ops.lora_grad_f32(dqkv, y, M, H, A, Bm, again_A, again_B)
+    assert torch.equal(again_A, dA) and torch.equal(again_B, dB)     # fixed summation order
+
+
+def test_exact_split_operand_gemms(ops):
+    """The split-operand GEMM family of the exact backward: dX = dY W through split3_transpose(W) (with the LoRA update folded),
+    dW = dY^T X through split3_transpose of both operands (reduction over a ragged number of rows, zero-padded), and
+    dgelu_split3, each against the f64 product at 3e-5 where the plain bf16 GEMM sits at 3e-3."""
+    H, M = 256, 333
+    w = dev(rnd(3 * H, H, seed=1, scale=H ** -0.5))
+    A, Bm = dev(rnd(8, H, seed=2, scale=0.1)), dev(rnd(2, H, 4, seed=3, scale=0.1))
+    weff = w.double().clone()
+    weff[:H] += Bm[0].double() @ A[:4].double()
+    weff[2 * H:] += Bm[1].double() @ A[4:].double()
+    dy = dev(rnd(M, 3 * H, seed=4))
+    wt = ops.split3_transpose(w, torch.empty(H * 9 * H, device="cuda", dtype=torch.bfloat16), 1, lora_a=A, lora_b=Bm)
+    a3 = ops.split3_rows(dy, torch.empty(M, 9 * H, device="cuda", dtype=torch.bfloat16))
+    dx = torch.empty(M, H, device="cuda")
+    from bioscanclip.hip.ops import EPI_F32, EPI_RESID_F32
+    ops.gemm(a3, wt, dx, EPI_F32)
+    assert rel_err(dx.double(), dy.double() @ weff) < 3e-5
+    x = dev(rnd(M, H, seed=5))
+    Mp = (M + 63) // 64 * 64
+    ta = ops.split3_transpose(dy, torch.empty(3 * H * 3 * Mp, device="cuda", dtype=torch.bfloat16), 0)
+    tb = ops.split3_transpose(x, torch.empty(H * 3 * Mp, device="cuda", dtype=torch.bfloat16), 1)
+    gw = dev(rnd(3 * H, H, seed=6))
+    gw0 = gw.double().clone()
+    ops.gemm(ta, tb, gw, EPI_RESID_F32, resid=gw)
+    assert rel_err(gw.double() - gw0, dy.double().t() @ x.double()) < 3e-5
+    z, g = dev(rnd(M, H, seed=7, scale=1.5)), dev(rnd(M, H, seed=8))
+    o32 = torch.empty(M, H, device="cuda")
+    d3 = ops.dgelu_split3(g, z, dst=torch.empty(M, 3 * H, device="cuda", dtype=torch.bfloat16), out32=o32)
+    ref = g.double() * dgelu(z.double())
+    assert rel_err(o32.double(), ref) < 1e-6
+    assert rel_err(d3[:, :H].float().double() + d3[:, H:2 * H].float().double(), ref) < 2e-5 and torch.equal(d3[:, :H], d3[:, 2 * H:])
+
+
+def test_exact_layernorm_bwd_f32_operands(ops):
+    """bsclip_layernorm_bwd with the f32 GEMM gradient in and the f32 operand out (resid_flags bits 2 / 3): the same numbers as the
+    bf16-operand call when the inputs are bf16-representable, and the operand carries the dropout mask of the bf16 one."""
+    M, H = 300, 768
+    x, gr = dev(rnd(M, H, seed=1)), dev(rnd(M, H, seed=2))
+    gg16 = dev(rnd(M, H, seed=3)).bfloat16()
+    gamma = dev(rnd(H, seed=4).abs() + 0.5)
+    stats = torch.stack([x.mean(1), (x.var(1, unbiased=False) + 1e-6).rsqrt()], 1).contiguous()
+    drop = (0.1, 77)
+    for mode in (0, 1):
+        d_ref, op_ref = torch.empty(M, H, device="cuda"), torch.empty(M, H, device="cuda", dtype=torch.bfloat16)
+        ops.layernorm_bwd(x, stats, gamma, mode, g_resid=gr, g_gemm=gg16, dx_f32=d_ref, dx_bf16=op_ref, dropout=drop)
+        d_new, op_new = torch.empty(M, H, device="cuda"), torch.empty(M, H, device="cuda")
+        ops.layernorm_bwd(x, stats, gamma, mode, g_resid=gr, g_gemm=gg16.float(), dx_f32=d_new, dx_bf16=op_new, dropout=drop)
+        assert torch.equal(d_new, d_ref) and torch.equal(op_new.bfloat16(), op_ref)
+        kept = op_new != 0
+        assert torch.allclose(op_new[kept], d_new[kept] / 0.9, rtol=1e-6) and 0.85 < kept.float().mean().item() < 0.95
