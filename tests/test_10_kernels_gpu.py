@@ -801,11 +801,13 @@ def test_exact_attention_dropout_masks_are_the_bf16_kernels(ops):
     ops.attn_bwd(q16, dctx.bfloat16(), lse16, B, S, heads, 0.125, dq16, dropout=drop)
     assert rel_err(dq16.float(), dqkv) < 3e-2
     u = dev(rnd(B * S, 3 * H, seed=6))
-    h = 2e-2
     cp, cm = torch.empty_like(ctx), torch.empty_like(ctx)
-    ops.attn_fwd_f32(qkv + h * u, B, S, heads, 0.125, cp, lse, dropout=drop)
-    ops.attn_fwd_f32(qkv - h * u, B, S, heads, 0.125, cm, lse, dropout=drop)
-    fd = (((cp - cm).double() * dctx.double()).sum() / (2 * h)).item()
+
+    def central(h):
+        ops.attn_fwd_f32(qkv + h * u, B, S, heads, 0.125, cp, lse, dropout=drop)
+        ops.attn_fwd_f32(qkv - h * u, B, S, heads, 0.125, cm, lse, dropout=drop)
+        return (((cp - cm).double() * dctx.double()).sum() / (2 * h)).item()
+    fd = (4 * central(1e-2) - central(2e-2)) / 3          # Richardson: the h^2 term of the central difference cancels
     an = (dqkv.double() * u.double()).sum().item()
     assert abs(fd - an) < 2e-3 * abs(an), (fd, an)
 
