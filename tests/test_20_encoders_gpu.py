@@ -268,18 +268,38 @@ def test_training_trajectory_matches_reference(with_text):
     """BASELINE config 1 (I+D, B=8, 10 steps over a two-batch epoch) and a 6-step I+D+T run: loss per step and trainable
     parameters after the last step vs the trajectory the imported reference produced with torch.optim.AdamW.  The golden
     loss falls from 2.24 (> ln 8) to 0.044: only the right embeddings, loss, gradients and optimizer reproduce it."""
+    _run_trajectory(with_text, TRAJ_TOL[with_text], f"trajectory text={with_text}")
+
+
+# the same trajectories in the exact mode: north_star's "outputs (embeddings, loss, gradients) match the reference CPU path within
+# 1e-3" on the first step's embeddings and gradient fingerprints and on the loss of EVERY step (the late steps carry whatever the
+# early ones differed by, amplified by a loss that falls 50 x; measured values in gpurun_out/parity.jsonl)
+TRAJ_TOL_EXACT = dict(emb=1e-3, grad=1e-3, loss=1e-3, params=1e-3)
+
+
+@pytest.mark.parametrize("with_text", [False, True])
+def test_training_trajectory_exact_mode_within_north_star_tolerance(with_text, monkeypatch):
+    """BSCLIP_PARITY=2, whole training steps: configs[0] (I+D, B=8, 10 steps) and the 6-step I+D+T run against the trajectory the
+    imported reference produced -- embeddings, gradients, per-step loss and the parameters after the last AdamW step within 1e-3."""
+    from bioscanclip.hip import engine
+    monkeypatch.setattr(engine, "RESID_STREAM_BF16", False)
+    monkeypatch.setattr(engine, "GRAD_STREAM_BF16", False)
+    monkeypatch.setattr(engine, "EXACT_FORWARD", True)
+    _run_trajectory(with_text, TRAJ_TOL_EXACT, f"trajectory_exact text={with_text}")
+
+
+def _run_trajectory(with_text, tol, log_name):
     from helpers import summary_distance
     from bioscanclip.hip.optim import FusedAdamW
     from bioscanclip.model.loss_func import ContrastiveLoss
     g = load_golden("trajectory_idt" if with_text else "trajectory_id")
-    tol = TRAJ_TOL[with_text]
     assert g["losses"][-1] < 0.6 * g["losses"][0] and abs(g["losses"][0] - torch.tensor(float(g["B"])).log().item()) > 5e-3
     model, sd = _build_clip(with_text, g["weight_seed"])
     model.to("cuda").train()
     opt = FusedAdamW(model.parameters(), lr=g["lr"])
     crit = ContrastiveLoss(criterion=torch.nn.CrossEntropyLoss(), logit_scale=1 / 0.07)
     losses = []
-    rec = {"test": f"trajectory text={with_text}"}
+    rec = {"test": log_name}
     for s in range(g["steps"]):
         image, dna, text, label = synth.synth_batch(g["B"], seed=g["batch_seed0"] + s % g["n_batches"], with_text=with_text)
         opt.zero_grad()

@@ -222,15 +222,22 @@ def test_engine_train_vs_eval_mode():
     assert all(torch.isfinite(g).all() and g.abs().sum() > 0 for g in grads)
 
 
-@pytest.mark.parametrize("full_ft", [False, True])
-def test_directional_derivative_with_the_masks_held_fixed(full_ft):
+@pytest.mark.parametrize("full_ft,exact", [(False, False), (True, False), (False, True)])
+def test_directional_derivative_with_the_masks_held_fixed(full_ft, exact, monkeypatch):
     """End-to-end check of the backward pass WITH dropout: the masks are a function of (site seed, element, step word), so with
     the engine's step word reset before every forward the encoder is a deterministic function of its parameters, and the
     gradient the kernels produce must agree with a central finite difference of  L = sum(y * cot)  along a random direction over
     all trainable tensors (the gradient direction, per tensor at the parameter's scale) -- LoRA pairs + decoder, or every parameter under full fine-tuning (weight, bias, LayerNorm,
     embedding gradients are then taken under the forward's masks, including the embedding LayerNorm's).  Three step sizes; the
-    smallest must agree to 5 % (measured: 1.2 % in the LoRA regime, 1e-4 under full fine-tuning)."""
+    smallest must agree to 5 % (measured: 1.2 % in the LoRA regime, 1e-4 under full fine-tuning).  ``exact``: the same under
+    BSCLIP_PARITY=2 -- the f32 attention forward / backward, the f32 LayerNorm operands and the split-operand GEMMs draw and
+    re-apply the masks of the same three dropout sites."""
     from oracle import synth
+    if exact:
+        from bioscanclip.hip import engine
+        monkeypatch.setattr(engine, "RESID_STREAM_BF16", False)
+        monkeypatch.setattr(engine, "GRAD_STREAM_BF16", False)
+        monkeypatch.setattr(engine, "EXACT_FORWARD", True)
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
     m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2)), r=4, num_classes=768,
@@ -282,4 +289,7 @@ def test_directional_derivative_with_the_masks_held_fixed(full_ft):
     # measured: LoRA regime 0.978 / 1.010 / 0.988, full fine-tuning 0.647 / 0.949 / 0.9999 -- the function is strongly curved along
     # its own gradient (softmax-mean output), the finite difference converges onto the kernels' gradient as the step shrinks;
     # far below one bf16 ulp per weight the staircase averages out over the 10^5 .. 10^8 perturbed weights
+    print("directional derivative, finite difference / analytic:", dict(full_ft=full_ft, exact=exact), ratios)
     assert abs(ratios[1.25e-4] - 1.0) < 0.05 and abs(ratios[5e-4] - 1.0) < 0.12, ratios
+    if exact:
+        assert m._engine.exact() and abs(ratios[5e-4] - 1.0) < 0.02, ratios
