@@ -581,10 +581,11 @@ def main():
                 out["parity_mode_ms_per_step"] = pm["ms_per_step"]
                 xm = side_measurement(device, True, False, 256, steps=max(4, a.steps // 4), parity=2)
                 out["exact_mode_ms_per_step"] = xm["ms_per_step"]
-                out["exact_mode"] = ("BSCLIP_PARITY=2: the forward that meets north_star's 1e-3 against the f32 reference (every trunk GEMM on "
-                                     "split-bf16 operands = 3 x the K, LoRA folded in f32, exact-erf GELU, f32 attention on the vector ALU; "
-                                     "embeddings 4e-5 / 1.5e-5 / 6e-6 at full depth, tests/test_20_encoders_gpu.py), default backward; same "
-                                     "workload as the headline: what bf16 operands buy is headline ms_per_step vs this")
+                out["exact_mode"] = ("BSCLIP_PARITY=2: the step that meets north_star's 1e-3 against the f32 reference on embeddings, loss and every "
+                                     "gradient (forward AND backward GEMMs on split-bf16 operands = 3 x the K, LoRA folded in f32, exact-erf GELU, "
+                                     "f32 attention forward / backward and f32 LoRA gradients on the vector ALU; golden 10-step trajectory within "
+                                     "1e-3, tests/test_20_encoders_gpu.py); same workload as the headline: what bf16 operands buy is the "
+                                     "headline's ms_per_step against this")
                 out["parity_mode"] = ("BSCLIP_PARITY=1: f32 residual and residual-gradient streams + split-bf16 patch embedding, same workload "
                                       "as the headline (what the default's bf16 streams buy: headline ms_per_step vs this); trunk GEMM and "
                                       "attention operands stay bf16 in both (DESIGN.md 4)")

@@ -30,10 +30,15 @@ def _build(seed, with_text, full_ft=False):
     return model.cuda().train()     # HF dropout 0.1 / 0.1 active
 
 
-@pytest.mark.parametrize("with_text,full_ft", [(False, False), (True, False), (True, True)])
-def test_graph_replay_equals_eager_step(with_text, full_ft):
+@pytest.mark.parametrize("with_text,full_ft,exact", [(False, False, False), (True, False, False), (True, True, False), (True, False, True)])
+def test_graph_replay_equals_eager_step(with_text, full_ft, exact, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    if exact:   # BSCLIP_PARITY=2: the exact forward and backward are captured like the default ones (dropout at the HF defaults)
+        from bioscanclip.hip import engine
+        monkeypatch.setattr(engine, "RESID_STREAM_BF16", False)
+        monkeypatch.setattr(engine, "GRAD_STREAM_BF16", False)
+        monkeypatch.setattr(engine, "EXACT_FORWARD", True)
     from bioscanclip.hip.graph import GraphedStep
     from bioscanclip.hip.optim import FusedAdamW
     from bioscanclip.model.loss_func import ContrastiveLoss
@@ -65,6 +70,7 @@ def test_graph_replay_equals_eager_step(with_text, full_ft):
             losses.append(loss.item())
         if g is not None:
             assert g.graph is not None
+        assert all(m._engine.exact() == exact for m in (model.image_encoder, model.dna_encoder))
         runs[mode] = (losses, {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad})
     le, lg = runs["eager"][0], runs["graph"][0]
     assert len(set(round(x, 6) for x in le)) == steps          # dropout + new batches: every step differs

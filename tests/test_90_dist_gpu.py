@@ -32,6 +32,9 @@ def _build(with_text=False, mode="lora"):
                     num_classes=768, lora_layer=ll) if with_text else None
     model = SimpleCLIP(img, dna, txt)
     model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=51))
+    if mode == "exact":     # BSCLIP_PARITY=2 (a process-wide switch: the spawned ranks set it here, the parent test restores it)
+        from bioscanclip.hip import engine
+        engine.set_parity_mode(2)
     if mode == "fullft":
         from bioscanclip.model.simple_clip import enable_full_fine_tuning
         enable_full_fine_tuning(model)
@@ -83,10 +86,13 @@ def _worker(rank, world, port, B, tmp, with_text, mode):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("with_text,mode", [(False, "lora"), (True, "lora"), (True, "fullft"), (False, "fp8")])
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path, with_text, mode):
+@pytest.mark.parametrize("with_text,mode", [(False, "lora"), (True, "lora"), (True, "fullft"), (False, "fp8"), (True, "exact")])
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path, with_text, mode, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    from bioscanclip.hip import engine
+    for name in ("RESID_STREAM_BF16", "GRAD_STREAM_BF16", "EXACT_FORWARD"):      # _build(mode="exact") flips them: restored on exit
+        monkeypatch.setattr(engine, name, getattr(engine, name))
     world, B = 2, 4
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -108,7 +114,8 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, with_text, mode):
     assert r0["order"] == r1["order"] and len(r0["order"]) == (3 if with_text else 2)   # same collectives, same order, every rank
     # full fine-tuning: the all-reduced buffers are the whole encoders (0.35 / 0.35 / 0.12 GB at full depth), every parameter's
     # gradient is in `flat`; fp8 trunks: per-sample quantisation is batch-independent (scale 1 / per-row weight scales)
-    assert rel_err(r0["flat"], flat) < (5e-3 if mode == "fullft" else 2e-3)
+    # exact mode: f32 gradients, f32-accumulated split-operand GEMMs -- the two-rank step IS the single-process step to f32 rounding
+    assert rel_err(r0["flat"], flat) < {"fullft": 5e-3, "exact": 2e-5}.get(mode, 2e-3)
 
 
 def _graph_worker(rank, world, port, B, tmp, steps):
