@@ -390,6 +390,7 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from bioscanclip.hip import dist as hdist
+    from bioscanclip.hip import engine as _engine
     from bioscanclip.hip.optim import FusedAdamW
     from bioscanclip.model.loss_func import ContrastiveLoss, GlobalBatchContrastiveLoss
 
@@ -542,6 +543,11 @@ def main():
                        "launch_path": ("eager (Python enqueue)" if graphed is None else
                                        "per-tower captured hipGraphs (forward_k | loss | backward_k | AdamW), each tower's all-gather / all-reduce issued from its stream between them"
                                        if world > 1 or force_dist else "hipGraph replay (one captured step)"),
+                       "numerics": {0: "default: bf16 GEMM / attention operands, bf16 residual and residual-gradient streams",
+                                    1: "BSCLIP_PARITY=1: f32 residual / residual-gradient streams (diagnostic run)",
+                                    2: "BSCLIP_PARITY=2: exact mode -- split-bf16 operands on every GEMM, f32 attention (diagnostic run: "
+                                       "1e-3 parity with the f32 reference, not the benchmark configuration)"}[
+                                        2 if _engine.EXACT_FORWARD else 0 if _engine.GRAD_STREAM_BF16 else 1],
                        "final_loss": round(final_loss, 6)},
             "step_roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
