@@ -2,7 +2,10 @@
 
 Per batch, in the reference's order: inputs to the device, ``optimizer.zero_grad()``, ``model(image, dna, text)``,
 ``criterion(...)``, ``backward()``, ``optimizer.step()``, ``scheduler.step()``.  What differs, deliberately:
-autograd anomaly mode stays off, the loss is read back once per step (the reference synchronises three times), tqdm / wandb
+autograd anomaly mode (switched on by the reference in every epoch, ``train_epoch.py:12``) is off unless asked for with
+``BSCLIP_DETECT_ANOMALY=1`` / ``hip.engine.set_detect_anomaly(True)`` -- then every tower's output and gradients and the loss are
+checked for Inf / NaN on the device and a RuntimeError names where they first appear, on the eager launch path --, the loss is
+read back once per step (the reference synchronises three times), tqdm / wandb
 are optional, and under a process group of more than one rank the flat trainable gradients are all-reduced (SUM) before the
 optimizer step.  Returns the mean loss of the epoch.
 
@@ -44,7 +47,8 @@ def _graphed_step(model, optimizer, criterion, device):
     """The captured step for this (model, optimizer, criterion), created on first use and kept on the model; None when the
     step has to stay eager: BSCLIP_GRAPH=0, a CPU device, an optimizer other than FusedAdamW, more than one rank."""
     from bioscanclip.hip import dist as hdist
-    if os.environ.get("BSCLIP_GRAPH", "1") == "0" or torch.device(device).type != "cuda":
+    from bioscanclip.hip import engine
+    if os.environ.get("BSCLIP_GRAPH", "1") == "0" or torch.device(device).type != "cuda" or engine.DETECT_ANOMALY:
         return None
     if not hasattr(optimizer, "enable_device_hyper"):
         return None
@@ -125,6 +129,10 @@ def train_epoch(activate_wandb, total_epochs, epoch, dataloader, model, optimize
             report(pending[0], value, pending[1])
             pending = None
         value = loss.item()  # the eager step's only host synchronisation
+        if value != value or value in (float("inf"), float("-inf")):
+            from bioscanclip.hip import engine
+            if engine.DETECT_ANOMALY:
+                raise RuntimeError(f"non-finite loss {value} at step {step} of epoch {epoch} (BSCLIP_DETECT_ANOMALY)")
         running += value
         report(step, value, lr)
     if pending is not None:

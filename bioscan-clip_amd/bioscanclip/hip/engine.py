@@ -41,15 +41,14 @@ RESID_STREAM_BF16 = os.environ.get("BSCLIP_RESID_STREAM", "bf16").lower() != "f3
 PATCH_SPLIT = os.environ.get("BSCLIP_PATCH_SPLIT", "1") != "0"
 
 
-# BSCLIP_PARITY=1 / set_parity_mode(True): the most exact configuration this build has -- f32 residual stream, f32
-# residual-gradient stream, split-bf16 patch embedding -- at the price bench.py reports as `parity_mode_ms_per_step`.  It is NOT
-# north_star's 1e-3: every trunk GEMM and the attention products still take bf16 operands (DESIGN.md 4 prices the split-bf16
-# form of those: 3 x the MFMA work of the step and hi / lo outputs from every producer kernel -- not built).
-# BSCLIP_PARITY=2 / set_parity_mode(2): the EXACT forward (round 4, csrc/exact.hip) -- every trunk GEMM on split-bf16 operands
-# (hi + lo, K tripled: exact to ~2^-16 on the bf16 matrix cores), LoRA folded into the weight in f32, exact-erf GELU in f32,
-# attention in f32 on the vector ALU, f32 streams.  Embeddings within 1e-3 of the f32 reference at depth 12 (measured 2e-5 on the
-# CPU emulation before it was built, tests/test_20_encoders_gpu.py holds the GPU path to it); the backward is the default one on the
-# bf16 copies of this forward's activations.  LoRA-regime ViT / BERT engines only (fp8 and full fine-tuning keep their own paths).
+# BSCLIP_PARITY=1 / set_parity_mode(1): f32 residual stream, f32 residual-gradient stream, split-bf16 patch embedding -- at the
+# price bench.py reports as `parity_mode_ms_per_step`.  NOT north_star's 1e-3: every trunk GEMM and the attention products still
+# take bf16 operands.
+# BSCLIP_PARITY=2 / set_parity_mode(2): the EXACT mode (round 4, csrc/exact.hip) -- every GEMM of the forward and of the backward
+# on split-bf16 operands (hi + lo, K tripled: exact to ~2^-16 on the bf16 matrix cores), LoRA folded into the weight in f32,
+# exact-erf GELU, attention forward / backward and the LoRA gradients in f32 on the vector ALU, f32 streams.  Embeddings, loss and
+# every gradient within 1e-3 of the f32 reference at depth 12 (measured <= 1.5e-4, tests/test_20_encoders_gpu.py).
+# LoRA-regime ViT / BERT engines only (fp8 and full fine-tuning keep their own paths, on the f32 streams).
 EXACT_FORWARD = False
 if os.environ.get("BSCLIP_PARITY", "0") in ("1", "2"):
     GRAD_STREAM_BF16 = RESID_STREAM_BF16 = False
@@ -71,6 +70,50 @@ def set_parity_mode(on, model=None):
             if getattr(m, "_engine", None) is not None:
                 m._engine = None
     return prev
+
+
+# BSCLIP_DETECT_ANOMALY=1 / set_detect_anomaly(True): this build's counterpart of ``torch.autograd.set_detect_anomaly(True)``, which
+# the reference loop switches on in every epoch (train_epoch.py:12).  Every encoder forward / backward is followed by a device-side
+# count of Inf / NaN values (bsclip_count_nonfinite) in its output / its flat gradient buffer, read back at once; on a hit the
+# per-layer activations are probed in execution order and a RuntimeError names the first tensor that holds non-finite values (the
+# reference's anomaly mode names the autograd node).  A debugging aid: it synchronises the host after every tower, so the step
+# stays eager (train_epoch skips the captured-graph path) -- off by default, as SURVEY App. B-6 decides for timed runs.
+DETECT_ANOMALY = os.environ.get("BSCLIP_DETECT_ANOMALY", "0") == "1"
+
+
+def set_detect_anomaly(on):
+    global DETECT_ANOMALY
+    prev, DETECT_ANOMALY = DETECT_ANOMALY, bool(on)
+    return prev
+
+
+def count_nonfinite(t):
+    """Number of Inf / NaN elements of an f32 / bf16 device tensor (host-synchronising: a debugging aid)."""
+    c = torch.zeros(1, dtype=torch.int32, device=t.device)
+    ops.count_nonfinite(t.contiguous(), c)
+    return int(c.item())
+
+
+def _anomaly_check(engine, phase, out=None):
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("BSCLIP_DETECT_ANOMALY reads every tower's result back to the host: it cannot run inside a hipGraph "
+                           "capture (train_epoch takes the eager path when it is on)")
+    who = type(engine).__name__
+    if phase == "forward":
+        if count_nonfinite(out) == 0:
+            return
+        for name, t in engine.anomaly_probes():
+            if count_nonfinite(t):
+                raise RuntimeError(f"{who} forward: non-finite values first appear in {name} (BSCLIP_DETECT_ANOMALY)")
+        raise RuntimeError(f"{who} forward: non-finite values in the encoder output (BSCLIP_DETECT_ANOMALY)")
+    if count_nonfinite(engine.flat.grad) == 0:
+        return
+    owner = getattr(engine, "_owner", None)
+    names = {id(p): n for n, p in owner.named_parameters()} if owner is not None else {}
+    bad = [names.get(id(p), f"trainable tensor #{i}") for i, p in enumerate(engine.flat.params)
+           if p.grad is not None and count_nonfinite(p.grad)]
+    raise RuntimeError(f"{who} backward: non-finite gradient values in {', '.join(bad[:6])}"
+                       f"{' ...' if len(bad) > 6 else ''} (BSCLIP_DETECT_ANOMALY)")
 
 
 _WS_GEN = itertools.count(1)   # every workspace gets a unique, never reused number (hip/graph.py keys captured graphs on it)
@@ -378,6 +421,20 @@ class ViTEngine(EncoderEngineBase):
         ws["h2_c"], ws["act_c"], ws["z_c"] = z(B, H), z(B, FF), z(B, FF, dt=torch.uint8)
         self.ws = ws
         return ws
+
+    def anomaly_probes(self):
+        """(name, tensor) of the forward's saved activations in execution order (BSCLIP_DETECT_ANOMALY).  The last block's
+        sub-layers exist on the token-0 rows only."""
+        ws, L, B, S, H = self.ws, len(self.layers), self.ws["B"], self.S, self.H
+        qkv, ctx = ("qkv32s", "ctx32s") if self.exact() else ("qkv", "ctx")
+        yield "the patch embedding + position table", ws["x"][0]
+        for l in range(L):
+            yield f"blocks.{l}.attn.qkv output", ws[qkv][l]
+            if l < L - 1:
+                yield f"blocks.{l}.attn output", ws[ctx][l]
+            tok0 = (lambda t: t.view(B, S * H)[:, :H]) if l == L - 1 else (lambda t: t)
+            yield f"blocks.{l} residual stream after attention", tok0(ws["x"][2 * l + 1])
+            yield f"blocks.{l} residual stream after the MLP", tok0(ws["x"][2 * l + 2])
 
     # -------------------------------------------------------------------------------------------- forward
     def _forward_exact(self, image, ws):
@@ -779,6 +836,18 @@ class BertEngine(EncoderEngineBase):
             ops.counter_add(self._step_word, 1)
         ops.set_dropout_step(self._step_word)
 
+    def anomaly_probes(self):
+        """(name, tensor) of the forward's saved activations in execution order (BSCLIP_DETECT_ANOMALY)."""
+        ws = self.ws
+        qkv = "qkv32s" if self.exact() else "qkv"
+        yield "the embedding sum (word + position + token type)", ws["emb"]
+        for l in range(len(self.layers)):
+            yield f"encoder.layer.{l}.attention.self q / k / v", ws[qkv][l]
+            yield f"encoder.layer.{l}.attention.output (pre-LayerNorm sum)", ws["s1"][l]
+            yield f"encoder.layer.{l}.output (pre-LayerNorm sum)", ws["s2"][l]
+        if self.head == "mlm_softmax_mean":
+            yield "cls.predictions.decoder logits", ws["logits"]
+
     def _forward_exact(self, ws, key_bias):
         """BSCLIP_PARITY=2 (see ViTEngine._forward_exact): the layers after the embedding LayerNorm (which has just written the f32
         layer input ys[0]) with every Linear on split-bf16 operands, f32 attention, exact-erf GELU; dropout sites and seeds as in
@@ -1045,7 +1114,10 @@ class _EncoderFn(torch.autograd.Function):
         ctx.engine = engine
         ctx.parent = _PARENT_STREAM[-1] if _PARENT_STREAM else None
         ctx.generation = engine._fwd_generation
-        return engine.forward(*fwd_args)
+        out = engine.forward(*fwd_args)
+        if DETECT_ANOMALY:
+            _anomaly_check(engine, "forward", out)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
@@ -1054,6 +1126,8 @@ class _EncoderFn(torch.autograd.Function):
                                "of the same encoder: the HIP engines hold one workspace per encoder -- run backward before the "
                                "next training-mode forward (the reference loop does: train_epoch.py:28-42)")
         ctx.engine.backward(dout.contiguous())
+        if DETECT_ANOMALY:
+            _anomaly_check(ctx.engine, "backward")
         from .dist import start_allreduce
         start_allreduce(ctx.engine.flat, type(ctx.engine).__name__)  # global-batch step: this tower's gradients are complete on this stream
         here = torch.cuda.current_stream()
@@ -1115,9 +1189,13 @@ def _engine_for(module, build):
 def run_encoder(module, build, fwd_args):
     eng = _engine_for(module, build)
     eng.training = module.training
+    eng._owner = module
     # the engine keeps ONE set of saved activations (its workspace): any later forward of the same encoder, with or without
     # autograd, overwrites them -- _EncoderFn.backward checks that it still owns them
     eng._fwd_generation = getattr(eng, "_fwd_generation", 0) + 1
     if torch.is_grad_enabled() and any(p.requires_grad for p in eng.flat.params):
         return _EncoderFn.apply(eng, fwd_args, *eng.flat.params)
-    return eng.forward(*fwd_args)
+    out = eng.forward(*fwd_args)
+    if DETECT_ANOMALY:
+        _anomaly_check(eng, "forward", out)
+    return out

@@ -113,6 +113,7 @@ SIGNATURES = {
     "bsclip_adamw_step_dev": (I, [P, P, P, P, L, P, F, F, F, F, F, P]),
     "bsclip_set_dropout_step": (I, [P]),
     "bsclip_counter_add": (I, [P, U, P]),
+    "bsclip_count_nonfinite": (I, [P, L, I, P, P]),
     "bsclip_clock_probe": (I, [P, P]),
 }
 

@@ -674,6 +674,13 @@ def set_dropout_step(counter):
     check(_l.load().bsclip_set_dropout_step(_p(counter)))
 
 
+def count_nonfinite(t, counter):
+    """counter (int32 / uint32 device word) += the number of Inf / NaN elements of the contiguous f32 / bf16 tensor ``t``."""
+    _req(t.dtype in (F32, BF16) and t.is_contiguous() and t.numel() > 0, "count_nonfinite: contiguous f32 / bf16 tensor")
+    _req(counter.dtype == torch.int32 and counter.numel() >= 1 and counter.device == t.device, "count_nonfinite: int32 device counter")
+    check(_l.load().bsclip_count_nonfinite(_p(t), t.numel(), int(t.dtype == BF16), _p(counter), _stream()))
+
+
 def counter_add(counter, inc=1):
     _req(counter.is_cuda and counter.numel() >= 1 and counter.element_size() == 4, "counter: 4-byte device word")
     check(_l.load().bsclip_counter_add(_p(counter), int(inc) & 0xFFFFFFFF, _stream()))

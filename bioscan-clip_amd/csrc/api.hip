@@ -48,6 +48,28 @@ extern "C" int bsclip_clock_probe(unsigned long long* out32_dev, void* stream) {
     return BSCLIP_OK;
 }
 
+// *counter += number of Inf / NaN elements of x (exponent field all ones): the check behind BSCLIP_DETECT_ANOMALY, the build's
+// counterpart of the reference's torch.autograd.set_detect_anomaly(True) (train_epoch.py:12)
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const void* __restrict__ x, long n, int is_bf16, uint32_t* __restrict__ counter) {
+    unsigned bad = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        if (is_bf16) bad += (static_cast<const unsigned short*>(x)[i] & 0x7f80u) == 0x7f80u;
+        else bad += (static_cast<const unsigned*>(x)[i] & 0x7f800000u) == 0x7f800000u;
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(counter, bad);
+}
+
+extern "C" int bsclip_count_nonfinite(const void* x, int64_t n, int is_bf16, uint32_t* counter_dev, void* stream) {
+    BSCLIP_REQUIRE(x && counter_dev && n > 0 && (is_bf16 == 0 || is_bf16 == 1), "bsclip_count_nonfinite: bad arguments");
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long)n, is_bf16,
+                       counter_dev);
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
 extern "C" int bsclip_counter_add(uint32_t* counter_dev, uint32_t inc, void* stream) {
     BSCLIP_REQUIRE(counter_dev, "bsclip_counter_add: null pointer");
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), counter_dev, inc);

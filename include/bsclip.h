@@ -44,6 +44,11 @@ int bsclip_clock_probe(unsigned long long* out32_dev, void* stream);
  * the same value, so regenerated masks match. */
 int bsclip_set_dropout_step(const uint32_t* step_dev);
 int bsclip_counter_add(uint32_t* counter_dev, uint32_t inc, void* stream);
+/* *counter_dev += the number of Inf / NaN elements among the n contiguous f32 (is_bf16 = 0) or bf16 (1) values at x.  The check behind
+ * BSCLIP_DETECT_ANOMALY=1, this build's counterpart of torch.autograd.set_detect_anomaly(True) in the reference loop
+ * (train_epoch.py:12): the engines probe their outputs, gradients and per-layer activations and name where non-finite values
+ * first appear. */
+int bsclip_count_nonfinite(const void* x, int64_t n, int is_bf16, uint32_t* counter_dev, void* stream);
 
 /* ---- GEMM family: C = epilogue(A[M,K] * B[N,K]^T), bf16 operands, f32 accumulate (MFMA 16x16x32) -------------
  * Replaces every torch.nn.Linear on the path: timm Attention.qkv/proj, Mlp.fc1/fc2 (via

@@ -527,3 +527,33 @@ def test_requires_gpu_inputs():
     m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=1), r=4, num_classes=768)
     with pytest.raises(RuntimeError, match="GPU"):
         m(torch.zeros(1, 3, 224, 224))
+
+
+def test_detect_anomaly_names_where_non_finite_values_appear(monkeypatch):
+    """BSCLIP_DETECT_ANOMALY (hip/engine.py): the counterpart of the reference loop's ``torch.autograd.set_detect_anomaly(True)``
+    (train_epoch.py:12).  A NaN planted in block 1's LoRA-A makes the forward raise and name block 1's QKV output (block 0's
+    tensors are clean); an infinite cotangent makes the backward raise and name gradient tensors; clean runs pass untouched."""
+    from bioscanclip.hip import engine, ops
+    from bioscanclip.model import arch
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    c = torch.zeros(1, dtype=torch.int32, device="cuda")
+    t = torch.randn(100_003, device="cuda")
+    t[5], t[77_777], t[100_002] = float("nan"), float("inf"), float("-inf")
+    ops.count_nonfinite(t, c)
+    ops.count_nonfinite(t.bfloat16(), c)
+    ops.count_nonfinite(torch.randn(4096, device="cuda"), c)
+    assert c.item() == 6
+    monkeypatch.setattr(engine, "DETECT_ANOMALY", True)
+    m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=3), r=4, num_classes=768)
+    _load(m, "image_encoder.", 13)
+    m.to("cuda").train()
+    x = synth.synth_batch(2, seed=23)[0].cuda()
+    y = m(x)
+    (y * torch.randn_like(y)).sum().backward()          # clean: nothing raised
+    with pytest.raises(RuntimeError, match="backward: non-finite gradient values in .*weight"):
+        y = m(x)
+        (y * float("inf")).sum().backward()
+    with torch.no_grad():
+        m.lora_vit.blocks[1].attn.qkv.linear_a_q.weight[0, 0] = float("nan")
+    with pytest.raises(RuntimeError, match=r"ViTEngine forward: non-finite values first appear in blocks\.1\.attn\.qkv output"):
+        m(x)
