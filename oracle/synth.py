@@ -21,7 +21,25 @@ PATCH_GAIN = 4.0     # ViT patch-embed filters (made zero-sum below)
 DECODER_GAIN = 8.0   # BarcodeBERT decoder: class logits std ~5 -> the softmax-mean embedding is far from uniform
 
 
+_TENSOR_CACHE, _TENSOR_CACHE_BYTES, _TENSOR_CACHE_LIMIT = {}, [0], 12 << 30
+
+
 def synth_tensor(key, shape, seed=0):
+    """``_synth_tensor`` through a per-process cache (the tests build the same 0.2 G-parameter models dozens of times: 3 s of
+    ``randn`` each).  A fresh clone is returned, so callers may train the tensors in place."""
+    k = (key, tuple(shape), seed)
+    t = _TENSOR_CACHE.get(k)
+    if t is None:
+        t = _synth_tensor(key, shape, seed)
+        if t.numel() >= 4096 and _TENSOR_CACHE_BYTES[0] + t.numel() * t.element_size() <= _TENSOR_CACHE_LIMIT:
+            _TENSOR_CACHE[k] = t
+            _TENSOR_CACHE_BYTES[0] += t.numel() * t.element_size()
+            return t.clone()
+        return t
+    return t.clone()
+
+
+def _synth_tensor(key, shape, seed=0):
     """Value rule chosen so that activations and LoRA branches are O(0.1-1) and nothing on the path is degenerate:
     LN gains ~1, biases small, Linear weights ~0.6/sqrt(fan_in), LoRA B non-zero; the query and key
     projections are QK_GAIN times larger so attention rows are peaked (with 0.6/sqrt(fan_in) everywhere the scores have std

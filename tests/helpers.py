@@ -56,3 +56,24 @@ def rel_err(a, b):
     a = a.detach().to("cpu", torch.float64)
     b = b.detach().to("cpu", torch.float64)
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def skip_param_init():
+    """Build a model without running its default parameter initialisers (2-3 s of ``normal_`` / ``kaiming_uniform_`` per
+    full-depth tower on the test box's CPU share).  ONLY for models whose whole ``state_dict`` is loaded right afterwards
+    (``oracle.synth.synth_state_dict`` + strict ``load_state_dict``): until then the parameters are uninitialised memory."""
+    import torch.nn.init as init
+    names = ["normal_", "trunc_normal_", "uniform_", "kaiming_uniform_", "kaiming_normal_", "xavier_uniform_", "xavier_normal_",
+             "zeros_", "ones_", "constant_"]
+    saved = {n: getattr(init, n) for n in names}
+    for n in names:
+        setattr(init, n, lambda t, *a, **k: t)
+    try:
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(init, n, f)

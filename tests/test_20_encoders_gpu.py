@@ -24,7 +24,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import check_summary, load_golden, rel_err  # noqa: E402
+from helpers import check_summary, load_golden, rel_err, skip_param_init  # noqa: E402
 from oracle import refcpu, synth  # noqa: E402
 
 NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)  # parity = deterministic path
@@ -127,8 +127,9 @@ def _compare_encoder(name, module, prefix, sd, hip_in, oracle_fn, cot_key, gold,
 def test_dna_encoder(layers):
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
-    m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=layers, **NODROP)), r=4,
-                          num_classes=768)
+    with skip_param_init():
+        m = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=layers, **NODROP)), r=4,
+                              num_classes=768)
     sd = _load(m, "dna_encoder.", 11)
     _, dna, _, _ = synth.synth_batch(2, seed=21)
     fn = lambda s, emulate=False, f64=False: refcpu.barcode_bert_encoder(s, dna, emulate_bf16=emulate)
@@ -151,7 +152,8 @@ def test_text_encoder():
 def test_vit_encoder(depth):
     from bioscanclip.model import arch
     from bioscanclip.model.image_encoder import LoRA_ViT_timm
-    m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=depth), r=4, num_classes=768)
+    with skip_param_init():
+        m = LoRA_ViT_timm(arch.VisionTransformerParams(depth=depth), r=4, num_classes=768)
     sd = _load(m, "image_encoder.", 13)
     image, _, _, _ = synth.synth_batch(2, seed=23)
     fn = lambda s, emulate=False, f64=False: refcpu.vit_encoder(s, image.double() if f64 else image, emulate_bf16=emulate)
@@ -251,7 +253,13 @@ def test_exact_forward_meets_north_star_tolerance(which, monkeypatch):
         check_summary(k, named[k[len(prefix):]].grad, gold_all[which]["grads"][k], 1e-3, what=which + " exact ")
 
 
-def _build_clip(with_text, seed):
+def _build_clip(*a, **k):
+    from helpers import skip_param_init
+    with skip_param_init():   # every tensor is loaded from oracle.synth right after construction
+        return _build_clip_inner(*a, **k)
+
+
+def _build_clip_inner(with_text, seed):
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
     from bioscanclip.model.image_encoder import LoRA_ViT_timm

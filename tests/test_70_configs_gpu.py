@@ -27,7 +27,13 @@ def _gpu():
         pytest.skip("needs a GPU")
 
 
-def _towers(with_text):
+def _towers(*a, **k):
+    from helpers import skip_param_init
+    with skip_param_init():   # every tensor is loaded from oracle.synth right after construction
+        return _towers_inner(*a, **k)
+
+
+def _towers_inner(with_text):
     from bioscanclip.model import arch
     from bioscanclip.model.dna_encoder import LoRA_barcode_bert
     from bioscanclip.model.image_encoder import LoRA_ViT_timm
@@ -65,7 +71,11 @@ def _exact_mode(monkeypatch, on=True):
                                              (512, False, True),       # configs[4]: fp8 trunks at their own local batch 512
                                              (256, True, "exact")])    # BSCLIP_PARITY=2 at the bench shape
 def test_large_batch_equals_small_batch_on_shared_rows(B, with_text, fp8, monkeypatch):
+    import gc
     n = 8
+    gc.collect()                       # engines of the previous case (up to 150 GB of activations at B = 1 024) are cyclic garbage
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
     if fp8 == "exact":   # the exact mode is pinned to the oracle at fixture size (test_20); this carries it to the full size
         _exact_mode(monkeypatch)
         fp8 = False
