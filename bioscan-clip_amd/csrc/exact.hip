@@ -13,6 +13,7 @@
 // The backward pass is the default one: it runs on the bf16 copies of what this forward produced.
 // Reference semantics: timm Attention / Mlp (image_encoder.py:108-109), HF BertSelfAttention / BertIntermediate (dna_encoder.py:105).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -178,6 +179,248 @@ __global__ __launch_bounds__(AF_THREADS) void attn_fwd_f32_kernel(const float* _
         for (int c = 0; c < 16; ++c)
             *reinterpret_cast<f32x4*>(out + 4 * c) = f32x4{o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv};
         lse[((size_t)b * heads + hd) * S + q] = m + __logf(l);
+    }
+}
+
+// ---- f32 attention on the matrix pipe: v_mfma_f32_32x32x2_f32 (f32 operands, exact f32 FMA chains; 64 cycles per SIMD) -------------
+// One workgroup per (batch, head), four waves; K and V of the head in LDS as f32 (row pitch 65 floats: a column read by 32 lanes, one
+// key each, hits 32 banks).  A wave owns query blocks of 32 and works on TRANSPOSED tiles so that the query sits on the lane:
+//   S^T[key, q] = K_j (A operand: lane = key row) x Q_i^T (B operand: lane = query column, the lane's half of the head dims in 32
+//   registers).  In the 32x32 accumulator lane (q, h) then holds the 16 keys 8g + 4h + c (register 4g + c): the softmax statistics
+//   of a query are two lanes (h = 0 / 1) wide -- one cross-lane exchange per tile -- and the same 16 registers ARE the B operand
+//   of the second product, O^T[d, q] += V_j^T (A: lane = head dim, row = the key the B lane holds at this step) x P^T: no transposes.
+typedef float mf32x16 __attribute__((ext_vector_type(16)));
+constexpr int MF_KP = 65;   // LDS row pitch in floats
+
+__device__ __forceinline__ mf32x16 mfma_f32(float a, float b, mf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+template <bool DROP>
+__global__ __launch_bounds__(AF_THREADS) void attn_fwd_mf32_kernel(const float* __restrict__ qkv, int ld, int S, int heads,
+                                                                   const float* __restrict__ key_bias, float scale,
+                                                                   float* __restrict__ ctx, int ld_ctx, float* __restrict__ lse,
+                                                                   DropCfg drop) {
+    BSCLIP_DROP_RESOLVE(drop);
+    __shared__ float sK[AF_SMAX * MF_KP];
+    __shared__ float sV[AF_SMAX * MF_KP];
+    __shared__ float sBias[AF_SMAX];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
+    const int HW = heads * 64;
+    const float* qb = qkv + (size_t)b * S * ld + hd * 64;
+    const int NB = (S + 31) / 32, SP = NB * 32;
+    for (int i = tid; i < SP * 64; i += AF_THREADS) {
+        const int r = i >> 6, c = i & 63;
+        sK[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + HW + c] : 0.f;
+        sV[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + 2 * HW + c] : 0.f;
+    }
+    for (int k = tid; k < SP; k += AF_THREADS) sBias[k] = k < S ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
+    __syncthreads();
+    const unsigned dhead = (unsigned)(b * heads + hd) * S;
+    for (int qi = wave; qi < NB; qi += 4) {
+        const int q = qi * 32 + ln, qc = min(q, S - 1);
+        float qreg[32];   // Q[q][2 s + hf]: the B operand of step s
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) qreg[s2] = qb[(size_t)qc * ld + 2 * s2 + hf];
+        mf32x16 o0 = {0}, o1 = {0};
+        float m = -INFINITY, lsum = 0.f;
+        const unsigned dbase = (dhead + (unsigned)qc) * SP;
+        for (int kj = 0; kj < NB; ++kj) {
+            mf32x16 acc = {0};
+            const float* kp = sK + (kj * 32 + ln) * MF_KP + hf;
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) acc = mfma_f32(kp[2 * s2], qreg[s2], acc);
+            float sv[16], mb = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kj * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                sv[r] = fmaf(acc[r], scale, sBias[key]);
+                mb = fmaxf(mb, sv[r]);
+            }
+            mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+            const float mn = fmaxf(m, mb);
+            const float corr = __expf(m - mn);      // exp(-inf) = 0 on the first tile
+            m = mn;
+            lsum *= corr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= corr;
+                o1[r] *= corr;
+            }
+            float pk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(sv[r] - m);
+                lsum += p;                            // the softmax sum is taken before dropout (HF: dropout(softmax(.)))
+                pk[r] = p;
+                if constexpr (DROP) pk[r] = p * drop_factor(drop, dbase + (unsigned)(kj * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)));
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {            // contraction index (t, hf) = key 8 (t / 4) + 4 hf + t % 4: the key pk[t] belongs to
+                const float* vp = sV + (kj * 32 + 8 * (t >> 2) + 4 * hf + (t & 3)) * MF_KP + ln;
+                o0 = mfma_f32(vp[0], pk[t], o0);
+                o1 = mfma_f32(vp[32], pk[t], o1);
+            }
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        if (q < S) {
+            const float inv = 1.0f / lsum;
+            float* out = ctx + (size_t)(b * S + q) * ld_ctx + hd * 64;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {             // O^T[d = 8 g + 4 hf + c (+ 32)][q]
+                *reinterpret_cast<f32x4*>(out + 8 * g + 4 * hf) = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(out + 32 + 8 * g + 4 * hf) =
+                    f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+            }
+            if (hf == 0) lse[((size_t)b * heads + hd) * S + q] = m + __logf(lsum);
+        }
+    }
+}
+
+// f32 attention backward on the matrix pipe (see attn_fwd_mf32_kernel for the transposed-tile scheme), two phases over one LDS image:
+//   Q phase  K, V resident; a wave owns query blocks, the query on the lane:  S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (f dP^T - delta),
+//            dQ^T += K^T dS^T  (the dS^T registers are the B operand).  delta = dO . O per query, kept for the second phase.
+//   K phase  Q, dO resident; a wave owns key blocks, the key on the lane:     S = Q K^T, dP = dO V^T, dV^T += dO^T (P f), dK^T += Q^T dS.
+// 96 + 128 MFMAs of 32x32x2 per pair of 32-blocks (the scores are formed once per phase: the two phases need them in transposed
+// register layouts, and a 32x32 f32 transpose through LDS costs more than 32 MFMAs here).
+template <bool DROP>
+__global__ __launch_bounds__(AF_THREADS) void attn_bwd_mf32_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dctx,
+                                                                   int ld_d, const float* __restrict__ ctx, int ld_c,
+                                                                   const float* __restrict__ lse, int S, int heads,
+                                                                   const float* __restrict__ key_bias, float scale,
+                                                                   float* __restrict__ dqkv, int ld_g, DropCfg drop) {
+    BSCLIP_DROP_RESOLVE(drop);
+    __shared__ float sA[AF_SMAX * MF_KP];   // K, then Q
+    __shared__ float sB[AF_SMAX * MF_KP];   // V, then dO
+    __shared__ float sBias[AF_SMAX], sLse[AF_SMAX], sDelta[AF_SMAX];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
+    const int HW = heads * 64;
+    const float* qb = qkv + (size_t)b * S * ld + hd * 64;
+    const float* db = dctx + (size_t)b * S * ld_d + hd * 64;
+    const float* cb = ctx + (size_t)b * S * ld_c + hd * 64;
+    float* gb = dqkv + (size_t)b * S * ld_g + hd * 64;
+    const int NB = (S + 31) / 32, SP = NB * 32;
+    const unsigned dhead = (unsigned)(b * heads + hd) * S;
+    for (int i = tid; i < SP * 64; i += AF_THREADS) {
+        const int r = i >> 6, c = i & 63;
+        sA[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + HW + c] : 0.f;
+        sB[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + 2 * HW + c] : 0.f;
+    }
+    for (int k = tid; k < SP; k += AF_THREADS) {
+        sBias[k] = k < S ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
+        sLse[k] = k < S ? lse[((size_t)b * heads + hd) * S + k] : INFINITY;    // a padded query row: p = exp(. - inf) = 0
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- Q phase
+    for (int qi = wave; qi < NB; qi += 4) {
+        const int q = qi * 32 + ln, qc = min(q, S - 1);
+        float qreg[32], doreg[32], dpart = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) {
+            qreg[s2] = qb[(size_t)qc * ld + 2 * s2 + hf];
+            doreg[s2] = db[(size_t)qc * ld_d + 2 * s2 + hf];
+            dpart = fmaf(doreg[s2], cb[(size_t)qc * ld_c + 2 * s2 + hf], dpart);
+        }
+        const float delta = dpart + __shfl_xor(dpart, 32, 64);
+        const float lq = sLse[q];
+        if (hf == 0) sDelta[q] = q < S ? delta : 0.f;
+        mf32x16 g0 = {0}, g1 = {0};
+        const unsigned dbase = (dhead + (unsigned)qc) * SP;
+        for (int kj = 0; kj < NB; ++kj) {
+            mf32x16 acc = {0}, acp = {0};
+            const float* kp = sA + (kj * 32 + ln) * MF_KP + hf;
+            const float* vp = sB + (kj * 32 + ln) * MF_KP + hf;
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) {
+                acc = mfma_f32(kp[2 * s2], qreg[s2], acc);
+                acp = mfma_f32(vp[2 * s2], doreg[s2], acp);
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kj * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                const float p = __expf(fmaf(acc[r], scale, sBias[key]) - lq);
+                float dp = acp[r];
+                if constexpr (DROP) dp *= drop_factor(drop, dbase + (unsigned)key);
+                ds[r] = p * (dp - delta);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float* kt = sA + (kj * 32 + 8 * (t >> 2) + 4 * hf + (t & 3)) * MF_KP + ln;
+                g0 = mfma_f32(kt[0], ds[t], g0);
+                g1 = mfma_f32(kt[32], ds[t], g1);
+            }
+        }
+        if (q < S) {
+            float* out = gb + (size_t)q * ld_g;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x4*>(out + 8 * g + 4 * hf) =
+                    f32x4{g0[4 * g] * scale, g0[4 * g + 1] * scale, g0[4 * g + 2] * scale, g0[4 * g + 3] * scale};
+                *reinterpret_cast<f32x4*>(out + 32 + 8 * g + 4 * hf) =
+                    f32x4{g1[4 * g] * scale, g1[4 * g + 1] * scale, g1[4 * g + 2] * scale, g1[4 * g + 3] * scale};
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < SP * 64; i += AF_THREADS) {
+        const int r = i >> 6, c = i & 63;
+        sA[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + c] : 0.f;
+        sB[r * MF_KP + c] = r < S ? db[(size_t)r * ld_d + c] : 0.f;
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- K phase
+    for (int kj = wave; kj < NB; kj += 4) {
+        const int k = kj * 32 + ln, kc = min(k, S - 1);
+        float kreg[32], vreg[32];
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) {
+            kreg[s2] = qb[(size_t)kc * ld + HW + 2 * s2 + hf];
+            vreg[s2] = qb[(size_t)kc * ld + 2 * HW + 2 * s2 + hf];
+        }
+        const float bias = sBias[k];
+        mf32x16 k0 = {0}, k1 = {0}, v0 = {0}, v1 = {0};
+        for (int qi = 0; qi < NB; ++qi) {
+            mf32x16 acc = {0}, acp = {0};
+            const float* qp = sA + (qi * 32 + ln) * MF_KP + hf;
+            const float* dp_ = sB + (qi * 32 + ln) * MF_KP + hf;
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) {
+                acc = mfma_f32(qp[2 * s2], kreg[s2], acc);
+                acp = mfma_f32(dp_[2 * s2], vreg[s2], acp);
+            }
+            float ds[16], pf[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = qi * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                const float p = __expf(fmaf(acc[r], scale, bias) - sLse[qq]);
+                float f = 1.0f;
+                if constexpr (DROP) f = drop_factor(drop, (dhead + (unsigned)min(qq, S - 1)) * SP + (unsigned)kc);
+                pf[r] = p * f;
+                ds[r] = p * (f * acp[r] - sDelta[qq]);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int row = (qi * 32 + 8 * (t >> 2) + 4 * hf + (t & 3)) * MF_KP + ln;
+                v0 = mfma_f32(sB[row], pf[t], v0);
+                v1 = mfma_f32(sB[row + 32], pf[t], v1);
+                k0 = mfma_f32(sA[row], ds[t], k0);
+                k1 = mfma_f32(sA[row + 32], ds[t], k1);
+            }
+        }
+        if (k < S) {
+            float* ok = gb + (size_t)k * ld_g + HW;
+            float* ov = gb + (size_t)k * ld_g + 2 * HW;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x4*>(ok + 8 * g + 4 * hf) =
+                    f32x4{k0[4 * g] * scale, k0[4 * g + 1] * scale, k0[4 * g + 2] * scale, k0[4 * g + 3] * scale};
+                *reinterpret_cast<f32x4*>(ok + 32 + 8 * g + 4 * hf) =
+                    f32x4{k1[4 * g] * scale, k1[4 * g + 1] * scale, k1[4 * g + 2] * scale, k1[4 * g + 3] * scale};
+                *reinterpret_cast<f32x4*>(ov + 8 * g + 4 * hf) = f32x4{v0[4 * g], v0[4 * g + 1], v0[4 * g + 2], v0[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(ov + 32 + 8 * g + 4 * hf) = f32x4{v1[4 * g], v1[4 * g + 1], v1[4 * g + 2], v1[4 * g + 3]};
+            }
+        }
     }
 }
 
@@ -584,6 +827,17 @@ extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, i
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_fwd_f32: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool valu = getenv("BSCLIP_EXACT_ATTN_VALU") != nullptr && getenv("BSCLIP_EXACT_ATTN_VALU")[0] == '1';
+    if (!valu) {   // the matrix-pipe form (f32 MFMA); BSCLIP_EXACT_ATTN_VALU=1 selects the one-row-per-thread vector-ALU kernel
+        if (drop.thr16)
+            hipLaunchKernelGGL((attn_fwd_mf32_kernel<true>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale,
+                               ctx, ld_ctx, lse, drop);
+        else
+            hipLaunchKernelGGL((attn_fwd_mf32_kernel<false>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale,
+                               ctx, ld_ctx, lse, drop);
+        BSCLIP_LAUNCH_CHECK();
+        return BSCLIP_OK;
+    }
     if (drop.thr16)
         hipLaunchKernelGGL((attn_fwd_f32_kernel<true>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale, ctx,
                            ld_ctx, lse, drop);
@@ -662,6 +916,17 @@ extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dc
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_bwd_f32: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool valu = getenv("BSCLIP_EXACT_ATTN_VALU") != nullptr && getenv("BSCLIP_EXACT_ATTN_VALU")[0] == '1';
+    if (!valu) {
+        if (drop.thr16)
+            hipLaunchKernelGGL((attn_bwd_mf32_kernel<true>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx,
+                               lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop);
+        else
+            hipLaunchKernelGGL((attn_bwd_mf32_kernel<false>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx,
+                               lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop);
+        BSCLIP_LAUNCH_CHECK();
+        return BSCLIP_OK;
+    }
     if (drop.thr16)
         hipLaunchKernelGGL((attn_bwd_f32_kernel<true>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx, lse,
                            S, heads, key_bias, scale, dqkv, ld_dqkv, drop);
