@@ -776,7 +776,9 @@ def test_exact_attention_fwd_bwd_f32(ops, B, S, heads, masked):
     dqkv = torch.full((B * S, 3 * H), float("nan"), device="cuda")
     ops.attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, scale, dqkv, key_bias=bias)
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
-        e = ((dqkv[:, sl] - gq[:, sl]).norm() / (gq[:, sl].norm() + 1e-5 * gq.norm())).item()   # S = 1: dq = dk = 0 in the reference
+        # S = 1: dq = dk = 0 in the reference (one key: dS = P (dP - delta) = 0); here dP and delta are two f32 summation orders of
+        # the same dot product, so dS is rounding noise (1e-7 of the gradient's scale): measured against the whole gradient then
+        e = ((dqkv[:, sl] - gq[:, sl]).norm() / torch.maximum(gq[:, sl].norm(), 1e-2 * gq.norm())).item()
         assert e < 3e-5, (name, e)
 
 
