@@ -589,7 +589,7 @@ def main():
                 out["exact_mode_ms_per_step"] = xm["ms_per_step"]
                 out["exact_mode"] = ("BSCLIP_PARITY=2: the step that meets north_star's 1e-3 against the f32 reference on embeddings, loss and every "
                                      "gradient (forward AND backward GEMMs on split-bf16 operands = 3 x the K, LoRA folded in f32, exact-erf GELU, "
-                                     "f32 attention forward / backward and f32 LoRA gradients on the vector ALU; golden 10-step trajectory within "
+                                     "f32-operand MFMA attention forward / backward, f32 LoRA gradients; golden 10-step trajectory within "
                                      "1e-3, tests/test_20_encoders_gpu.py); same workload as the headline: what bf16 operands buy is the "
                                      "headline's ms_per_step against this")
                 out["parity_mode"] = ("BSCLIP_PARITY=1: f32 residual and residual-gradient streams + split-bf16 patch embedding, same workload "

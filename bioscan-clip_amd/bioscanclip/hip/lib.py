@@ -69,6 +69,7 @@ SIGNATURES = {
     "bsclip_lora_grad_f32_workspace_floats": (L, [I]),
     "bsclip_lora_grad_f32": (I, [P, I, P, I, I, I, P, P, P, P, P, P]),
     "bsclip_attn_bwd_f32": (I, [P, I, P, I, P, I, P, I, I, I, P, F, P, I, F, U, P]),
+    "bsclip_exact_attn_set_impl": (I, [I]),
     "bsclip_im2col_patch16": (I, [P, I, P, I, I, P]),
     "bsclip_mask_to_bias": (I, [P, I, P, P]),
     "bsclip_vit_cls_rows": (I, [P, I, P, P, I, I, I, P]),

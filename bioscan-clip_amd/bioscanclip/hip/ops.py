@@ -423,6 +423,11 @@ def lora_grad_f32(dqkv, y, M, H, lora_a, lora_b, dA, dB):
                                          _p(dA), _p(dB), _p(ws), _stream()))
 
 
+def exact_attn_set_impl(impl):
+    """0 = f32 attention on the matrix pipe (default), 1 = the vector-ALU kernels (second implementation, for tests)."""
+    check(_l.load().bsclip_exact_attn_set_impl(int(impl)))
+
+
 def attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None):
     _req(all(t.dtype == F32 for t in (qkv, dctx, ctx, lse, dqkv)), "attn_bwd_f32 dtypes")
     _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64 and dqkv.shape[0] >= B * S and dqkv.shape[1] >= 3 * heads * 64

@@ -8,12 +8,13 @@
 //   bsclip_split3_rows    f32 activation [M, K]            -> bf16 [M, 3K] = [hi | lo | hi]
 //   bsclip_split3_weight  f32 weight [N, K] (+ LoRA B.A)   -> bf16 [N, 3K] = [hi | hi | lo]   (LoRA folded in f32: W + B A)
 //   bsclip_gelu_split3    f32 pre-activation [M, N]        -> exact-erf GELU as [hi | lo | hi] + the 8-bit gelu' side band
-//   bsclip_attn_fwd_f32   softmax(q k^T scale + bias) v in f32 on the vector ALU (attention is 4 % of the step's FLOPs; the mode
-//                         is a parity mode, its speed is reported, not defended), same dropout masks as the bf16 kernels
-// The backward pass is the default one: it runs on the bf16 copies of what this forward produced.
+//   bsclip_attn_fwd_f32 / bsclip_attn_bwd_f32   softmax(q k^T scale + bias) v and its backward in f32, on the matrix pipe's f32
+//                         form (v_mfma_f32_32x32x2_f32: exact f32 FMA chains at the vector-ALU peak rate without the LDS-broadcast
+//                         bottleneck of a one-row-per-thread kernel, which is kept as a second implementation:
+//                         bsclip_exact_attn_set_impl(1)); same dropout masks as the bf16 kernels
+//   ... and the exact backward: bsclip_dgelu_split3, bsclip_split3_transpose, bsclip_lora_grad_f32, bsclip_softmax_meanpool_bwd_f32.
 // Reference semantics: timm Attention / Mlp (image_encoder.py:108-109), HF BertSelfAttention / BertIntermediate (dna_encoder.py:105).
 #include <math.h>
-#include <stdlib.h>
 
 #include "common.h"
 
@@ -191,11 +192,12 @@ __global__ __launch_bounds__(AF_THREADS) void attn_fwd_f32_kernel(const float* _
 //   of the second product, O^T[d, q] += V_j^T (A: lane = head dim, row = the key the B lane holds at this step) x P^T: no transposes.
 typedef float mf32x16 __attribute__((ext_vector_type(16)));
 constexpr int MF_KP = 65;   // LDS row pitch in floats
+constexpr int MF_THREADS = 512, MF_WAVES = MF_THREADS / 64;   // two waves per SIMD: one's softmax under the other's MFMAs; 7 (5) blocks over 8 waves
 
 __device__ __forceinline__ mf32x16 mfma_f32(float a, float b, mf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 template <bool DROP>
-__global__ __launch_bounds__(AF_THREADS) void attn_fwd_mf32_kernel(const float* __restrict__ qkv, int ld, int S, int heads,
+__global__ __launch_bounds__(MF_THREADS) void attn_fwd_mf32_kernel(const float* __restrict__ qkv, int ld, int S, int heads,
                                                                    const float* __restrict__ key_bias, float scale,
                                                                    float* __restrict__ ctx, int ld_ctx, float* __restrict__ lse,
                                                                    DropCfg drop) {
@@ -208,15 +210,15 @@ __global__ __launch_bounds__(AF_THREADS) void attn_fwd_mf32_kernel(const float* 
     const int HW = heads * 64;
     const float* qb = qkv + (size_t)b * S * ld + hd * 64;
     const int NB = (S + 31) / 32, SP = NB * 32;
-    for (int i = tid; i < SP * 64; i += AF_THREADS) {
+    for (int i = tid; i < SP * 64; i += MF_THREADS) {
         const int r = i >> 6, c = i & 63;
         sK[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + HW + c] : 0.f;
         sV[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + 2 * HW + c] : 0.f;
     }
-    for (int k = tid; k < SP; k += AF_THREADS) sBias[k] = k < S ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
+    for (int k = tid; k < SP; k += MF_THREADS) sBias[k] = k < S ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
     __syncthreads();
     const unsigned dhead = (unsigned)(b * heads + hd) * S;
-    for (int qi = wave; qi < NB; qi += 4) {
+    for (int qi = wave; qi < NB; qi += MF_WAVES) {
         const int q = qi * 32 + ln, qc = min(q, S - 1);
         float qreg[32];   // Q[q][2 s + hf]: the B operand of step s
 #pragma unroll
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(AF_THREADS) void attn_fwd_mf32_kernel(const float* 
 // 96 + 128 MFMAs of 32x32x2 per pair of 32-blocks (the scores are formed once per phase: the two phases need them in transposed
 // register layouts, and a 32x32 f32 transpose through LDS costs more than 32 MFMAs here).
 template <bool DROP>
-__global__ __launch_bounds__(AF_THREADS) void attn_bwd_mf32_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dctx,
+__global__ __launch_bounds__(MF_THREADS) void attn_bwd_mf32_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dctx,
                                                                    int ld_d, const float* __restrict__ ctx, int ld_c,
                                                                    const float* __restrict__ lse, int S, int heads,
                                                                    const float* __restrict__ key_bias, float scale,
@@ -301,18 +303,18 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_mf32_kernel(const float* 
     float* gb = dqkv + (size_t)b * S * ld_g + hd * 64;
     const int NB = (S + 31) / 32, SP = NB * 32;
     const unsigned dhead = (unsigned)(b * heads + hd) * S;
-    for (int i = tid; i < SP * 64; i += AF_THREADS) {
+    for (int i = tid; i < SP * 64; i += MF_THREADS) {
         const int r = i >> 6, c = i & 63;
         sA[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + HW + c] : 0.f;
         sB[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + 2 * HW + c] : 0.f;
     }
-    for (int k = tid; k < SP; k += AF_THREADS) {
+    for (int k = tid; k < SP; k += MF_THREADS) {
         sBias[k] = k < S ? (key_bias ? key_bias[(size_t)b * S + k] : 0.f) : -INFINITY;
         sLse[k] = k < S ? lse[((size_t)b * heads + hd) * S + k] : INFINITY;    // a padded query row: p = exp(. - inf) = 0
     }
     __syncthreads();
     // ---------------------------------------------------------------- Q phase
-    for (int qi = wave; qi < NB; qi += 4) {
+    for (int qi = wave; qi < NB; qi += MF_WAVES) {
         const int q = qi * 32 + ln, qc = min(q, S - 1);
         float qreg[32], doreg[32], dpart = 0.f;
 #pragma unroll
@@ -363,14 +365,14 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_mf32_kernel(const float* 
         }
     }
     __syncthreads();
-    for (int i = tid; i < SP * 64; i += AF_THREADS) {
+    for (int i = tid; i < SP * 64; i += MF_THREADS) {
         const int r = i >> 6, c = i & 63;
         sA[r * MF_KP + c] = r < S ? qb[(size_t)r * ld + c] : 0.f;
         sB[r * MF_KP + c] = r < S ? db[(size_t)r * ld_d + c] : 0.f;
     }
     __syncthreads();
     // ---------------------------------------------------------------- K phase
-    for (int kj = wave; kj < NB; kj += 4) {
+    for (int kj = wave; kj < NB; kj += MF_WAVES) {
         const int k = kj * 32 + ln, kc = min(k, S - 1);
         float kreg[32], vreg[32];
 #pragma unroll
@@ -773,6 +775,13 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_f32_kernel(const float* _
 
 }  // namespace
 
+static int g_exact_attn_impl = 0;
+extern "C" int bsclip_exact_attn_set_impl(int impl) {
+    BSCLIP_REQUIRE(impl == 0 || impl == 1, "bsclip_exact_attn_set_impl: %d (0 = f32 MFMA, 1 = vector ALU)", impl);
+    g_exact_attn_impl = impl;
+    return BSCLIP_OK;
+}
+
 extern "C" int bsclip_split3_rows(const float* src, int ld_src, int M, int K, void* dst, int ld_dst, void* stream) {
     BSCLIP_REQUIRE(src && dst, "bsclip_split3_rows: null pointer");
     BSCLIP_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && ld_src >= K && ld_src % 4 == 0 && ld_dst >= 3 * K && ld_dst % 4 == 0,
@@ -827,13 +836,12 @@ extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, i
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_fwd_f32: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool valu = getenv("BSCLIP_EXACT_ATTN_VALU") != nullptr && getenv("BSCLIP_EXACT_ATTN_VALU")[0] == '1';
-    if (!valu) {   // the matrix-pipe form (f32 MFMA); BSCLIP_EXACT_ATTN_VALU=1 selects the one-row-per-thread vector-ALU kernel
+    if (g_exact_attn_impl == 0) {   // the matrix-pipe form (f32 MFMA); impl 1 = the one-row-per-thread vector-ALU kernel
         if (drop.thr16)
-            hipLaunchKernelGGL((attn_fwd_mf32_kernel<true>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale,
+            hipLaunchKernelGGL((attn_fwd_mf32_kernel<true>), dim3(B * heads), dim3(MF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale,
                                ctx, ld_ctx, lse, drop);
         else
-            hipLaunchKernelGGL((attn_fwd_mf32_kernel<false>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale,
+            hipLaunchKernelGGL((attn_fwd_mf32_kernel<false>), dim3(B * heads), dim3(MF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale,
                                ctx, ld_ctx, lse, drop);
         BSCLIP_LAUNCH_CHECK();
         return BSCLIP_OK;
@@ -916,13 +924,12 @@ extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dc
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_bwd_f32: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool valu = getenv("BSCLIP_EXACT_ATTN_VALU") != nullptr && getenv("BSCLIP_EXACT_ATTN_VALU")[0] == '1';
-    if (!valu) {
+    if (g_exact_attn_impl == 0) {
         if (drop.thr16)
-            hipLaunchKernelGGL((attn_bwd_mf32_kernel<true>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx,
+            hipLaunchKernelGGL((attn_bwd_mf32_kernel<true>), dim3(B * heads), dim3(MF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx,
                                lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop);
         else
-            hipLaunchKernelGGL((attn_bwd_mf32_kernel<false>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx,
+            hipLaunchKernelGGL((attn_bwd_mf32_kernel<false>), dim3(B * heads), dim3(MF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx,
                                lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop);
         BSCLIP_LAUNCH_CHECK();
         return BSCLIP_OK;

@@ -234,7 +234,7 @@ int bsclip_attn_bwd2(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx,
  *                  gelu' side band the default backward reads
  *   meanpool_tokens_f32: x f32 [B*S, H] -> out f32 [B, H], the mean over each sequence's S tokens (language_encoder.py:89)
  *   attn_fwd_f32:  qkv f32 [B*S, ld_qkv] ([q | k | v], heads*64 each) -> ctx f32 [B*S, ld_ctx], lse f32 [B, heads, S]; f32 arithmetic
- *                  on the vector ALU, the bf16 kernels' dropout masks; argument meaning as bsclip_attn_fwd.
+ *                  (f32-operand MFMA, S <= 224), the bf16 kernels' dropout masks; argument meaning as bsclip_attn_fwd.
  * The exact backward (BSCLIP_PARITY=2) keeps every gradient in f32 and runs its dX / dW GEMMs on split operands as well:
  *   dgelu_split3:  dact f32 [M, N], z f32 [M, N] (fc1 pre-activation) -> dact * gelu'(z) as bf16 [M, 3N] = [hi | lo | hi] (dst nullable)
  *                  and / or f32 [M, ld_out32] (out32 nullable)
@@ -246,8 +246,8 @@ int bsclip_attn_bwd2(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx,
  *   lora_grad_f32: dA [8, H] += (B^T dq | B^T dv) y^T, dB [2, H, 4] += (dq | dv)^T (A y) from dqkv f32 [M, ld_dqkv] ([dq | dk | dv]) and
  *                  the LayerNorm output y f32 [M, ld_y] (reference lora_layer.py:16-39); workspace:
  *                  bsclip_lora_grad_f32_workspace_floats(H) floats; sums in a fixed order
- *   attn_bwd_f32:  dqkv f32 [B*S, ld_dqkv] from qkv f32, dctx f32, the forward's ctx f32 (delta = dctx . ctx) and lse; f32 arithmetic on
- *                  the vector ALU, the forward's dropout masks; argument meaning as bsclip_attn_bwd.
+ *   attn_bwd_f32:  dqkv f32 [B*S, ld_dqkv] from qkv f32, dctx f32, the forward's ctx f32 (delta = dctx . ctx) and lse; f32-operand
+ *                  MFMA, the forward's dropout masks; argument meaning as bsclip_attn_bwd.
  * bsclip_layernorm_bwd takes the f32 GEMM gradient / writes the f32 operand through resid_flags bits 2 / 3. */
 int bsclip_split3_rows(const float* src, int ld_src, int M, int K, void* dst, int ld_dst, void* stream);
 int bsclip_split3_weight(const float* w, int ld_w, int N, int K, const float* lora_a, const float* lora_b, int H, void* dst, int ld_dst,
@@ -266,6 +266,9 @@ int bsclip_softmax_meanpool_bwd_f32(const float* logits, const float* stats, con
 int64_t bsclip_lora_grad_f32_workspace_floats(int H);
 int bsclip_lora_grad_f32(const float* dqkv, int ld_dqkv, const float* y, int ld_y, int M, int H, const float* lora_a, const float* lora_b,
                          float* dA, float* dB, float* workspace, void* stream);
+/* 0 (default) = f32 attention on the matrix pipe (v_mfma_f32_32x32x2_f32), 1 = the one-row-per-thread vector-ALU kernels (a second
+ * implementation of the same arithmetic, kept to test against; 2 - 4 x slower) */
+int bsclip_exact_attn_set_impl(int impl);
 int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx, const float* lse, int B,
                         int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv, float dropout_p,
                         uint32_t dropout_seed, void* stream);

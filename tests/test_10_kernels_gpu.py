@@ -885,3 +885,33 @@ def test_exact_layernorm_bwd_f32_operands(ops):
         assert torch.equal(d_new, d_ref) and torch.equal(op_new.bfloat16(), op_ref)
         kept = op_new != 0
         assert torch.allclose(op_new[kept], d_new[kept] / 0.9, rtol=1e-6) and 0.85 < kept.float().mean().item() < 0.95
+
+
+@pytest.mark.parametrize("B,S,heads,masked,drop", [(3, 197, 12, False, None), (2, 133, 12, False, (0.1, 99)), (5, 20, 8, True, (0.1, 7)),
+                                                   (2, 224, 2, True, None), (3, 1, 2, False, None)])
+def test_exact_attention_two_implementations_agree(ops, B, S, heads, masked, drop):
+    """The f32 attention exists twice -- on the matrix pipe's f32 form (v_mfma_f32_32x32x2_f32, transposed tiles, the default) and as
+    one-row-per-thread vector-ALU kernels -- with the same dropout masks: outputs, lse and all three gradients agree to f32
+    rounding (different summation orders), dropout included (a mask mismatch would be an O(0.3) difference)."""
+    H = heads * 64
+    qkv, dctx = dev(rnd(B * S, 3 * H, seed=1)), dev(rnd(B * S, H, seed=2))
+    bias = None
+    if masked:
+        lens = torch.randint(1, S + 1, (B,), generator=torch.Generator().manual_seed(3))
+        bias = dev((1.0 - (torch.arange(S)[None] < lens[:, None]).float()) * torch.finfo(torch.float32).min)
+    out = {}
+    try:
+        for impl in (0, 1):
+            ops.exact_attn_set_impl(impl)
+            ctx, lse = torch.empty(B * S, H, device="cuda"), torch.empty(B, heads, S, device="cuda")
+            dqkv = torch.full((B * S, 3 * H), float("nan"), device="cuda")
+            ops.attn_fwd_f32(qkv, B, S, heads, 0.125, ctx, lse, key_bias=bias, dropout=drop)
+            ops.attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, 0.125, dqkv, key_bias=bias, dropout=drop)
+            out[impl] = (ctx, lse, dqkv)
+    finally:
+        ops.exact_attn_set_impl(0)
+    assert rel_err(out[0][0], out[1][0]) < 2e-6 and rel_err(out[0][1], out[1][1]) < 1e-6
+    g0, g1 = out[0][2], out[1][2]
+    for sl in (slice(0, H), slice(H, 2 * H), slice(2 * H, 3 * H)):
+        # S = 1: dq = dk = 0 analytically, what is left is dS = P (dP - delta) rounding noise against 1e-2 of the gradient's norm
+        assert ((g0[:, sl] - g1[:, sl]).norm() / torch.maximum(g1[:, sl].norm(), 1e-2 * g1.norm())).item() < (3e-5 if S == 1 else 3e-6)
