@@ -565,3 +565,19 @@ def test_detect_anomaly_names_where_non_finite_values_appear(monkeypatch):
         m.lora_vit.blocks[1].attn.qkv.linear_a_q.weight[0, 0] = float("nan")
     with pytest.raises(RuntimeError, match=r"ViTEngine forward: non-finite values first appear in blocks\.1\.attn\.qkv output"):
         m(x)
+    # the BERT engines (post-LN trunk, MLM softmax-mean head), in the default and in the exact mode
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    for exact in (False, True):
+        monkeypatch.setattr(engine, "RESID_STREAM_BF16", not exact)
+        monkeypatch.setattr(engine, "GRAD_STREAM_BF16", not exact)
+        monkeypatch.setattr(engine, "EXACT_FORWARD", exact)
+        d = LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=3, **NODROP)), r=4, num_classes=768)
+        _load(d, "dna_encoder.", 11)
+        d.to("cuda").train()
+        ids = synth.synth_batch(2, seed=21)[1].cuda()
+        y = d(ids)
+        (y * torch.randn_like(y)).sum().backward()      # clean
+        with torch.no_grad():
+            d.lora_barcode_bert.bert.encoder.layer[1].attention.self.value.w_a.weight[0, 0] = float("inf")
+        with pytest.raises(RuntimeError, match=r"BertEngine forward: non-finite values first appear in encoder\.layer\.1\.attention\.self q / k / v"):
+            d(ids)
