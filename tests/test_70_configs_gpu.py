@@ -321,3 +321,34 @@ def test_every_shipped_model_config_trains(cfg, tmp_path, capsys):
                             "debug_flag=true", f"project_root_path={tmp_path}"])
     capsys.readouterr()
     assert len(losses) == 1 and losses[0] == losses[0] and 0.0 < losses[0] < 20.0, losses
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_batches_of_one_and_three_equal_the_rows_of_a_larger_batch(exact, monkeypatch):
+    """The smallest batches (M = 197 / 133 / 20 rows: below every tile size of the GEMM kernels, one workgroup of most others) through
+    all three towers: their embeddings are the first rows of the 8-sample batch, their gradients finite and equal to the gradients
+    the 8-sample batch gives with a cotangent on those rows -- in the default and in the exact mode."""
+    from bioscanclip.model import arch
+    from bioscanclip.model.dna_encoder import LoRA_barcode_bert
+    from bioscanclip.model.image_encoder import LoRA_ViT_timm
+    from bioscanclip.model.language_encoder import LoRA_bert
+    from bioscanclip.model.simple_clip import SimpleCLIP
+    from helpers import skip_param_init
+    if exact:
+        _exact_mode(monkeypatch)
+    with skip_param_init():
+        model = SimpleCLIP(LoRA_ViT_timm(arch.VisionTransformerParams(depth=2), r=4, num_classes=768),
+                           LoRA_barcode_bert(arch.BertForMaskedLMParams(arch.barcode_bert_config(num_hidden_layers=2, **NODROP)), r=4, num_classes=768),
+                           LoRA_bert(arch.BertModelParams(arch.bert_small_config(num_hidden_layers=2, **NODROP)), r=4, num_classes=768))
+    model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=61))
+    model = model.cuda().train()
+    image, dna, text, _ = synth.synth_batch(8, seed=71, with_text=True)
+    image, dna, text = image.cuda(), dna.cuda(), {k: v.cuda() for k, v in text.items()}
+    for n in (1, 3):
+        cot = [synth.synth_tensor(f"cfg.small.cot.{i}", (n, 768), seed=5).cuda() for i in range(3)]
+        y_big, g_big = _run(model, image, dna, text, cot, n)
+        y_small, g_small = _run(model, image[:n], dna[:n], {k: v[:n] for k, v in text.items()}, cot, n)
+        for a, b in zip(y_small, y_big):
+            assert torch.isfinite(a).all() and rel_err(a, b) < 2e-6, (n, rel_err(a, b))
+        worst = max(rel_err(g_small[k], g_big[k]) for k in g_big)
+        assert all(torch.isfinite(g).all() for g in g_small.values()) and worst < 2e-4, (n, worst)
