@@ -250,11 +250,21 @@ class EncoderEngineBase:
         return self.flat.view(self._extra_index + k, self.flat.params[self._extra_index + k].shape, grad=grad)
 
     def refresh_lora_weights(self):
-        for l, lay in enumerate(self.layers):
-            b = self.lora_b(l)
-            if b is not None:
-                ops.waug_set_lora(lay.waug, self.H, b[0], b[1])
-                if self.fp8:  # LoRA-B columns of the bf16 K-augmentation tile, in the fp8 accumulator's units
+        """LoRA-B into the K-augmentation columns of every layer's QKV weight: one launch over a table of device addresses (the
+        weights and the flat parameter buffer live as long as the engine)."""
+        if getattr(self, "_waug_table", None) is None:
+            rows = [(lay.waug.data_ptr(), self.lora_b(l)[0].data_ptr(), self.lora_b(l)[1].data_ptr())
+                    for l, lay in enumerate(self.layers) if self.lora_b(l) is not None]
+            lds = {_lay.waug.stride(0) for _lay in self.layers}
+            assert len(lds) == 1
+            self._waug_table = (torch.tensor(rows, dtype=torch.int64, device=self.device).reshape(-1, 3).contiguous(), len(rows), lds.pop())
+        table, n, ld_w = self._waug_table
+        if n:
+            ops.waug_set_lora_layers(table, n, ld_w, self.H)
+        if self.fp8:  # LoRA-B columns of the bf16 K-augmentation tile, in the fp8 accumulator's units
+            for l, lay in enumerate(self.layers):
+                b = self.lora_b(l)
+                if b is not None:
                     ops.lora_baug_set(lay.baug, self.H, b[0], b[1], lay.s_qkv)
 
     fp8 = False

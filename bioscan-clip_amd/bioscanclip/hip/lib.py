@@ -102,6 +102,7 @@ SIGNATURES = {
     "bsclip_transpose_bf16": (I, [P, I, I, I, P, I, P]),
     "bsclip_cast_f32_bf16": (I, [P, L, P, P]),
     "bsclip_waug_set_lora": (I, [P, I, I, P, P, P]),
+    "bsclip_waug_set_lora_layers": (I, [P, I, I, I, P]),
     "bsclip_ln_param_grad_workspace_floats": (L, [I]),
     "bsclip_ln_param_grad": (I, [P, I, I, P, I, I, P, I, P, I, P, P, I, F, U, P, P, P, P]),
     "bsclip_embed_grad_workspace_floats": (L, [I]),

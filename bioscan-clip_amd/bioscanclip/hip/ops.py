@@ -649,6 +649,12 @@ def cast_f32_bf16(src, dst):
     check(_l.load().bsclip_cast_f32_bf16(_p(src), src.numel(), _p(dst), _stream()))
 
 
+def waug_set_lora_layers(table, layers, ld_w, H):
+    """One launch for all LoRA layers of an encoder: ``table`` int64 [layers, 3] of device addresses (W_aug, B_q, B_v)."""
+    _req(table.dtype == torch.int64 and table.is_contiguous() and table.is_cuda and table.numel() >= 3 * layers, "waug_set_lora_layers: table")
+    check(_l.load().bsclip_waug_set_lora_layers(_p(table), int(layers), int(ld_w), int(H), _stream()))
+
+
 def waug_set_lora(w_aug, H, bq, bv):
     _req(w_aug.dtype == BF16 and w_aug.shape[0] >= 3 * H and w_aug.shape[1] >= H + KPAD, "w_aug bf16 [3H, H+KPAD]")
     _req(all(t.dtype == F32 and t.is_contiguous() and tuple(t.shape) == (H, 4) for t in (bq, bv)), "bq/bv f32 [H,4]")

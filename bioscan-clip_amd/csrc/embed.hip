@@ -187,6 +187,21 @@ __global__ void waug_set_lora_kernel(bf16_t* __restrict__ w, int ld_w, int H, co
     *reinterpret_cast<uint2*>(dst) = o;
 }
 
+// the same for every LoRA layer of an encoder in one launch (blockIdx.y = layer): table[l] = {W_aug, B_q, B_v} device addresses
+__global__ void waug_set_lora_layers_kernel(const int64_t* __restrict__ table, int ld_w, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * H) return;
+    const int64_t* t = table + 3 * (size_t)blockIdx.y;
+    bf16_t* w = reinterpret_cast<bf16_t*>(t[0]);
+    const bool is_v = i >= H;
+    const int n = is_v ? i - H : i;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(is_v ? t[2] : t[1]) + (size_t)n * 4);
+    uint2 o;
+    o.x = pack_bf2(v[0], v[1]);
+    o.y = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(w + (size_t)(is_v ? 2 * H + n : n) * ld_w + H + (is_v ? 4 : 0)) = o;
+}
+
 // HF "extended attention mask": (1 - m) * finfo(float32).min, added to the scores of padded keys
 __global__ void mask_to_bias_kernel(const int64_t* __restrict__ mask, int n, float* __restrict__ bias) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,6 +299,15 @@ extern "C" int bsclip_cast_f32_bf16(const float* in, int64_t n, void* out, void*
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in,
                        (long)n, static_cast<bf16_t*>(out));
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+extern "C" int bsclip_waug_set_lora_layers(const int64_t* table_dev, int layers, int ld_w, int H, void* stream) {
+    BSCLIP_REQUIRE(table_dev && layers > 0 && layers <= 65535 && ld_w >= H + BSCLIP_KPAD && ld_w % 4 == 0 && H % 4 == 0,
+                   "bsclip_waug_set_lora_layers: bad args");
+    hipLaunchKernelGGL(waug_set_lora_layers_kernel, dim3(ceil_div(2 * H, 256), layers), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       table_dev, ld_w, H);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

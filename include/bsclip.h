@@ -396,6 +396,9 @@ int bsclip_cast_f32_bf16(const float* in, int64_t n, void* out, void* stream);
 /* W_aug[3H, H+KPAD] bf16: cols [H,H+4) of rows [0,H) = B_q, cols [H+4,H+8) of rows [2H,3H) = B_v (refreshed
  * every step from the f32 masters; the frozen [3H,H] block is written once at pack time). */
 int bsclip_waug_set_lora(void* w_aug, int ld_w, int H, const float* lora_bq, const float* lora_bv, void* stream);
+/* ... for every LoRA layer of an encoder in one launch: table_dev[l] = {W_aug, B_q, B_v} as three 64-bit device addresses (the
+ * buffers live as long as the encoder: the table is built once); all layers share ld_w and H. */
+int bsclip_waug_set_lora_layers(const int64_t* table_dev, int layers, int ld_w, int H, void* stream);
 
 /* ---- full fine-tuning only (reference simple_clip.py:199-201 unfreezes every parameter) ----------------
  * ln_param_grad: d_gamma[c] += sum_r dy[r,c] xhat[r,c], d_beta[c] += sum_r dy[r,c] with dy assembled like
