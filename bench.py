@@ -43,7 +43,8 @@ GFLOP_PER_TRIPLE_IDT = 119.3
 # passes of profiles/r03_j_fc1_pmc.txt (tools/scripts/r03_pmc2.sh), taken after the persistent rewrite of the kernel
 # (766.1 MB before it: profiles/r03_b_fc1_pmc.txt).
 FC1_TRAFFIC_BYTES_B256 = 643.6e6
-FC1_TRAFFIC_SOURCE = "offline rocprofv3 --pmc passes (profiles/r03_j_fc1_pmc.txt, tools/scripts/r03_pmc2.sh), not collected by this run"
+FC1_TRAFFIC_SOURCE = ("offline rocprofv3 --pmc passes (profiles/r03_j_fc1_pmc.txt; re-run on the round-4 tree: profiles/r04_q_fc1_pmc.txt, "
+                      "tools/scripts/r04_gemm_pmc.sh -- same counters to 0.2 %), not collected by this run")
 METRIC = "paired samples/sec/node (I+D+T, global batch) + step MFMA-roofline % at 1/2/4/8 GPU"   # BASELINE.json:metric, verbatim
 
 
