@@ -57,7 +57,8 @@ if os.environ.get("BSCLIP_PARITY", "0") in ("1", "2"):
 
 
 def set_parity_mode(on, model=None):
-    """Switch at run time: 0 / False = default, 1 / True = f32 streams, 2 = f32 streams + the exact forward.  Engines built
+    """Switch at run time: 0 / False = default, 1 / True = f32 streams, 2 = the exact mode (f32 streams + the exact forward and
+    backward, csrc/exact.hip).  Engines built
     afterwards pick it up; pass ``model`` to have its engines rebuilt at the next forward.  Returns the previous
     (grad_stream_bf16, resid_stream_bf16) pair (restore with the module attributes; EXACT_FORWARD is reset by passing 0 / 1)."""
     global GRAD_STREAM_BF16, RESID_STREAM_BF16, EXACT_FORWARD
@@ -269,7 +270,7 @@ class EncoderEngineBase:
 
     fp8 = False
 
-    # ------------------------------------------------------------------------------ exact forward (BSCLIP_PARITY=2)
+    # ------------------------------------------------------------------------------ exact mode (BSCLIP_PARITY=2)
     def exact(self):
         return EXACT_FORWARD and not self.fp8 and not self.full_ft
 
