@@ -581,3 +581,41 @@ def test_detect_anomaly_names_where_non_finite_values_appear(monkeypatch):
             d.lora_barcode_bert.bert.encoder.layer[1].attention.self.value.w_a.weight[0, 0] = float("inf")
         with pytest.raises(RuntimeError, match=r"BertEngine forward: non-finite values first appear in encoder\.layer\.1\.attention\.self q / k / v"):
             d(ids)
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_train_epoch_entry_point_reproduces_the_reference_trajectory(exact, monkeypatch):
+    """``bioscanclip.epoch.train_epoch.train_epoch`` ITSELF (reference signature, the captured-graph launch path it
+    takes by default, the loss read one step late) over configs[0] -- five epochs of the two-batch loader = the golden run's ten
+    steps: the epoch means of the loss and the trainable parameters after the last epoch against the imported reference's
+    trajectory, at the trajectory tolerances of the default mode and at north_star's 1e-3 in the exact mode."""
+    from helpers import summary_distance
+    from bioscanclip.epoch.train_epoch import train_epoch
+    from bioscanclip.hip import engine
+    from bioscanclip.hip.optim import FusedAdamW
+    from bioscanclip.model.loss_func import ContrastiveLoss
+    if exact:
+        monkeypatch.setattr(engine, "RESID_STREAM_BF16", False)
+        monkeypatch.setattr(engine, "GRAD_STREAM_BF16", False)
+        monkeypatch.setattr(engine, "EXACT_FORWARD", True)
+    g = load_golden("trajectory_id")
+    tol = TRAJ_TOL_EXACT if exact else TRAJ_TOL[False]
+    model, _ = _build_clip(False, g["weight_seed"])
+    model.to("cuda")
+    opt = FusedAdamW(model.parameters(), lr=g["lr"])
+    crit = ContrastiveLoss(criterion=torch.nn.CrossEntropyLoss(), logit_scale=1 / 0.07)
+    loader = []
+    for i in range(g["n_batches"]):   # the reference's 7-tuple: (processid, image, dna, input_ids, token_type_ids, attention_mask, label)
+        image, dna, _, label = synth.synth_batch(g["B"], seed=g["batch_seed0"] + i)
+        loader.append((None, image, dna, None, None, None, label))
+    epochs = g["steps"] // g["n_batches"]
+    means = [train_epoch(False, epochs, e, loader, model, opt, crit, "cuda", scheduler=None, rank=0) for e in range(epochs)]
+    torch.cuda.synchronize()
+    ref = [sum(g["losses"][e * g["n_batches"]:(e + 1) * g["n_batches"]]) / g["n_batches"] for e in range(epochs)]
+    err = [abs(a - b) / abs(b) for a, b in zip(means, ref)]
+    named = dict(model.named_parameters())
+    pd = {k: summary_distance(k, named[k], gs) for k, gs in g["params_after"].items()}
+    worst = max(max(d.values()) for d in pd.values())
+    _log({"test": f"train_epoch_trajectory exact={exact}", "epoch_mean_loss": means, "ref": ref, "loss_rel_err": err, "params_after_worst": worst})
+    assert getattr(model, "_bsclip_graphed", None) is not None and model.image_encoder._engine.exact() == exact   # the captured path ran
+    assert max(err) < tol["loss"] and worst < tol["params"], (err, worst)
