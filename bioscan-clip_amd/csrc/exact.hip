@@ -784,6 +784,8 @@ extern "C" int bsclip_exact_attn_set_impl(int impl) {
 
 extern "C" int bsclip_split3_rows(const float* src, int ld_src, int M, int K, void* dst, int ld_dst, void* stream) {
     BSCLIP_REQUIRE(src && dst, "bsclip_split3_rows: null pointer");
+    BSCLIP_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0,
+                   "bsclip_split3_rows: src must be 16-byte, dst 8-byte aligned");
     BSCLIP_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && ld_src >= K && ld_src % 4 == 0 && ld_dst >= 3 * K && ld_dst % 4 == 0,
                    "bsclip_split3_rows: M=%d K=%d ld_src=%d ld_dst=%d", M, K, ld_src, ld_dst);
     const size_t n = (size_t)M * (K / 4);
@@ -810,6 +812,9 @@ extern "C" int bsclip_split3_weight(const float* w, int ld_w, int N, int K, cons
 extern "C" int bsclip_gelu_split3(const float* z, int ld_z, int M, int N, void* dst, int ld_dst, void* codes, int ld_codes, float* g32,
                                   int ld_g32, void* stream) {
     BSCLIP_REQUIRE(z && (dst || g32), "bsclip_gelu_split3: null pointer");
+    BSCLIP_REQUIRE(((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(g32)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0 &&
+                       (reinterpret_cast<uintptr_t>(codes) & 3) == 0,
+                   "bsclip_gelu_split3: z / g32 must be 16-byte, dst 8-byte, codes 4-byte aligned");
     BSCLIP_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld_z >= N && ld_z % 4 == 0 && (dst == nullptr || (ld_dst >= 3 * N && ld_dst % 4 == 0)) &&
                        (codes == nullptr || (ld_codes >= N && ld_codes % 4 == 0)) && (g32 == nullptr || (ld_g32 >= N && ld_g32 % 4 == 0)),
                    "bsclip_gelu_split3: M=%d N=%d ld_z=%d ld_dst=%d ld_codes=%d ld_g32=%d", M, N, ld_z, ld_dst, ld_codes, ld_g32);
@@ -833,6 +838,8 @@ extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, i
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= AF_SMAX, "bsclip_attn_fwd_f32: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 4 == 0 && ld_ctx >= heads * 64 && ld_ctx % 4 == 0,
                    "bsclip_attn_fwd_f32: ld_qkv=%d ld_ctx=%d", ld_qkv, ld_ctx);
+    BSCLIP_REQUIRE(((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(ctx)) & 15) == 0,
+                   "bsclip_attn_fwd_f32: qkv and ctx must be 16-byte aligned (vector loads / stores)");
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_fwd_f32: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -859,6 +866,9 @@ extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, i
 extern "C" int bsclip_dgelu_split3(const float* dact, int ld_dact, const float* z, int ld_z, int M, int N, void* dst, int ld_dst,
                                    float* out32, int ld_out32, void* stream) {
     BSCLIP_REQUIRE(dact && z && (dst || out32), "bsclip_dgelu_split3: null pointer");
+    BSCLIP_REQUIRE(((reinterpret_cast<uintptr_t>(dact) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(out32)) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(dst) & 7) == 0,
+                   "bsclip_dgelu_split3: dact / z / out32 must be 16-byte, dst 8-byte aligned");
     BSCLIP_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld_dact >= N && ld_dact % 4 == 0 && ld_z >= N && ld_z % 4 == 0 &&
                        (dst == nullptr || (ld_dst >= 3 * N && ld_dst % 4 == 0)) && (out32 == nullptr || (ld_out32 >= N && ld_out32 % 4 == 0)),
                    "bsclip_dgelu_split3: M=%d N=%d ld_dact=%d ld_z=%d ld_dst=%d ld_out32=%d", M, N, ld_dact, ld_z, ld_dst, ld_out32);
@@ -921,6 +931,9 @@ extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dc
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 4 == 0 && ld_dqkv >= 3 * heads * 64 && ld_dqkv % 4 == 0 && ld_ctx >= heads * 64 &&
                        ld_ctx % 4 == 0 && ld_dctx >= heads * 64 && ld_dctx % 4 == 0,
                    "bsclip_attn_bwd_f32: ld_qkv=%d ld_dqkv=%d ld_ctx=%d ld_dctx=%d", ld_qkv, ld_dqkv, ld_ctx, ld_dctx);
+    BSCLIP_REQUIRE(((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(dctx) |
+                     reinterpret_cast<uintptr_t>(dqkv)) & 15) == 0,
+                   "bsclip_attn_bwd_f32: qkv, ctx, dctx and dqkv must be 16-byte aligned (vector loads / stores)");
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_bwd_f32: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
