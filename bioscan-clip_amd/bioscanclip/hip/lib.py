@@ -56,8 +56,6 @@ SIGNATURES = {
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, F, U, I, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
-    "bsclip_attn_fwd2": (I, [P, I, I, I, I, P, F, P, P, I, P, F, U, P]),
-    "bsclip_attn_bwd2": (I, [P, I, P, I, P, P, I, P, I, I, I, P, F, P, I, F, U, P]),
     "bsclip_split3_rows": (I, [P, I, I, I, P, I, P]),
     "bsclip_split3_weight": (I, [P, I, I, I, P, P, I, P, I, P]),
     "bsclip_gelu_split3": (I, [P, I, I, I, P, I, P, I, P, I, P]),
@@ -101,7 +99,6 @@ SIGNATURES = {
     "bsclip_colsum": (I, [P, I, I, I, I, P, P]),
     "bsclip_transpose_bf16": (I, [P, I, I, I, P, I, P]),
     "bsclip_cast_f32_bf16": (I, [P, L, P, P]),
-    "bsclip_waug_set_lora": (I, [P, I, I, P, P, P]),
     "bsclip_waug_set_lora_layers": (I, [P, I, I, I, P]),
     "bsclip_ln_param_grad_workspace_floats": (L, [I]),
     "bsclip_ln_param_grad": (I, [P, I, I, P, I, I, P, I, P, I, P, P, I, F, U, P, P, P, P]),
@@ -126,6 +123,8 @@ DIAG_SIGNATURES = {
     "bsclip_gemm_duo_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, P]),
     "bsclip_gemm_pers_diag": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), P, I, P]),
     "bsclip_attn_bwd_diag": (I, [P, I, P, I, P, I, I, I, F, P, I, P, P]),
+    "bsclip_attn_fwd2": (I, [P, I, I, I, I, P, F, P, P, I, P, F, U, P]),
+    "bsclip_attn_bwd2": (I, [P, I, P, I, P, P, I, P, I, I, I, P, F, P, I, F, U, P]),
     "bsclip_attn_bwd2_diag": (I, [P, I, P, I, P, P, I, P, I, I, I, F, P, I, P, P]),
     "bsclip_attn_bwd_pers_diag": (I, [P, I, P, I, P, P, I, P, I, I, I, F, P, I, P, P]),
 }

@@ -443,6 +443,7 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
     return BSCLIP_OK;
 }
 
+#ifdef BSCLIP_DIAG   // experiment (round 4): only in libbsclip_hip_diag.so, like the backward it serves (attn_sweep.hip / attn_pers.hip)
 #define ATTN_FWD2_LAUNCH(NBV, DR, TL)                                                                           \
     hipLaunchKernelGGL((attn_fwd_kernel<NBV, DR, TL, true>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
                        static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale, static_cast<bf16_t*>(ctx), ld_ctx, \
@@ -483,6 +484,7 @@ extern "C" int bsclip_attn_fwd2(const void* qkv, int ld_qkv, int B, int S, int h
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }
+#endif  // BSCLIP_DIAG
 
 #define ATTN_BWD_LAUNCH(NBV, DR, TL)                                                                             \
     hipLaunchKernelGGL((attn_bwd_kernel<NBV, DR, false, TL>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \

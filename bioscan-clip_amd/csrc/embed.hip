@@ -173,21 +173,7 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
 }
 
 // W_aug rows [0,H): cols [H,H+4) = B_q[n,:]; rows [2H,3H): cols [H+4,H+8) = B_v[n,:]
-__global__ void waug_set_lora_kernel(bf16_t* __restrict__ w, int ld_w, int H, const float* __restrict__ bq,
-                                     const float* __restrict__ bv) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * H) return;
-    const bool is_v = i >= H;
-    const int n = is_v ? i - H : i;
-    const f32x4 v = *reinterpret_cast<const f32x4*>((is_v ? bv : bq) + (size_t)n * 4);
-    uint2 o;
-    o.x = pack_bf2(v[0], v[1]);
-    o.y = pack_bf2(v[2], v[3]);
-    bf16_t* dst = w + (size_t)(is_v ? 2 * H + n : n) * ld_w + H + (is_v ? 4 : 0);
-    *reinterpret_cast<uint2*>(dst) = o;
-}
-
-// the same for every LoRA layer of an encoder in one launch (blockIdx.y = layer): table[l] = {W_aug, B_q, B_v} device addresses
+// for every LoRA layer of an encoder in one launch (blockIdx.y = layer): table[l] = {W_aug, B_q, B_v} device addresses
 __global__ void waug_set_lora_layers_kernel(const int64_t* __restrict__ table, int ld_w, int H) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * H) return;
@@ -308,16 +294,6 @@ extern "C" int bsclip_waug_set_lora_layers(const int64_t* table_dev, int layers,
                    "bsclip_waug_set_lora_layers: bad args");
     hipLaunchKernelGGL(waug_set_lora_layers_kernel, dim3(ceil_div(2 * H, 256), layers), dim3(256), 0, static_cast<hipStream_t>(stream),
                        table_dev, ld_w, H);
-    BSCLIP_LAUNCH_CHECK();
-    return BSCLIP_OK;
-}
-
-extern "C" int bsclip_waug_set_lora(void* w_aug, int ld_w, int H, const float* lora_bq, const float* lora_bv,
-                                    void* stream) {
-    BSCLIP_REQUIRE(w_aug && lora_bq && lora_bv && ld_w >= H + BSCLIP_KPAD && ld_w % 4 == 0 && H % 4 == 0,
-                   "bsclip_waug_set_lora: bad args");
-    hipLaunchKernelGGL(waug_set_lora_kernel, dim3(ceil_div(2 * H, 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), static_cast<bf16_t*>(w_aug), ld_w, H, lora_bq, lora_bv);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

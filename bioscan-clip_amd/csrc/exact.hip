@@ -799,6 +799,11 @@ extern "C" int bsclip_split3_weight(const float* w, int ld_w, int N, int K, cons
                                     int ld_dst, void* stream) {
     BSCLIP_REQUIRE(w && dst, "bsclip_split3_weight: null pointer");
     BSCLIP_REQUIRE((lora_a == nullptr) == (lora_b == nullptr), "bsclip_split3_weight: lora_a and lora_b go together");
+    // the kernel reads w, lora_a and lora_b as f32x4 and writes dst as 8-byte words: views into a flat parameter buffer are aligned
+    // only while every parameter's numel is a multiple of 4 -- a misaligned view must be an error code, not a GPU fault
+    BSCLIP_REQUIRE(((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(lora_a) | reinterpret_cast<uintptr_t>(lora_b)) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(dst) & 7) == 0,
+                   "bsclip_split3_weight: w / lora_a / lora_b must be 16-byte, dst 8-byte aligned");
     BSCLIP_REQUIRE(N > 0 && K > 0 && K % 4 == 0 && ld_w >= K && ld_w % 4 == 0 && ld_dst >= 3 * K && ld_dst % 4 == 0 &&
                        (lora_a == nullptr || (N == 3 * H && K == H)),
                    "bsclip_split3_weight: N=%d K=%d H=%d ld_w=%d ld_dst=%d", N, K, H, ld_w, ld_dst);

@@ -111,7 +111,7 @@ int bsclip_gemm_fp8(const void* A8, int lda, const void* B8, int ldb, void* C, i
  * (1 for an all-zero row), dst = round(src / scale[r]).  C % 4 == 0. */
 int bsclip_quantize_rows_fp8(const float* src, int R, int C, void* dst, int ld_dst, float* scale, void* stream);
 /* b_aug[3H, 64] bf16 (zero outside the LoRA columns): cols [0,4) of rows [0,H) = B_q / alpha, cols [4,8) of rows [2H,3H) =
- * B_v / alpha, refreshed every step from the f32 masters (the fp8 counterpart of bsclip_waug_set_lora). */
+ * B_v / alpha, refreshed every step from the f32 masters (the fp8 counterpart of bsclip_waug_set_lora_layers). */
 int bsclip_lora_baug_set(void* b_aug, int ld_b, int H, const float* lora_bq, const float* lora_bv, const float* alpha,
                          void* stream);
 /* one-time device tables (GELU Phi/phi table of the 256x256 kernel's epilogue).  bsclip_gemm_bf16 fills them lazily on
@@ -148,6 +148,19 @@ int bsclip_gemm_pers_diag(const void* A, int lda, const void* B, int ldb, void* 
  * diag[B*heads*4*8]; tools/attn_phases.py */
 int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
                          int heads, float scale, void* dqkv, int ld_dqkv, unsigned long long* diag, void* stream);
+/* Round 4 experiment, NOT a product kernel since ABI 9 (the pair is a wash against bsclip_attn_fwd / bsclip_attn_bwd):
+ * the same attention with a backward that forms every product once (csrc/attn_sweep.hip: key-owner waves sweep the query
+ * blocks, a dQ wave follows; 20 MFMAs + 16 exp per 32x32 tile pair instead of 32 + 32).  delta = rowsum(P . dP) is taken from
+ * the forward's OUTPUT, which therefore leaves O to 16 mantissa bits -- ctx = bf16(O) (the out-projection's operand, as before)
+ * and ctx_lo = bf16(O - ctx), same layout -- and per query row stats[B, heads, S, 4] f32 = (nm2, inv, rZ, 0): e_k = exp2(s_k
+ * scale log2e + nm2), inv = 1 / sum_k e_k, rZ = sum_k e_k / Z' where Z' sums the bf16-ROUNDED operands of the P.V product
+ * (dropped keys: their e_k), so that sum_k dS_k = 0 holds to f32 rounding with delta = (dctx . O) rZ.  stats 16-byte aligned.
+ * No q_rows form (every query row carries a gradient); argument meaning otherwise as bsclip_attn_fwd / bsclip_attn_bwd. */
+int bsclip_attn_fwd2(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, void* ctx,
+                     void* ctx_lo, int ld_ctx, float* stats, float dropout_p, uint32_t dropout_seed, void* stream);
+int bsclip_attn_bwd2(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo, int ld_ctx,
+                     const float* stats, int B, int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
+                     float dropout_p, uint32_t dropout_seed, void* stream);
 /* the key-owner-sweep backward (bsclip_attn_bwd2; S = 197 or 133, no mask, no dropout) with per-wave section stamps,
  * diag[B*heads*(NB+1)*8], NB = ceil(S / 32) key-owner waves + the dQ wave; tools/attn_sweep_phases.py */
 int bsclip_attn_bwd2_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo,
@@ -208,19 +221,6 @@ int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const 
 int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
                     int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
                     float dropout_p, uint32_t dropout_seed, void* stream);
-
-/* Round 4: the same attention with a backward that forms every product once (csrc/attn_sweep.hip: key-owner waves sweep the query
- * blocks, a dQ wave follows; 20 MFMAs + 16 exp per 32x32 tile pair instead of 32 + 32).  delta = rowsum(P . dP) is taken from
- * the forward's OUTPUT, which therefore leaves O to 16 mantissa bits -- ctx = bf16(O) (the out-projection's operand, as before)
- * and ctx_lo = bf16(O - ctx), same layout -- and per query row stats[B, heads, S, 4] f32 = (nm2, inv, rZ, 0): e_k = exp2(s_k
- * scale log2e + nm2), inv = 1 / sum_k e_k, rZ = sum_k e_k / Z' where Z' sums the bf16-ROUNDED operands of the P.V product
- * (dropped keys: their e_k), so that sum_k dS_k = 0 holds to f32 rounding with delta = (dctx . O) rZ.  stats 16-byte aligned.
- * No q_rows form (every query row carries a gradient); argument meaning otherwise as bsclip_attn_fwd / bsclip_attn_bwd. */
-int bsclip_attn_fwd2(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, void* ctx,
-                     void* ctx_lo, int ld_ctx, float* stats, float dropout_p, uint32_t dropout_seed, void* stream);
-int bsclip_attn_bwd2(const void* qkv, int ld_qkv, const void* dctx, int ld_dctx, const void* ctx, const void* ctx_lo, int ld_ctx,
-                     const float* stats, int B, int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv,
-                     float dropout_p, uint32_t dropout_seed, void* stream);
 
 /* ---- "exact" forward mode (BSCLIP_PARITY=2; csrc/exact.hip): every trunk GEMM on split-bf16 operands, f32 attention -----------
  * A bf16 MFMA GEMM is exact to ~2^-16 when both operands are carried as hi + lo (hi = bf16(x), lo = bf16(x - hi)) and the product is
@@ -394,10 +394,10 @@ int bsclip_transpose_colsum_bf16(const void* in, int ld_in, int R, int C, void* 
                                  float* workspace, void* stream);
 int bsclip_cast_f32_bf16(const float* in, int64_t n, void* out, void* stream);
 /* W_aug[3H, H+KPAD] bf16: cols [H,H+4) of rows [0,H) = B_q, cols [H+4,H+8) of rows [2H,3H) = B_v (refreshed
- * every step from the f32 masters; the frozen [3H,H] block is written once at pack time). */
-int bsclip_waug_set_lora(void* w_aug, int ld_w, int H, const float* lora_bq, const float* lora_bv, void* stream);
-/* ... for every LoRA layer of an encoder in one launch: table_dev[l] = {W_aug, B_q, B_v} as three 64-bit device addresses (the
- * buffers live as long as the encoder: the table is built once); all layers share ld_w and H. */
+ * every step from the f32 masters; the frozen [3H,H] block is written once at pack time).
+ * One launch for every LoRA layer of an encoder: table_dev[l] = {W_aug, B_q, B_v} as three 64-bit device addresses (the buffers live
+ * as long as the encoder: the table is built once); all layers share ld_w and H.  (ABI 9: the one-layer form bsclip_waug_set_lora is
+ * gone -- no engine called it.) */
 int bsclip_waug_set_lora_layers(const int64_t* table_dev, int layers, int ld_w, int H, void* stream);
 
 /* ---- full fine-tuning only (reference simple_clip.py:199-201 unfreezes every parameter) ----------------

@@ -21,10 +21,17 @@ import math
 import torch
 
 
-def _q(x, emulate_bf16):
+# Rounding sites left exact under emulate_bf16 (tools/site_sensitivity.py: which operand roundings carry the distance to the f32
+# reference; hip/engine.py's BSCLIP_PARITY=3 splits exactly the sites named here).  Site names: "qkv.a" / "qkv.w" (QKV GEMM
+# operands), "q" / "k" / "v" (the attention operands = the QKV GEMM's stored output), "p" (un-normalised probabilities),
+# "proj.a" / "proj.w", "fc1.a" / "fc1.w", "fc2.a" / "fc2.w", "resid", "head.a" / "head.w", "lora" (t and the LoRA-B operand).
+EXACT_SITES = set()
+
+
+def _q(x, emulate_bf16, site=None):
     """Optional bf16 rounding of a GEMM operand (straight-through for autograd).  Used to restate
     *where* the HIP path rounds (A/B operands of every MFMA GEMM) while keeping fp32 math."""
-    if not emulate_bf16:
+    if not emulate_bf16 or (site is not None and site in EXACT_SITES):
         return x
     return x + (x.detach().to(torch.bfloat16).to(x.dtype) - x.detach())
 
@@ -40,7 +47,7 @@ EMULATE_PATCH_SPLIT = True
 
 def _rq(x, emulate_bf16):
     """bf16 rounding of a stored residual-stream tensor (only under emulate_bf16)."""
-    return _q(x, emulate_bf16 and EMULATE_RESID_BF16)
+    return _q(x, emulate_bf16 and EMULATE_RESID_BF16, "resid")
 
 
 def _q8(x, scale=None):
@@ -62,8 +69,8 @@ def linear_fp8(x, w, b=None):
     return y if b is None else y + b
 
 
-def linear(x, w, b=None, emulate_bf16=False):
-    y = _q(x, emulate_bf16) @ _q(w, emulate_bf16).t()
+def linear(x, w, b=None, emulate_bf16=False, site=None):
+    y = _q(x, emulate_bf16, site and site + ".a") @ _q(w, emulate_bf16, site and site + ".w").t()
     return y if b is None else y + b
 
 
@@ -90,7 +97,7 @@ def sdpa(q, k, v, bias=None, emulate_bf16=False):
     if not emulate_bf16:
         return torch.softmax(s, dim=-1) @ v
     e = torch.exp(s - s.amax(dim=-1, keepdim=True))
-    return (_q(e, True) @ v) / e.sum(dim=-1, keepdim=True)
+    return (_q(e, True, "p") @ v) / e.sum(dim=-1, keepdim=True)
 
 
 # --------------------------------------------------------------------------------------
@@ -106,7 +113,7 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
     # fp8 trunks (emulate_fp8): QKV / fc1 / fc2 take e4m3 operands, everything else rounds as the bf16 path does; the fp8 engines
     # keep the f32 residual stream
     rq = (lambda t, e: t) if emulate_fp8 else _rq
-    lin8 = (lambda x, w, b, e: linear_fp8(x, w, b)) if emulate_fp8 else linear
+    lin8 = (lambda x, w, b, e, site=None: linear_fp8(x, w, b)) if emulate_fp8 else linear
     B = image.shape[0]
     w_pe = p("patch_embed.proj.weight")
     D = w_pe.shape[0]
@@ -126,33 +133,33 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
         b = f"blocks.{i}."
         h = layer_norm(x, p(b + "norm1.weight"), p(b + "norm1.bias"), 1e-6)
         if (prefix + b + "attn.qkv.qkv.weight") in sd:  # _LoRA_qkv_timm surgery applied
-            qkv = lin8(h, p(b + "attn.qkv.qkv.weight"), p(b + "attn.qkv.qkv.bias"), eb)
+            qkv = lin8(h, p(b + "attn.qkv.qkv.weight"), p(b + "attn.qkv.qkv.bias"), eb, site="qkv")
             # emulation note: the HIP LayerNorm kernel forms t = y A^T from the f32 row and the f32 master A and rounds
             # only t (csrc/norm.hip), so the inner product is NOT taken on rounded operands
             t_q = linear(h, p(b + "attn.qkv.linear_a_q.weight"))
             t_v = linear(h, p(b + "attn.qkv.linear_a_v.weight"))
             tap(f"t.{i}", torch.cat([t_q, t_v], dim=-1))
-            new_q = linear(t_q, p(b + "attn.qkv.linear_b_q.weight"), None, eb)
-            new_v = linear(t_v, p(b + "attn.qkv.linear_b_v.weight"), None, eb)
+            new_q = linear(t_q, p(b + "attn.qkv.linear_b_q.weight"), None, eb, site="lora")
+            new_v = linear(t_v, p(b + "attn.qkv.linear_b_v.weight"), None, eb, site="lora")
             qkv = torch.cat([qkv[..., :D] + new_q, qkv[..., D:2 * D], qkv[..., 2 * D:] + new_v], dim=-1)
         else:
-            qkv = lin8(h, p(b + "attn.qkv.weight"), p(b + "attn.qkv.bias"), eb)
+            qkv = lin8(h, p(b + "attn.qkv.weight"), p(b + "attn.qkv.bias"), eb, site="qkv")
         S = qkv.shape[1]
         qkv = qkv.reshape(B, S, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
         tap(f"h1.{i}", h)
         tap(f"qkv.{i}", qkv.permute(1, 3, 0, 2, 4).reshape(B, S, 3 * D))
-        ctx = sdpa(_q(qkv[0], eb), _q(qkv[1], eb), _q(qkv[2], eb), emulate_bf16=eb).transpose(1, 2).reshape(B, S, D)
+        ctx = sdpa(_q(qkv[0], eb, "q"), _q(qkv[1], eb, "k"), _q(qkv[2], eb, "v"), emulate_bf16=eb).transpose(1, 2).reshape(B, S, D)
         tap(f"ctx.{i}", ctx)
-        x = rq(x + linear(ctx, p(b + "attn.proj.weight"), p(b + "attn.proj.bias"), eb), eb)
+        x = rq(x + linear(ctx, p(b + "attn.proj.weight"), p(b + "attn.proj.bias"), eb, site="proj"), eb)
         tap(f"x{2 * i + 1}", x)
         h = layer_norm(x, p(b + "norm2.weight"), p(b + "norm2.bias"), 1e-6)
-        h = gelu_erf(lin8(h, p(b + "mlp.fc1.weight"), p(b + "mlp.fc1.bias"), eb))
-        x = rq(x + lin8(h, p(b + "mlp.fc2.weight"), p(b + "mlp.fc2.bias"), eb), eb)
+        h = gelu_erf(lin8(h, p(b + "mlp.fc1.weight"), p(b + "mlp.fc1.bias"), eb, site="fc1"))
+        x = rq(x + lin8(h, p(b + "mlp.fc2.weight"), p(b + "mlp.fc2.bias"), eb, site="fc2"), eb)
         tap(f"x{2 * i + 2}", x)
     x = layer_norm(x, p("norm.weight"), p("norm.bias"), 1e-6)
     if return_hidden:
         return x
-    return linear(x[:, 0], p("head.weight"), p("head.bias"), eb)
+    return linear(x[:, 0], p("head.weight"), p("head.bias"), eb, site="head")
 
 
 # --------------------------------------------------------------------------------------
@@ -160,13 +167,13 @@ def vit_encoder(sd, image, prefix="image_encoder.lora_vit.", num_heads=12, emula
 # --------------------------------------------------------------------------------------
 def _lora_or_plain(sd, base, h, eb, f8=False):
     """``_LoRALayer.forward``: ``w(x) + w_b(w_a(x))`` (dna_encoder.py:47-49) or the untouched Linear."""
-    lin = (lambda x, w, b, e: linear_fp8(x, w, b)) if f8 else linear
+    lin = (lambda x, w, b, e, site=None: linear_fp8(x, w, b)) if f8 else linear
     if (base + "w.weight") in sd:
         # (emulation: t = h w_a^T is formed in f32 and only t is rounded, as in the ViT branch above; fp8 trunks: the frozen
         # weight takes e4m3 operands, the LoRA branch stays bf16)
-        return lin(h, sd[base + "w.weight"], sd[base + "w.bias"], eb) + linear(
-            linear(h, sd[base + "w_a.weight"]), sd[base + "w_b.weight"], None, eb)
-    return lin(h, sd[base + "weight"], sd[base + "bias"], eb)
+        return lin(h, sd[base + "w.weight"], sd[base + "w.bias"], eb, site="qkv") + linear(
+            linear(h, sd[base + "w_a.weight"]), sd[base + "w_b.weight"], None, eb, site="lora")
+    return lin(h, sd[base + "weight"], sd[base + "bias"], eb, site="qkv")
 
 
 def bert_encoder(sd, prefix, input_ids, token_type_ids=None, attention_mask=None, num_heads=12, eps=1e-12,
@@ -178,7 +185,7 @@ def bert_encoder(sd, prefix, input_ids, token_type_ids=None, attention_mask=None
     eb = emulate_bf16 or emulate_fp8
     f8 = emulate_fp8
     rq = (lambda t, e: t) if f8 else _rq          # the fp8 engines keep the f32 residual stream
-    lin8 = (lambda x, w, b, e: linear_fp8(x, w, b)) if f8 else linear
+    lin8 = (lambda x, w, b, e, site=None: linear_fp8(x, w, b)) if f8 else linear
     B, S = input_ids.shape
     if token_type_ids is None:
         token_type_ids = torch.zeros_like(input_ids)
@@ -205,13 +212,13 @@ def bert_encoder(sd, prefix, input_ids, token_type_ids=None, attention_mask=None
         k = _lora_or_plain(sd, lp + "attention.self.key.", h, eb, f8)
         v = _lora_or_plain(sd, lp + "attention.self.value.", h, eb, f8)
         sh = lambda t: t.reshape(B, S, num_heads, hd).transpose(1, 2)
-        ctx = sdpa(_q(sh(q), eb), _q(sh(k), eb), _q(sh(v), eb), bias, emulate_bf16=eb).transpose(1, 2).reshape(B, S, H)
-        a = linear(ctx, sd[lp + "attention.output.dense.weight"], sd[lp + "attention.output.dense.bias"], eb)
+        ctx = sdpa(_q(sh(q), eb, "q"), _q(sh(k), eb, "k"), _q(sh(v), eb, "v"), bias, emulate_bf16=eb).transpose(1, 2).reshape(B, S, H)
+        a = linear(ctx, sd[lp + "attention.output.dense.weight"], sd[lp + "attention.output.dense.bias"], eb, site="proj")
         # (bf16 stream: the LayerNorm's bf16 GEMM operand IS the residual branch, and the sum is stored rounded)
         h = layer_norm(rq(rq(h, eb) + a, eb), sd[lp + "attention.output.LayerNorm.weight"],
                        sd[lp + "attention.output.LayerNorm.bias"], eps)
-        m = gelu_erf(lin8(h, sd[lp + "intermediate.dense.weight"], sd[lp + "intermediate.dense.bias"], eb))
-        m = lin8(m, sd[lp + "output.dense.weight"], sd[lp + "output.dense.bias"], eb)
+        m = gelu_erf(lin8(h, sd[lp + "intermediate.dense.weight"], sd[lp + "intermediate.dense.bias"], eb, site="fc1"))
+        m = lin8(m, sd[lp + "output.dense.weight"], sd[lp + "output.dense.bias"], eb, site="fc2")
         h = layer_norm(rq(rq(h, eb) + m, eb), sd[lp + "output.LayerNorm.weight"], sd[lp + "output.LayerNorm.bias"], eps)
     return h
 
@@ -223,9 +230,9 @@ def barcode_bert_encoder(sd, ids, prefix="dna_encoder.lora_barcode_bert.", num_h
     eb = emulate_bf16 or emulate_fp8
     h = bert_encoder(sd, prefix + "bert.", ids, num_heads=num_heads, emulate_bf16=eb, emulate_fp8=emulate_fp8)
     t = prefix + "cls.predictions."
-    h = gelu_erf(linear(h, sd[t + "transform.dense.weight"], sd[t + "transform.dense.bias"], eb))
+    h = gelu_erf(linear(h, sd[t + "transform.dense.weight"], sd[t + "transform.dense.bias"], eb, site="head"))
     h = layer_norm(h, sd[t + "transform.LayerNorm.weight"], sd[t + "transform.LayerNorm.bias"], 1e-12)
-    logits = linear(h, sd[t + "decoder.weight"], sd[t + "decoder.bias"], eb)
+    logits = linear(h, sd[t + "decoder.weight"], sd[t + "decoder.bias"], eb, site="head")
     return torch.softmax(logits, dim=-1).mean(dim=1)
 
 
@@ -235,7 +242,7 @@ def bert_text_encoder(sd, language_input, prefix="language_encoder.", num_heads=
     h = bert_encoder(sd, prefix + "lora_bert.", language_input["input_ids"],
                      language_input.get("token_type_ids"), language_input.get("attention_mask"),
                      num_heads=num_heads, emulate_bf16=emulate_bf16)
-    return linear(h.mean(dim=1), sd[prefix + "proj.weight"], sd[prefix + "proj.bias"], emulate_bf16)
+    return linear(h.mean(dim=1), sd[prefix + "proj.weight"], sd[prefix + "proj.bias"], emulate_bf16, site="head")
 
 
 def l2_normalize(x, eps=1e-12):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/bsclip.h but not exported"
-    assert handle.bsclip_abi_version() == 8
+    assert handle.bsclip_abi_version() == 9
 
 
 def test_ctypes_table_matches_header():
@@ -68,3 +68,35 @@ def test_argument_validation_without_gpu():
     assert "null operand" in lib.last_error()
     assert h.bsclip_infonce_workspace_floats(256, 1) == -1
     assert h.bsclip_infonce_workspace_floats(256, 2) > 0
+
+
+# entry points that launch nothing: queries, the error string and the process-global benchmarking switches (kernel selection for
+# tests / tools / bench.py A-B runs; tests/conftest.py resets them after every GPU test)
+CONTROL_ENTRY_POINTS = {"bsclip_last_error", "bsclip_abi_version", "bsclip_epi_args_size", "bsclip_gemm_set_tile",
+                        "bsclip_gemm_set_persistent_grid", "bsclip_exact_attn_set_impl", "bsclip_infonce_set_impl"}
+
+
+def test_product_library_ships_only_what_an_engine_launches():
+    """Every compute entry point of libbsclip_hip.so is reached from the product package: its ``hip/ops.py`` wrapper is called by an
+    engine / optimizer / loss / pipeline module (or the entry point is named there directly).  Kernels nothing launches belong in the
+    diagnostic library (round 4's key-owner-sweep attention lived in the product library unused)."""
+    import glob
+    from bioscanclip.hip import lib
+    pkg = os.path.join(ROOT, "bioscan-clip_amd")
+    src = {f: open(f).read() for f in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True)}
+    ops_src = src[os.path.join(pkg, "bioscanclip", "hip", "ops.py")]
+    wrappers = {}
+    for blk in re.split(r"\n(?=def )", ops_src):
+        m = re.match(r"def (\w+)\(", blk)
+        if m:
+            wrappers[m.group(1)] = set(re.findall(r"\b(bsclip_\w+)\b", blk))
+    callers = "\n".join(v for k, v in src.items() if not k.endswith(os.path.join("hip", "ops.py")) and not k.endswith(os.path.join("hip", "lib.py")))
+    unused = []
+    for name in lib.SIGNATURES:
+        if name in CONTROL_ENTRY_POINTS or re.search(r"\b" + name + r"\b", callers):
+            continue
+        via = [f for f, e in wrappers.items() if name in e]
+        if not any(re.search(r"\bops\." + f + r"\b", callers) or re.search(r"(?<!def )\b" + f + r"\(", ops_src) for f in via):
+            unused.append(name)
+    assert not unused, f"exported by the product library but launched by no product module: {unused}"
+    assert CONTROL_ENTRY_POINTS <= set(lib.SIGNATURES)

@@ -165,33 +165,6 @@ def test_attention_dropout_fwd_bwd(ops, B, S, heads, masked):
         assert rel_err(dqkv[:, sl].float(), gq[:, sl]) < 3e-2, name
 
 
-@pytest.mark.parametrize("B,S,heads,masked", [(2, 64, 2, False), (3, 20, 8, True), (2, 133, 3, False), (2, 197, 3, False),
-                                              (25, 133, 12, False)])     # 300 items: the persistent kernel, 2 per workgroup
-def test_attention_sweep_dropout_matches_two_phase(ops, B, S, heads, masked):
-    """bsclip_attn_fwd2 / bwd2 with attention-probs dropout: the same (seed, element) masks as the two-phase kernels -- the
-    forward output is identical bit for bit -- and a gradient that agrees with theirs (which the test above holds to torch
-    autograd on the extracted mask) within bf16 rounding, dropped keys included (dS = -P delta there)."""
-    H = heads * 64
-    qkv = rnd(B * S, 3 * H, seed=1).bfloat16()
-    bias = None
-    if masked:
-        lens = torch.randint(2, S + 1, (B,), generator=torch.Generator().manual_seed(3))
-        bias = ((1.0 - (torch.arange(S)[None] < lens[:, None]).float()) * torch.finfo(torch.float32).min).cuda()
-    seed = 4242
-    ctx, ctx_lo, ctx1 = (torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16) for _ in range(3))
-    stats = torch.empty(B, heads, S, 4, device="cuda")
-    lse = torch.empty(B, heads, S, device="cuda")
-    ops.attn_fwd(qkv, B, S, heads, 0.125, ctx1, lse, key_bias=bias, dropout=(P, seed))
-    ops.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats, key_bias=bias, dropout=(P, seed))
-    assert torch.equal(ctx, ctx1)
-    dctx = rnd(B * S, H, seed=2).bfloat16()
-    new, old = (torch.empty(B * S, 3 * H, device="cuda", dtype=torch.bfloat16) for _ in range(2))
-    ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, old, key_bias=bias, dropout=(P, seed))
-    ops.attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, 0.125, new, key_bias=bias, dropout=(P, seed))
-    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
-        assert rel_err(new[:, sl].float(), old[:, sl].float()) < 8e-3, (name, rel_err(new[:, sl].float(), old[:, sl].float()))
-
-
 def test_engine_train_vs_eval_mode():
     """train mode: stochastic (a new mask per forward) with an unbiased mean; eval mode: deterministic and identical
     to the p = 0 configuration."""

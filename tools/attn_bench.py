@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.join(ROOT, "bioscan-clip_amd"))
 import torch  # noqa: E402
 
 from bioscanclip.hip import ops  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments"))
+import attn_sweep_ops as xo  # noqa: E402  (round-4 experiment kernels: diagnostic library only since ABI 9)
 
 B = int(os.environ.get("B", "256"))
 for name, S, p in (("vit", 197, 0.0), ("dna", 133, 0.1), ("dna-nodrop", 133, 0.0)):
@@ -22,8 +24,8 @@ for name, S, p in (("vit", 197, 0.0), ("dna", 133, 0.1), ("dna-nodrop", 133, 0.0
     res = {}
     for what, fn in (("fwd", lambda: ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse, dropout=drop)),
                      ("bwd", lambda: ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv, dropout=drop)),
-                     ("fwd2", lambda: ops.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats, dropout=drop)),
-                     ("bwd2", lambda: ops.attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, 0.125, dqkv, dropout=drop))):
+                     ("fwd2", lambda: xo.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats, dropout=drop)),
+                     ("bwd2", lambda: xo.attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, 0.125, dqkv, dropout=drop))):
         fn()
         best = 1e9
         for _ in range(3):

@@ -1,7 +1,10 @@
+import sys
 import os, sys
 sys.path.insert(0, "/root/repo/bioscan-clip_amd")
 import torch
 from bioscanclip.hip import ops
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments"))
+import attn_sweep_ops as xo  # noqa: E402  (round-4 experiment kernels: diagnostic library only since ABI 9)
 def t(fn, n=10):
     fn(); best = 1e9
     for _ in range(3):
@@ -22,6 +25,6 @@ for S in (197, 133):
         lse = torch.empty(B, heads, S, device="cuda")
         f = t(lambda: ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse))
         b = t(lambda: ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv))
-        ops.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats)
-        b2 = t(lambda: ops.attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, 0.125, dqkv))
+        xo.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats)
+        b2 = t(lambda: xo.attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, 0.125, dqkv))
         print(f"S={S} {name}: fwd {f:6.1f} us  bwd (two-phase) {b:6.1f} us  bwd2 (persistent sweep) {b2:6.1f} us", flush=True)

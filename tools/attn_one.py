@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.join(ROOT, "bioscan-clip_amd"))
 import torch  # noqa: E402
 
 from bioscanclip.hip import ops  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments"))
+import attn_sweep_ops as xo  # noqa: E402  (round-4 experiment kernels: diagnostic library only since ABI 9)
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 197
 p = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
@@ -22,6 +24,6 @@ stats = torch.empty(B, heads, S, 4, device="cuda")
 for _ in range(3):
     ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse, dropout=drop)
     ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv, dropout=drop)
-    ops.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats, dropout=drop)                 # the key-owner-sweep pair
-    ops.attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, 0.125, dqkv, dropout=drop)
+    xo.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats, dropout=drop)                 # the key-owner-sweep pair
+    xo.attn_bwd2(qkv, dctx, ctx, ctx_lo, stats, B, S, heads, 0.125, dqkv, dropout=drop)
 torch.cuda.synchronize()

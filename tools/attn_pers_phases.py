@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.join(ROOT, "bioscan-clip_amd"))
 import torch  # noqa: E402
 
 from bioscanclip.hip import lib, ops  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments"))
+import attn_sweep_ops as xo  # noqa: E402  (round-4 experiment kernels: diagnostic library only since ABI 9)
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 197
 B, heads, H = int(os.environ.get("B", "256")), 12, 768
@@ -20,7 +22,7 @@ ctx = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
 ctx_lo = torch.empty_like(ctx)
 dqkv = torch.empty(B * S, 3 * H, device="cuda", dtype=torch.bfloat16)
 stats = torch.empty(B, heads, S, 4, device="cuda")
-ops.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats)
+xo.attn_fwd2(qkv, B, S, heads, 0.125, ctx, ctx_lo, stats)
 grid = min(256, B * heads)
 diag = torch.zeros(grid * NW * 16, dtype=torch.int64, device="cuda")
 h = lib.load_diag()
