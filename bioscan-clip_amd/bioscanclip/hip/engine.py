@@ -39,6 +39,9 @@ RESID_STREAM_BF16 = os.environ.get("BSCLIP_RESID_STREAM", "bf16").lower() != "f3
 # one every block amplifies -- exact to ~2^-16 it takes the ViT's distance to the f32 reference at depth 12 from 2.5e-2 to
 # 1.7e-2 on the CPU emulation, for +0.8 % of the ViT's forward FLOPs.  "0" restores the plain bf16 GEMM.
 PATCH_SPLIT = os.environ.get("BSCLIP_PATCH_SPLIT", "1") != "0"
+# Attention-probs dropout (BERT towers, train mode): the forward kernel leaves its keep decisions as bit words, the backward reads them
+# instead of re-hashing (csrc/attn_common.h KEEP_WORDS).  "0" = re-hash in the backward (round 4's form; identical masks and gradients).
+ATTN_KEEP_BITS = os.environ.get("BSCLIP_ATTN_KEEP_BITS", "1") != "0"
 
 
 # BSCLIP_PARITY=1 / set_parity_mode(1): f32 residual stream, f32 residual-gradient stream, split-bf16 patch embedding -- at the
@@ -747,6 +750,10 @@ class BertEngine(EncoderEngineBase):
         ws["qkv"] = [z(M, 3 * H) for _ in range(L)]
         ws["ctx"] = [z(M, H) for _ in range(L)]
         ws["lse"] = [z(B, self.heads, S, dt=F32) for _ in range(L)]
+        # attention-probs dropout: the forward leaves its keep decisions (1 bit per probability, 32 B per query row) for the backward,
+        # which otherwise re-hashes every element (BSCLIP_ATTN_KEEP_BITS=0: the re-hashing form, same masks); 64 B per query row
+        ws["kbits"] = ([torch.zeros(B * self.heads * S * ops.KEEP_WORDS, dtype=torch.int32, device=dev) for _ in range(L)]
+                       if self.p_attn > 0.0 and ATTN_KEEP_BITS and not self.exact() else None)
         ws["s1"] = [z(M, H, dt=sdt) for _ in range(L)]      # pre-LN sums (LN backward inputs)
         ws["s2"] = [z(M, H, dt=sdt) for _ in range(L)]
         ws["sta"] = [z(M, 2, dt=F32) for _ in range(L)]
@@ -996,8 +1003,9 @@ class BertEngine(EncoderEngineBase):
                              b_aug=lay.baug)
             else:
                 ops.gemm(ws["yb"][l], lay.waug, ws["qkv"][l], EPI_BF16, bias=lay.b_qkv)
-            ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], key_bias=key_bias,
-                         dropout=self._drop(ws, self.p_attn, l, 1))
+            drop_p = self._drop(ws, self.p_attn, l, 1)
+            ops.attn_fwd(ws["qkv"][l], B, S, self.heads, scale, ws["ctx"][l], ws["lse"][l], key_bias=key_bias, dropout=drop_p,
+                         keep_bits=ws["kbits"][l] if drop_p is not None and ws["kbits"] is not None else None)
             ops.gemm(ws["ctx"][l], lay.w_o, ws["s1"][l], EPI_R, bias=lay.b_o, resid=ws["yb"][l] if rb else ws["y"],
                      dropout=self._drop(ws, self.p_hidden, l, 2))
             if f8:
@@ -1076,8 +1084,10 @@ class BertEngine(EncoderEngineBase):
             ops.layernorm_bwd(ws["s1"][l], ws["sta"][l], lay.ln_a[0], 1, g_resid=ws["dsb"] if one_b else ws["ds"], g_gemm=ws["dh"],
                               dx_f32=None if one_a else ws["ds1"], dx_bf16=ws["dsb"], dropout=drop_a)
             ops.gemm(ws["dsb"], lay.w_o_t, ws["dctx"], EPI_BF16)
+            drop_p = self._drop(ws, self.p_attn, l, 1)
             ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
-                         key_bias=ws["key_bias"], dropout=self._drop(ws, self.p_attn, l, 1))
+                         key_bias=ws["key_bias"], dropout=drop_p,
+                         keep_bits=ws["kbits"][l] if drop_p is not None and ws["kbits"] is not None else None)
             lb = self.lora_b(l)
             if lb is not None:
                 gbb = self.lora_b(l, grad=True)

@@ -305,8 +305,9 @@ class BertEngineFT(_FTMixin, BertEngine):
                               dx_bf16=ws["dsb"], dropout=self._drop(ws, self.p_hidden, l, 2))
             self._dw(ws["dsb"], ws["ctx"][l], M, H, H, f"{l}.o.w", f"{l}.o.b")
             ops.gemm(ws["dsb"], lay.w_o_t, ws["dctx"], EPI_BF16)
+            drop_p = self._drop(ws, self.p_attn, l, 1)   # the forward (BertEngine.forward) left its keep decisions in ws["kbits"]
             ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"], key_bias=ws["key_bias"],
-                         dropout=self._drop(ws, self.p_attn, l, 1))
+                         dropout=drop_p, keep_bits=ws["kbits"][l] if drop_p is not None and ws["kbits"] is not None else None)
             self._dw(ws["dqkv"], ws["yb"][l], M, 3 * H, H, f"{l}.q.w", f"{l}.q.b", w_n=3 * H * H)
             lb = self.lora_b(l)
             if lb is not None:

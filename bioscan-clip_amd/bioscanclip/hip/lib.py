@@ -54,8 +54,8 @@ SIGNATURES = {
     "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_fwd_fp8": (I, [P, I, I, I, I, P, P, F, P, I, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, F, U, I, P]),
-    "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, F, U, P]),
-    "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, F, U, P]),
+    "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, P, F, U, P]),
+    "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, P, F, U, P]),
     "bsclip_split3_rows": (I, [P, I, I, I, P, I, P]),
     "bsclip_split3_weight": (I, [P, I, I, I, P, P, I, P, I, P]),
     "bsclip_gelu_split3": (I, [P, I, I, I, P, I, P, I, P, I, P]),

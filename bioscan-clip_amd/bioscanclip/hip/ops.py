@@ -244,8 +244,19 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
                                          | (8 if dx_bf16 is not None and dx_bf16.dtype == F32 else 0), _stream()))
 
 
-def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, q_rows=0):
+KEEP_WORDS = 16   # csrc/attn_common.h: 32-bit dropout keep words per (batch, head, query) row (2 lane halves x 8)
+
+
+def _keep_bits_ok(keep_bits, B, S, heads, who):
+    if keep_bits is not None:
+        _req(keep_bits.dtype == torch.int32 and keep_bits.is_contiguous() and keep_bits.is_cuda
+             and keep_bits.numel() >= B * heads * S * KEEP_WORDS, f"{who}: keep_bits int32 [B * heads, S, 2, {KEEP_WORDS // 2}]")
+
+
+def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, q_rows=0, keep_bits=None):
+    """``keep_bits`` (int32 [B * heads, S, 2, 8], with dropout only): the forward leaves its keep decisions there for ``attn_bwd``."""
     ld_qkv, ld_ctx = _rowmajor(qkv, "qkv"), _rowmajor(ctx, "ctx")
+    _keep_bits_ok(keep_bits, B, S, heads, "attn_fwd")
     _req(qkv.dtype == BF16 and ctx.dtype == BF16 and lse.dtype == F32, "attn_fwd dtypes")
     _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64, "attn_fwd: qkv too small")
     _req(ctx.shape[0] >= B * S and ctx.shape[1] >= heads * 64 and lse.numel() >= B * heads * S, "attn_fwd: outputs too small")
@@ -253,11 +264,13 @@ def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, q_r
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_attn_fwd(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), ld_ctx, _p(lse),
-                                    int(q_rows), dp, ds, _stream()))
+                                    int(q_rows), _p(keep_bits), dp, ds, _stream()))
 
 
-def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None, q_rows=0):
+def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None, q_rows=0, keep_bits=None):
+    """``keep_bits``: the words the forward of the SAME (seed, step) left; None = re-hash the decisions (same masks, slower)."""
     ld_qkv, ld_ctx, ld_d = _rowmajor(qkv, "qkv"), _rowmajor(dctx, "dctx"), _rowmajor(dqkv, "dqkv")
+    _keep_bits_ok(keep_bits, B, S, heads, "attn_bwd")
     _req(all(t.dtype == BF16 for t in (qkv, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
     _req(min(qkv.shape[0], dctx.shape[0], dqkv.shape[0]) >= B * S, "attn_bwd: rows")
     _req(qkv.shape[1] >= 3 * heads * 64 and dqkv.shape[1] >= 3 * heads * 64 and dctx.shape[1] >= heads * 64
@@ -266,7 +279,7 @@ def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=No
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_attn_bwd(_p(qkv), ld_qkv, _p(dctx), ld_ctx, _p(lse), B, S, heads, _p(key_bias),
-                                    float(scale), _p(dqkv), ld_d, int(q_rows), dp, ds, _stream()))
+                                    float(scale), _p(dqkv), ld_d, int(q_rows), _p(keep_bits), dp, ds, _stream()))
 
 
 def split3_rows(src, dst, M=None, K=None):

@@ -24,12 +24,16 @@ namespace {
 //   Z' = sum over kept keys of pd_k / keep_scale + sum over dropped keys of e_k,  pd_k = bf16(e_k * keep_k) -- the operand the
 //   P.V product really used -- so that sum_k dS_k = 0 holds to f32 rounding for dS_k = inv pd_k (dP_k - delta / keep_scale),
 //   delta = (dO . O) rZ;  and O itself to 16 mantissa bits: ctx = bf16(O), ctx_lo = bf16(O - ctx).
-template <int NB, bool DROP, int TAIL = 32, bool V2 = false>
+// KB (DROP only): the forward leaves its keep decisions as bit words (attn_common.h KEEP_WORDS) for the backward.  A template parameter,
+// not a test of the pointer: behind a run-time branch the compiler sinks the whole bit computation into the branch and keeps all 80
+// factors (or compare masks) of a query block alive until then (+46 VGPRs at S = 133, spills at S = 197).
+template <int NB, bool DROP, int TAIL = 32, bool V2 = false, bool KB = false>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, int S,
                                                                    int heads, const float* __restrict__ key_bias,
                                                                    float scale, bf16_t* __restrict__ ctx, int ld_ctx,
                                                                    float* __restrict__ lse, DropCfg drop, int nqb,
-                                                                   bf16_t* __restrict__ ctx_lo = nullptr) {
+                                                                   bf16_t* __restrict__ ctx_lo = nullptr,
+                                                                   unsigned* __restrict__ kbits = nullptr) {
     constexpr int SP = NB * 32;
     BSCLIP_DROP_RESOLVE(drop);
     __shared__ __attribute__((aligned(16))) char smem[2 * SP * ROWB + SP * 4];
@@ -107,18 +111,44 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
         float sumx = 0.f, zacc = 0.f;   // V2: sum of e_k * keep_k before rounding, sum of the rounded operand pd_k
         if constexpr (DROP) {  // HF: dropout on the normalised probabilities (the row sum above is taken before it)
             const unsigned base = ((unsigned)(b * heads + hd) * S + (unsigned)qrow) * SP + 4 * h;
+            if constexpr (KB) {
+                // Bits first, factors from the bits: the compiler sinks the p *= keep multiplies into the P.V loop below, and with the
+                // factors taken from the hashes it kept all 80 of a query block alive until then (+50 VGPRs at S = 133, spills at
+                // S = 197); a factor re-derived from its bit (v_bfe_i32 + v_and) needs only the row's NB words.
+                unsigned kw[KEEP_WORDS];   // this lane half's bits of the row's keep words: bit 8 g + i = key 32 kt + 8 g + 4 h + i
 #pragma unroll
-            for (int kt = 0; kt < NB; ++kt)
+                for (int kt = 0; kt < KEEP_WORDS; ++kt) kw[kt] = 0u;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (g >= (kt == NB - 1 ? tail_groups<TAIL>() : 4)) continue;
-                    const f32x4 k4 = keep4(drop, base + 32 * kt + 8 * g);
+                for (int kt = 0; kt < NB; ++kt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        p[kt][4 * g + i] *= k4[i];
-                        if constexpr (V2) sumx += p[kt][4 * g + i];
-                    }
+                    for (int g = 0; g < (kt == NB - 1 ? tail_groups<TAIL>() : 4); ++g)
+                        kw[kt] |= keep4_nibble(drop, base + 32 * kt + 8 * g) << (8 * g);
+                if (q0 + (lane & 31) < S) {   // each lane half stores ITS bits (no exchange): [row][half][KEEP_WORDS]
+                    unsigned* kr = kbits + (((size_t)(b * heads + hd) * S + q0 + (lane & 31)) * 2 + h) * KEEP_WORDS;
+                    *reinterpret_cast<u32x4*>(kr) = u32x4{kw[0], kw[1], kw[2], kw[3]};
+                    if constexpr (NB > 4) *reinterpret_cast<u32x4*>(kr + 4) = u32x4{kw[4], kw[5], kw[6], kw[7]};
                 }
+#pragma unroll
+                for (int kt = 0; kt < NB; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4 * (kt == NB - 1 ? tail_groups<TAIL>() : 4); ++r) {
+                        p[kt][r] *= keep_of_bit(kw[kt], 8 * (r >> 2) + (r & 3), drop.scale);
+                        if constexpr (V2) sumx += p[kt][r];
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < NB; ++kt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (g >= (kt == NB - 1 ? tail_groups<TAIL>() : 4)) continue;
+                        const f32x4 k4 = keep4(drop, base + 32 * kt + 8 * g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            p[kt][4 * g + i] *= k4[i];
+                            if constexpr (V2) sumx += p[kt][4 * g + i];
+                        }
+                    }
+            }
         }
 
         // O^T[d, query] = sum_key V^T[d, key] P^T[key, query]
@@ -156,13 +186,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
     }
 }
 
-template <int NB, bool DROP, bool DIAG = false, int TAIL = 32>
+// BITS (DROP only): the dropout decisions come from the keep-bit words the forward left (attn_common.h KEEP_WORDS) instead of being
+// re-hashed per element pair (query-owner phase) / per element (key-owner phase).  PRE (no dropout): the key-owner phase starts the
+// dP accumulator from -delta ("row constants as the initial accumulator", cdna_hip_programming.md, attention backward): dS = P dP'.
+template <int NB, bool DROP, bool DIAG = false, int TAIL = 32, bool BITS = false, bool PRE = false>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
                                                                    const bf16_t* __restrict__ dctx, int ld_ctx,
                                                                    const float* __restrict__ lse, int S, int heads,
                                                                    const float* __restrict__ key_bias, float scale,
                                                                    bf16_t* __restrict__ dqkv, int ld_d, DropCfg drop,
-                                                                   int nqb, unsigned long long* diag = nullptr) {
+                                                                   int nqb, unsigned long long* diag = nullptr,
+                                                                   const unsigned* __restrict__ kbits = nullptr) {
+    static_assert(!(BITS && !DROP) && !(PRE && DROP), "BITS needs dropout, PRE excludes it");
     constexpr int SP = NB * 32;
     constexpr int RM = SP * ROWB;
     BSCLIP_DROP_RESOLVE(drop);
@@ -172,12 +207,13 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         }
     };
     stamp(0);
-    __shared__ __attribute__((aligned(16))) char smem[2 * RM + 3 * SP * 4];
+    __shared__ __attribute__((aligned(16))) char smem[2 * RM + 3 * SP * 4 + (BITS ? NB * SP * 4 : 0)];
     char* sR0 = smem;       // phase 1: K | phase 2: Q
     char* sR1 = smem + RM;  // phase 1: V | phase 2: dO
     float* sLse = reinterpret_cast<float*>(smem + 2 * RM);
     float* sDelta = sLse + SP;
     float* sBias = sDelta + SP;
+    [[maybe_unused]] unsigned* sKb = reinterpret_cast<unsigned*>(sBias + SP);   // BITS, phase 2: keep words [key tile][query]
 
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -226,6 +262,23 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         }
         const float nlse_q = -sLse[q0 + (lane & 31)];
         const unsigned dbase = (bh * S + (unsigned)qrow) * SP + 4 * h;  // dropout index of (q, key 4h)
+        [[maybe_unused]] unsigned kwq[NB];   // BITS: the query row's keep words of this lane half: bit 8 g + i is key 32 kt + 8 g + 4 h + i
+        if constexpr (BITS) {   // this lane half's own words, as the forward's lane half (same query, same h) stored them
+            const unsigned* kr = kbits + (((size_t)bh * S + qrow) * 2 + h) * KEEP_WORDS;
+            const u32x4 wa = *reinterpret_cast<const u32x4*>(kr);
+            u32x4 wb = {0u, 0u, 0u, 0u};
+            if constexpr (NB > 4) wb = *reinterpret_cast<const u32x4*>(kr + 4);
+#pragma unroll
+            for (int kt = 0; kt < NB; ++kt) kwq[kt] = kt < 4 ? wa[kt & 3] : wb[kt & 3];
+        }
+        auto keep_q = [&](int kt, int g) -> f32x4 {   // keep factors of keys 32 kt + 8 g + 4 h + (0..3) of this lane's query row
+            if constexpr (BITS) {
+                return f32x4{keep_of_bit(kwq[kt], 8 * g + 0, drop.scale), keep_of_bit(kwq[kt], 8 * g + 1, drop.scale),
+                             keep_of_bit(kwq[kt], 8 * g + 2, drop.scale), keep_of_bit(kwq[kt], 8 * g + 3, drop.scale)};
+            } else {
+                return keep4(drop, dbase + 32 * kt + 8 * g);
+            }
+        };
         // pass 1: delta_q = sum_key P[q,key] dP[q,key], from the SAME P and dP the gradient uses, so that
         // sum_key dS[q,key] = 0 holds to f32 rounding (delta from the bf16-rounded O does not: it loses the cancellation
         // whenever the values of a head are nearly equal across keys).  Round 3: P is formed ONCE -- pass 1 keeps it as packed
@@ -258,7 +311,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                     continue;
                 }
                 f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
-                if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
+                if constexpr (DROP) k4 = keep_q(kt, g);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, nlse_q));
@@ -271,7 +324,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             p16[kt][1] = pack8(s, 1);
         }
         const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
-        if (h == 0) sDelta[q0 + (lane & 31)] = delta_q;
+        if (h == 0) sDelta[q0 + (lane & 31)] = PRE ? -delta_q : delta_q;
         if (blk == wave) stamp(6);
         // pass 2: dS^T = P^T (dP^T - delta);  dQ^T += K^T dS^T, scaled once at the end
         f32x16 dq[2] = {zero16(), zero16()};
@@ -295,7 +348,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                         continue;
                     }
                     f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
-                    if constexpr (DROP) k4 = keep4(drop, dbase + 32 * kt + 8 * g);
+                    if constexpr (DROP) k4 = keep_q(kt, g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const unsigned w = pu[2 * g2 + (i >> 1)];
@@ -324,6 +377,13 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
     // ---------------- phase 2 staging: Q, dO row-major ----------------
     stage_tile<SP>(qb, ld, S, sR0, wave, lane);
     stage_tile<SP>(dob, ld_ctx, S, sR1, wave, lane);
+    if constexpr (BITS) {   // the item's keep words, transposed to [key tile][query]: a lane's 4 consecutive query rows are one 16-byte read
+        for (int i = tid; i < S * NB; i += ATT_WAVES * 64) {   // bit j of the staged word = key 32 kt + j: half 1's nibbles sit 4 keys up
+            const int q = i / NB, kt = i - q * NB;
+            const unsigned* kr = kbits + ((size_t)bh * S + q) * 2 * KEEP_WORDS + kt;
+            sKb[kt * SP + q] = kr[0] | (kr[KEEP_WORDS] << 4);
+        }
+    }
     stage_wait();
     __syncthreads();
     stamp(4);
@@ -351,6 +411,14 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             constexpr bool TAILED = decltype(tailed)::value;
             constexpr int ng = TAILED ? tail_groups<TAIL>() : 4, ns2 = TAILED ? tail_ksteps<TAIL>() : 2;
             f32x16 s = bk16, dp = zero16();
+            if constexpr (PRE) {   // dP' = dP - delta: the row constant is the accumulator's start value (sDelta holds -delta)
+#pragma unroll
+                for (int g = 0; g < ng; ++g) {
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + 32 * qt + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dp[4 * g + i] = d4[i];
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 s = mfma32(frag_rm(sR0, 32 * qt, ks, lane), kf[ks], s);    // S[q, key] + bias / scale
@@ -364,15 +432,26 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                     continue;
                 }
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * g + 4 * h);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + 32 * qt + 8 * g + 4 * h);
+                [[maybe_unused]] f32x4 d4;
+                if constexpr (!PRE) d4 = *reinterpret_cast<const f32x4*>(sDelta + 32 * qt + 8 * g + 4 * h);
+                [[maybe_unused]] u32x4 w4;
+                if constexpr (BITS) w4 = *reinterpret_cast<const u32x4*>(sKb + blk * SP + 32 * qt + 8 * g + 4 * h);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + i], scale2, -l4[i]));
                     if constexpr (DROP) {
-                        const int q = min(32 * qt + 8 * g + 4 * h + i, S - 1);
-                        const float keep = drop_factor(drop, (bh * S + (unsigned)q) * SP + (unsigned)krow);
+                        float keep;
+                        if constexpr (BITS) {
+                            keep = keep_of_bit(w4[i], (unsigned)(lane & 31), drop.scale);   // bit (key in tile) of (query, key tile blk)
+                        } else {
+                            const int q = min(32 * qt + 8 * g + 4 * h + i, S - 1);
+                            keep = drop_factor(drop, (bh * S + (unsigned)q) * SP + (unsigned)krow);
+                        }
                         s[4 * g + i] = pr * keep;                               // dropped P (feeds dV)
                         dp[4 * g + i] = pr * (dp[4 * g + i] * keep - d4[i]);    // dS (scale applied to dK at the end)
+                    } else if constexpr (PRE) {
+                        s[4 * g + i] = pr;
+                        dp[4 * g + i] = pr * dp[4 * g + i];
                     } else {
                         s[4 * g + i] = pr;
                         dp[4 * g + i] = pr * (dp[4 * g + i] - d4[i]);
@@ -404,20 +483,26 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
 
 }  // namespace
 
-#define ATTN_FWD_LAUNCH(NBV, DR, TL)                                                                            \
-    hipLaunchKernelGGL((attn_fwd_kernel<NBV, DR, TL>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,             \
+#define ATTN_FWD_LAUNCH(NBV, DR, TL, KBV)                                                                       \
+    hipLaunchKernelGGL((attn_fwd_kernel<NBV, DR, TL, false, KBV>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s, \
                        static_cast<const bf16_t*>(qkv), ld_qkv, S, heads, key_bias, scale, static_cast<bf16_t*>(ctx), ld_ctx, \
-                       lse, drop, nqb)
+                       lse, drop, nqb, static_cast<bf16_t*>(nullptr), static_cast<unsigned*>(keep_bits))
+#define ATTN_FWD_PICK(NBV, TL)                                                                                  \
+    do {                                                                                                        \
+        if (drop.thr16 && keep_bits) ATTN_FWD_LAUNCH(NBV, true, TL, true);                                      \
+        else if (drop.thr16) ATTN_FWD_LAUNCH(NBV, true, TL, false);                                             \
+        else ATTN_FWD_LAUNCH(NBV, false, TL, false);                                                            \
+    } while (0)
 #define ATTN_FWD_CASE(NBV)                                                                                      \
     case NBV:                                                                                                   \
-        if (drop.thr16) ATTN_FWD_LAUNCH(NBV, true, 32);                                                         \
-        else ATTN_FWD_LAUNCH(NBV, false, 32);                                                                   \
+        ATTN_FWD_PICK(NBV, 32);                                                                                 \
         break;
 
 extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias,
-                               float scale, void* ctx, int ld_ctx, float* lse, int q_rows, float dropout_p,
+                               float scale, void* ctx, int ld_ctx, float* lse, int q_rows, void* keep_bits, float dropout_p,
                                uint32_t dropout_seed, void* stream) {
     BSCLIP_REQUIRE(qkv && ctx && lse, "bsclip_attn_fwd: null pointer");
+    BSCLIP_REQUIRE((reinterpret_cast<uintptr_t>(keep_bits) & 15) == 0, "bsclip_attn_fwd: keep_bits must be 16-byte aligned");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_fwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_ctx >= heads * 64 && ld_ctx % 4 == 0,
                    "bsclip_attn_fwd: ld_qkv=%d ld_ctx=%d", ld_qkv, ld_ctx);
@@ -428,11 +513,9 @@ extern "C" int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int he
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the production sequence lengths get the instantiation that knows their last tile holds 5 rows (see tail_groups)
     if (S == 197) {
-        if (drop.thr16) ATTN_FWD_LAUNCH(7, true, 5);
-        else ATTN_FWD_LAUNCH(7, false, 5);
+        ATTN_FWD_PICK(7, 5);
     } else if (S == 133) {
-        if (drop.thr16) ATTN_FWD_LAUNCH(5, true, 5);
-        else ATTN_FWD_LAUNCH(5, false, 5);
+        ATTN_FWD_PICK(5, 5);
     } else {
         switch ((S + 31) / 32) {
             ATTN_FWD_CASE(1) ATTN_FWD_CASE(2) ATTN_FWD_CASE(3) ATTN_FWD_CASE(4) ATTN_FWD_CASE(5) ATTN_FWD_CASE(6)
@@ -486,20 +569,31 @@ extern "C" int bsclip_attn_fwd2(const void* qkv, int ld_qkv, int B, int S, int h
 }
 #endif  // BSCLIP_DIAG
 
-#define ATTN_BWD_LAUNCH(NBV, DR, TL)                                                                             \
-    hipLaunchKernelGGL((attn_bwd_kernel<NBV, DR, false, TL>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s,       \
+#define ATTN_BWD_LAUNCH(NBV, DR, TL, BT, PR)                                                                     \
+    hipLaunchKernelGGL((attn_bwd_kernel<NBV, DR, false, TL, BT, PR>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s, \
                        static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, lse, S, heads, \
-                       key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, nqb)
+                       key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, nqb, static_cast<unsigned long long*>(nullptr), \
+                       static_cast<const unsigned*>(keep_bits))
+// dropout: from the forward's keep words when the caller has them, re-hashed otherwise; no dropout: delta preloaded (PRE)
+#define ATTN_BWD_PICK(NBV, TL)                                                                                   \
+    do {                                                                                                         \
+        if (drop.thr16 && keep_bits) ATTN_BWD_LAUNCH(NBV, true, TL, true, false);                                \
+        else if (drop.thr16) ATTN_BWD_LAUNCH(NBV, true, TL, false, false);                                       \
+        else if (g_attn_preload) ATTN_BWD_LAUNCH(NBV, false, TL, false, true);                                   \
+        else ATTN_BWD_LAUNCH(NBV, false, TL, false, false);                                                      \
+    } while (0)
 #define ATTN_BWD_CASE(NBV)                                                                                       \
     case NBV:                                                                                                    \
-        if (drop.thr16) ATTN_BWD_LAUNCH(NBV, true, 32);                                                          \
-        else ATTN_BWD_LAUNCH(NBV, false, 32);                                                                    \
+        ATTN_BWD_PICK(NBV, 32);                                                                                  \
         break;
+// A/B switch of the round-5 "row constant as the initial accumulator" form of the no-dropout key-owner phase (default on)
+static const bool g_attn_preload = !(getenv("BSCLIP_ATTN_PRELOAD") && atoi(getenv("BSCLIP_ATTN_PRELOAD")) == 0);
 
 extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
                                int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
-                               float dropout_p, uint32_t dropout_seed, void* stream) {
+                               const void* keep_bits, float dropout_p, uint32_t dropout_seed, void* stream) {
     BSCLIP_REQUIRE(qkv && dctx && lse && dqkv, "bsclip_attn_bwd: null pointer");
+    BSCLIP_REQUIRE((reinterpret_cast<uintptr_t>(keep_bits) & 15) == 0, "bsclip_attn_bwd: keep_bits must be 16-byte aligned");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_bwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 8 == 0 && ld_dqkv >= 3 * heads * 64 && ld_dqkv % 4 == 0 &&
                        ld_ctx >= heads * 64 && ld_ctx % 8 == 0,
@@ -511,8 +605,7 @@ extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     // S = 133 gains 5 % from the trimmed last tile; at S = 197 the trimmed instantiation schedules worse (268.6 vs 265.0 us)
     if (S == 133) {
-        if (drop.thr16) ATTN_BWD_LAUNCH(5, true, 5);
-        else ATTN_BWD_LAUNCH(5, false, 5);
+        ATTN_BWD_PICK(5, 5);
     } else {
         switch ((S + 31) / 32) {
             ATTN_BWD_CASE(1) ATTN_BWD_CASE(2) ATTN_BWD_CASE(3) ATTN_BWD_CASE(4) ATTN_BWD_CASE(5) ATTN_BWD_CASE(6)

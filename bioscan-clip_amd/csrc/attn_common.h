@@ -144,6 +144,23 @@ __device__ __forceinline__ f32x4 keep4(const DropCfg& d, unsigned idx) {
     k[3] = (b1 >> 16) >= d.thr16 ? d.scale : 0.f;
     return k;
 }
+// the four keep decisions of keys idx .. idx+3 as a nibble (bit i = key idx + i kept): what the forward leaves in the keep-bit words
+__device__ __forceinline__ unsigned keep4_nibble(const DropCfg& d, unsigned idx) {
+    const unsigned b0 = drop_pair_bits(d, idx), b1 = drop_pair_bits(d, idx + 2);
+    return ((b0 & 0xffffU) >= d.thr16 ? 1u : 0u) | ((b0 >> 16) >= d.thr16 ? 2u : 0u) | ((b1 & 0xffffU) >= d.thr16 ? 4u : 0u) |
+           ((b1 >> 16) >= d.thr16 ? 8u : 0u);
+}
+// Keep-bit words (round 5): the forward leaves, per (batch, head) item and query row, 2 x KEEP_WORDS 32-bit words -- one set per lane
+// half h of the wave that owned the row (no cross-lane exchange): bit 8 g + i of word kt of half h = "key 32 kt + 8 g + 4 h + i of this
+// query row was kept", i.e. exactly the keys that lane half holds in the score accumulators -- so that the backward reads the decisions
+// instead of re-hashing every element (its key-owner phase hashed once per ELEMENT: 67 of 218 us at S = 133,
+// profiles/r04_b_attn_bench.log).  The query-owner phase reads its own half's words; the key-owner phase stages W0 | (W1 << 4)
+// (bit j = key 32 kt + j).  Same decisions, same arithmetic: the gradients are bit for bit those of the hashing form.
+constexpr int KEEP_WORDS = 8;   // words per lane half (S <= 224 needs 7; 8 keeps 16-byte stores aligned): 64 B per query row
+// keep factor (0 or scale) of bit `pos` of a keep word: one v_bfe_i32 (0 / -1) + one v_and
+__device__ __forceinline__ float keep_of_bit(unsigned w, unsigned pos, float scale) {
+    return __int_as_float(__builtin_amdgcn_sbfe((int)w, pos, 1u) & __float_as_int(scale));
+}
 // Dropout element index of P[q, key] for head-instance bh: ((bh * S + q) * SP + key), SP = padded length (multiple of
 // 32), so a lane's 4 consecutive keys share two hash pairs.
 

@@ -215,11 +215,17 @@ int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats
  * fwd writes ctx/lse for those rows only, bwd takes dctx as zero on the others and writes zeros into their dq rows (the last
  * ViT block, whose output is read at token 0 only: image_encoder.py:108-109 -> timm global_pool='token').
  * S <= 224.  bwd recomputes P from qkv + lse, forms delta = rowsum(P . dP) in f32 from the same tiles (not from the
- * bf16-rounded ctx: that loses the softmax-backward cancellation), and writes dqkv in the same layout as qkv. */
+ * bf16-rounded ctx: that loses the softmax-backward cancellation), and writes dqkv in the same layout as qkv.
+ * keep_bits (ABI 9, nullable; read / written only when dropout_p > 0): uint32 [B * heads, S, 2, 8], 16-byte aligned -- bit 8 g + i of word
+ * kt of half h of row (b, head, q) = "key 32 kt + 8 g + 4 h + i of that query row was kept" (the key set one lane half of the kernels holds;
+ * words kt >= ceil(S / 32) are unused).  The forward writes the words from the decisions it hashes; a
+ * backward that is handed them reads the decisions instead of re-hashing (the same masks, hence the same gradients bit for bit;
+ * the key-owner phase hashed once per element: a quarter of the S = 133 launch).  Without them the backward re-hashes, as before. */
 int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale,
-                    void* ctx, int ld_ctx, float* lse, int q_rows, float dropout_p, uint32_t dropout_seed, void* stream);
+                    void* ctx, int ld_ctx, float* lse, int q_rows, void* keep_bits, float dropout_p, uint32_t dropout_seed,
+                    void* stream);
 int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
-                    int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
+                    int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows, const void* keep_bits,
                     float dropout_p, uint32_t dropout_seed, void* stream);
 
 /* ---- "exact" forward mode (BSCLIP_PARITY=2; csrc/exact.hip): every trunk GEMM on split-bf16 operands, f32 attention -----------

@@ -165,6 +165,52 @@ def test_attention_dropout_fwd_bwd(ops, B, S, heads, masked):
         assert rel_err(dqkv[:, sl].float(), gq[:, sl]) < 3e-2, name
 
 
+@pytest.mark.parametrize("B,S,heads,masked", [(2, 64, 2, False), (3, 20, 8, True), (2, 133, 12, False), (2, 197, 3, False),
+                                              (1, 224, 2, True), (3, 1, 2, False), (30, 133, 12, False)])
+def test_attention_keep_bits_reproduce_the_hashed_masks(ops, B, S, heads, masked):
+    """Round 5: the forward leaves its dropout decisions as bit words (64 B per query row) and the backward reads them instead of
+    re-hashing every element.  Same decisions, same arithmetic: the forward output does not change, the gradients are bit for bit
+    those of the re-hashing backward, and the words themselves spell the mask the test above extracts through V = I."""
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, seed=1).bfloat16()
+    dctx = rnd(B * S, H, seed=2).bfloat16()
+    bias = None
+    if masked:
+        lens = torch.randint(2, S + 1, (B,), generator=torch.Generator().manual_seed(3))
+        bias = ((1.0 - (torch.arange(S)[None] < lens[:, None]).float()) * torch.finfo(torch.float32).min).cuda()
+    seed = 4242
+    ctx0, ctx1 = (torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    lse0, lse1 = (torch.empty(B, heads, S, device="cuda") for _ in range(2))
+    bits = torch.full((B * heads * S * ops.KEEP_WORDS,), -1, device="cuda", dtype=torch.int32)
+    ops.attn_fwd(qkv, B, S, heads, 0.125, ctx0, lse0, key_bias=bias, dropout=(P, seed))
+    ops.attn_fwd(qkv, B, S, heads, 0.125, ctx1, lse1, key_bias=bias, dropout=(P, seed), keep_bits=bits)
+    assert torch.equal(ctx0, ctx1) and torch.equal(lse0, lse1)
+    g0 = torch.full((B * S, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
+    g1 = torch.full_like(g0, float("nan"))
+    ops.attn_bwd(qkv, dctx, lse0, B, S, heads, 0.125, g0, key_bias=bias, dropout=(P, seed))
+    ops.attn_bwd(qkv, dctx, lse0, B, S, heads, 0.125, g1, key_bias=bias, dropout=(P, seed), keep_bits=bits)
+    assert torch.equal(g0, g1)
+    # the words: bit 8 g + i of word kt of lane half h = key 32 kt + 8 g + 4 h + i; about 1 - p of the valid keys are kept
+    w = bits.view(B * heads, S, 2, ops.KEEP_WORDS // 2).cpu().to(torch.int64) & 0xFFFFFFFF
+    nb = (S + 31) // 32
+    keep = torch.zeros(B * heads, S, nb * 32, dtype=torch.bool)
+    for h in range(2):
+        for kt in range(nb):
+            for g in range(4):
+                for i in range(4):
+                    keep[:, :, 32 * kt + 8 * g + 4 * h + i] = ((w[:, :, h, kt] >> (8 * g + i)) & 1).bool()
+    frac = keep[:, :, :S].float().mean().item()
+    assert abs(frac - (1 - P)) < (0.05 if B * heads * S * S < 4000 else 0.01), frac
+    # ... and a different seed gives different words, the same seed the same words
+    bits2, bits3 = torch.zeros_like(bits), torch.zeros_like(bits)
+    ops.attn_fwd(qkv, B, S, heads, 0.125, ctx1, lse1, key_bias=bias, dropout=(P, seed), keep_bits=bits2)
+    ops.attn_fwd(qkv, B, S, heads, 0.125, ctx1, lse1, key_bias=bias, dropout=(P, seed + 1), keep_bits=bits3)
+    valid = torch.ones(B * heads, S, 2, ops.KEEP_WORDS // 2, dtype=torch.bool)
+    valid[:, :, :, nb:] = False
+    v = valid.view(-1).cuda()
+    assert torch.equal(bits2[v], bits[v]) and (S == 1 or not torch.equal(bits3[v], bits[v]))
+
+
 def test_engine_train_vs_eval_mode():
     """train mode: stochastic (a new mask per forward) with an unbiased mean; eval mode: deterministic and identical
     to the p = 0 configuration."""
