@@ -12,8 +12,10 @@ carries that configuration (and configs[4]'s fp8 shape) as `extra`, measured in 
 One "step" = zero_grad + forward + loss + backward + (all-reduce) + optimizer step; nothing is skipped or cached.
 
 One JSON line is printed by rank 0 (contract in the task statement).  Besides the required keys:
-  roofline      -- the LOWEST-fraction GEMM family of the step (fc1 + bias + GELU, 24 launches per step) timed live with HIP
-                   events on the launch stream, in the same launch mix as the step.
+  roofline      -- the DOMINANT kernel family of the step by time: the bias-free dX GEMMs (dfc1, dproj, dqkv: 70 launches per step,
+                   gemm_nt_pers_kernel<EPI_BF16, no bias>), timed live with HIP events on the launch stream in the step's launch mix;
+                   `traffic` from the rocprofv3 --pmc passes of that mix (profiles/*.json, --pmc-traffic), never a constant.
+  roofline_lowest -- the LOWEST-fraction GEMM family (fc1 + bias + GELU, 24 launches per step), same method.
   roofline_families -- every kernel family that takes more than 2 % of the step (the GEMM families by epilogue, attention forward /
                    backward), each timed live in its own launch mix: TFLOP/s and fraction of the dense bf16 MFMA peak.
   step_roofline -- algorithmic FLOPs of the whole step (118.3 GFLOP per I+D pair) / measured step time
@@ -38,13 +40,10 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md chip table)
 GFLOP_PER_PAIR_ID = 118.3   # fwd 58.8 + LoRA-regime bwd
 GFLOP_PER_TRIPLE_IDT = 119.3
-# HBM-side bytes per launch of the dominant kernel: NOT measured by this run (PMC passes need rocprofv3 around the process).
-# Offline figure: (11 x 798.6 + 12 x 542.6 + 150.2) / 24 MB from the per-shape FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE
-# passes of profiles/r03_j_fc1_pmc.txt (tools/scripts/r03_pmc2.sh), taken after the persistent rewrite of the kernel
-# (766.1 MB before it: profiles/r03_b_fc1_pmc.txt).
-FC1_TRAFFIC_BYTES_B256 = 643.6e6
-FC1_TRAFFIC_SOURCE = ("offline rocprofv3 --pmc passes (profiles/r03_j_fc1_pmc.txt; re-run on the round-4 tree: profiles/r04_q_fc1_pmc.txt, "
-                      "tools/scripts/r04_gemm_pmc.sh -- same counters to 0.2 %), not collected by this run")
+# HBM-side bytes per launch (roofline.traffic) cannot be measured by this process (PMC passes need rocprofv3 around it): they are read
+# from the JSON that tools/scripts/r05_dx_pmc.sh writes from separate --pmc passes (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+# correction + WRITE_SIZE, KB -> bytes) over the SAME launch mix (tools/family_one.py), and labelled with the tree they were taken on.
+DEFAULT_PMC_TRAFFIC = {"dx": os.path.join(ROOT, "profiles", "r05_dx_pmc.json"), "fc1": os.path.join(ROOT, "profiles", "r05_fc1_pmc.json")}
 METRIC = "paired samples/sec/node (I+D+T, global batch) + step MFMA-roofline % at 1/2/4/8 GPU"   # BASELINE.json:metric, verbatim
 
 
@@ -99,26 +98,49 @@ def synthetic_batch(B, with_text, device, seed):
 VIT_LAST_BLOCK_SKIPPED_GFLOP = (2 * 196 * 768 * (768 + 2 * 3072) * 2 + 4 * 196 * 197 * 768 * 3.5) / 1e9
 
 
-def time_dominant_gemm(B, device, reps=4):
-    """The kernel with the largest share of the step: the fc1 + bias + exact GELU GEMM (writes gelu(z) and gelu'(z)) --
-    gemm_nt_pers_kernel<EPI_GELU_BF16, bias> (csrc/gemm_pers.h).  One step launches it 24 times: 11x ViT fc1 [B*197, 3072, 768] (the 12th ViT block's MLP
-    runs on the B token-0 rows only and goes to the small-grid kernel), 12x BarcodeBERT fc1 [B*133, 3072, 768] and once for
-    cls.predictions.transform [B*133, 768, 768].  The same mix is timed here with HIP
-    events on the launch stream, so the average duration is directly comparable with the kernel's row in the
-    rocprofv3 --stats summary of this command (profiles/)."""
+def family_shapes(B):
+    """(M, N, K, launches per step) of the two GEMM families the roofline objects describe, at local batch B (I+D step: ViT rows
+    B*197 -- its 12th block runs on the token-0 rows and goes to the small-grid kernel --, BarcodeBERT rows B*133)."""
+    Mv, Md = B * 197, B * 133
+    return {"dx": [(Mv, 768, 3072, 11), (Mv, 768, 768, 11), (Mv, 768, 2304, 11), (Md, 768, 3072, 12), (Md, 768, 768, 12), (Md, 768, 2304, 12)],
+            "fc1": [(Mv, 3072, 768, 11), (Md, 3072, 768, 12), (Md, 768, 768, 1)]}
+
+
+def _pmc_traffic(path, B):
+    """(bytes per launch, provenance) from a tools/scripts/r05_dx_pmc.sh JSON, or (None, why not)."""
+    try:
+        d = json.load(open(path))
+    except Exception as exc:   # noqa: BLE001
+        return None, f"no PMC file ({type(exc).__name__}: {path})"
+    if d.get("local_batch") != B:
+        return None, f"PMC passes were taken at local batch {d.get('local_batch')}, this run is at {B}"
+    kb = 2.0 * d["fetch_size_kb_sum"] + d["write_size_kb_sum"]     # FETCH_SIZE counts 64 B per 128-B request on gfx950: doubled
+    return kb * 1024.0 / d["launches"], (f"offline: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) and WRITE_SIZE passes over this launch mix, "
+                                         f"{os.path.relpath(path, ROOT)} (tree {d.get('tree', '?')}, {d.get('date', '?')}); not collected by this run")
+
+
+def time_gemm_family(which, B, device, pmc_path, reps=4):
+    """One GEMM family of the step, timed live with HIP events on the launch stream in the step's own launch mix, so that the average
+    duration is directly comparable with the kernel's row in the rocprofv3 --stats summary of this command (profiles/).
+    "dx": the bias-free dX GEMMs gemm_nt_pers_kernel<EPI_BF16, no bias> -- dfc1 [M, 768, 3072], dproj [M, 768, 768], dqkv [M, 768, 2304]
+    of 11 ViT blocks and 12 BarcodeBERT layers: the largest family by time (19 % of the step's kernel time).
+    "fc1": fc1 + bias + exact GELU (writes gelu(z) and 8-bit gelu'(z)) gemm_nt_pers_kernel<EPI_GELU_BF16, bias>: the lowest fraction."""
     from bioscanclip.hip import ops
-    from bioscanclip.hip.lib import EPI_GELU_BF16
-    shapes = [(B * 197, 3072, 768, 11), (B * 133, 3072, 768, 12), (B * 133, 768, 768, 1)]
+    from bioscanclip.hip.lib import EPI_BF16, EPI_GELU_BF16
+    shapes = family_shapes(B)[which]
+    epi = EPI_BF16 if which == "dx" else EPI_GELU_BF16
     bufs = []
     for M, N, K, _ in shapes:
+        kw = {}
+        if which == "fc1":
+            kw = {"bias": torch.randn(N, device=device), "aux": torch.empty(M, N, device=device, dtype=torch.uint8)}
         bufs.append((torch.randn(M, K, device=device).bfloat16(), (torch.randn(N, K, device=device) * 0.03).bfloat16(),
-                     torch.randn(N, device=device), torch.empty(M, N, device=device, dtype=torch.bfloat16),
-                     torch.empty(M, N, device=device, dtype=torch.uint8)))
+                     torch.empty(M, N, device=device, dtype=torch.bfloat16), kw))
 
     def mix():
-        for (M, N, K, cnt), (a, w, bias, out, z) in zip(shapes, bufs):
+        for (M, N, K, cnt), (a, w, out, kw) in zip(shapes, bufs):
             for _ in range(cnt):
-                ops.gemm(a, w, out, EPI_GELU_BF16, bias=bias, aux=z)
+                ops.gemm(a, w, out, epi, **kw)
 
     mix()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -131,19 +153,22 @@ def time_dominant_gemm(B, device, reps=4):
     mean_ms = e0.elapsed_time(e1) / (reps * launches)
     flops = sum(2.0 * M * N * K * c for M, N, K, c in shapes) / launches
     achieved = flops / (mean_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            # bytes per launch at the L2's memory side, FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, averaged over the
-            # same launch mix; collected offline with rocprofv3 --pmc (profiles/r03_j_fc1_pmc.txt), valid for B=256
-            "traffic": FC1_TRAFFIC_BYTES_B256 if B == 256 else None,
-            "traffic_note": FC1_TRAFFIC_SOURCE + "; algorithmic bytes per launch: "
-                            "%.1f MB (A + W bf16, gelu bf16, gelu' 8-bit)" % (sum(((M * K + N * K) * 2.0 + 3.0 * M * N) * c for M, N, K, c in shapes)
-                                                                             / launches / 1e6),
-            "kernel": "gemm_nt_pers_kernel<2 = EPI_GELU_BF16, true, false, true> (fc1 + bias + GELU; 24 launches per step)",
-            "kernel_role": "the LOWEST-fraction GEMM family of the step (its two-output GELU epilogue); the largest family by time is the "
-                           "bias-free dX GEMMs -- every family: roofline_families",
-            "launch_mix_MNK_count": [list(x) for x in shapes],
-            "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "avg_launch_ms": round(mean_ms, 4)}
+    traffic, source = _pmc_traffic(pmc_path, B)
+    out_bytes = 2.0 if which == "dx" else 3.0      # bf16 out; fc1: gelu bf16 + gelu' 8-bit
+    algo = sum(((M * K + N * K) * 2.0 + out_bytes * M * N) * c for M, N, K, c in shapes) / launches
+    res = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+           "traffic": None if traffic is None else round(traffic, 0), "traffic_source": source,
+           "algorithmic_bytes_per_launch": round(algo, 0),
+           "kernel": ("gemm_nt_pers_kernel<0 = EPI_BF16, false, false, true> (bias-free dX GEMMs: dfc1, dproj, dqkv; 70 launches per step)" if which == "dx"
+                      else "gemm_nt_pers_kernel<2 = EPI_GELU_BF16, true, false, true> (fc1 + bias + GELU; 24 launches per step)"),
+           "kernel_role": ("the dominant kernel family of the step by time" if which == "dx" else
+                           "the LOWEST-fraction GEMM family of the step (its two-output GELU epilogue)"),
+           "launch_mix_MNK_count": [list(x) for x in shapes],
+           "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "avg_launch_ms": round(mean_ms, 4)}
+    del bufs
+    torch.cuda.empty_cache()
+    return res
 
 
 def time_families(B, device, reps=3):
@@ -366,6 +391,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (configs[1] I+D at B=256, fp8 trunks at B=512) the "
                     "default single-GPU line carries as extra keys")
+    ap.add_argument("--pmc-traffic", default=None, help="JSON of the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the dominant kernel's "
+                    "launch mix (tools/scripts/r05_dx_pmc.sh); default profiles/r05_dx_pmc.json")
     a = ap.parse_args()
     a.text = not a.no_text
 
@@ -418,6 +445,8 @@ def main():
         # all-reduce issued eagerly from that tower's stream between them (hip/graph.py GraphedDistStep) -- a rank's host work
         # drops from ~35 ms to ~1 ms per step and the collectives run beside the other towers' kernels
         graphed = (GraphedDistStep if world > 1 or force_dist else GraphedStep)(model, opt, crit, warmup=2)
+        if world > 1 or force_dist:
+            graphed.profile_waits = True     # event pairs around the waits for the collectives (read after the timed region)
 
     def step():
         nonlocal graphed
@@ -479,6 +508,8 @@ def main():
     clk0, clk1 = torch.zeros(32, dtype=torch.int64, device=device), torch.zeros(32, dtype=torch.int64, device=device)
     _ops.clock_probe(clk0)
     fence()
+    if graphed is not None and hasattr(graphed, "wait_events"):
+        graphed.wait_events.clear()          # only the timed steps
     # The host stays at most two steps ahead of the device (as train_epoch does by reading the loss one step late): with an
     # unbounded run-ahead the K launches are enqueued in microseconds and the thread then sits in the runtime's queue back-pressure
     # -- a spin.  The throttle polls an event between sleeps: the GPU never idles (a step is always queued behind the running one).
@@ -505,7 +536,23 @@ def main():
     _ops.clock_probe(clk1)
     torch.cuda.synchronize()
     clock_ghz = _ops.engine_clock_ghz(clk0, clk1)
+    dist_info = None
     if world > 1 or force_dist:
+        # per-rank wall time of the K steps (the line's value uses the MAX, as the contract says) and what each rank's main stream
+        # spent waiting for collectives AFTER its own towers were done -- so that the first SCALE record explains itself
+        waits = graphed.collective_wait_ms() if graphed is not None and hasattr(graphed, "collective_wait_ms") else None
+        mine = torch.tensor([elapsed / a.steps * 1e3, -1.0 if waits is None else waits[0], -1.0 if waits is None else waits[1]],
+                            device=device, dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = torch.stack(allv).cpu()
+        dist_info = {"ranks": world, "ms_per_step_per_rank": [round(v, 3) for v in per_rank[:, 0].tolist()],
+                     "ms_per_step_min": round(per_rank[:, 0].min().item(), 3), "ms_per_step_max": round(per_rank[:, 0].max().item(), 3),
+                     "exposed_allgather_wait_ms_per_step": None if waits is None else round(per_rank[:, 1].max().item(), 4),
+                     "exposed_allreduce_wait_ms_per_step": None if waits is None else round(per_rank[:, 2].max().item(), 4),
+                     "note": "exposed wait = time a rank's main stream waited for the step's all-gathers (before the loss graph) / gradient "
+                             "all-reduces (before the optimizer graph) after its own tower graphs had finished: the collective time the "
+                             "overlap did not hide, max over ranks; a straggler rank shows as ms_per_step_min << max on the others' waits"}
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -544,6 +591,9 @@ def main():
                        "launch_path": ("eager (Python enqueue)" if graphed is None else
                                        "per-tower captured hipGraphs (forward_k | loss | backward_k | AdamW), each tower's all-gather / all-reduce issued from its stream between them"
                                        if world > 1 or force_dist else "hipGraph replay (one captured step)"),
+                       "collectives": ("none (one process, local-batch loss)" if not (world > 1 or force_dist) else
+                                       "C-ABI entry points (bsclip_allgather_* / bsclip_allreduce_grads): one RCCL communicator and stream per tower, event-ordered (BSCLIP_NATIVE_COMM=1)"
+                                       if getattr(graphed, "native", False) else "torch.distributed (ProcessGroupNCCL = RCCL), issued from the tower streams"),
                        "numerics": {0: "default: bf16 GEMM / attention operands, bf16 residual and residual-gradient streams",
                                     1: "BSCLIP_PARITY=1: f32 residual / residual-gradient streams (diagnostic run)",
                                     2: "BSCLIP_PARITY=2: exact mode -- split-bf16 operands on every GEMM, f32 attention (diagnostic run: "
@@ -569,7 +619,10 @@ def main():
                        "enqueue_wall_ms_per_step": round(t_enq / a.steps * 1e3, 3),
                        "note": "the enqueueing thread sleeps between hipEventQuery polls (at most two steps queued ahead); what is left is "
                                "the HIP / ROCr runtime's own helper threads"}
-        out["roofline"] = time_dominant_gemm(B, device)
+        if dist_info is not None:
+            out["dist"] = dist_info
+        out["roofline"] = time_gemm_family("dx", B, device, a.pmc_traffic or DEFAULT_PMC_TRAFFIC["dx"])
+        out["roofline_lowest"] = time_gemm_family("fc1", B, device, DEFAULT_PMC_TRAFFIC["fc1"])
         if world == 1 and not (a.fp8 or a.full_ft or a.no_extras):
             try:
                 out["roofline_families"] = time_families(B, device)

@@ -162,8 +162,12 @@ def flat_buffers(model):
 
 def _check_issue_order(group):
     """Collectives pair up across ranks by issue order alone, and the per-encoder all-reduces are issued from autograd's
-    thread: the first step compares the order (which encoder, how many elements) across ALL ranks, every later step compares
-    it with the first.  A mismatch would otherwise sum one encoder's gradients into another's, silently."""
+    thread: the first overlapped step compares the order (which encoder, how many elements) across ALL ranks -- every rank makes
+    that call, also one that issued nothing, and every rank sees every rank's list, so they agree on the verdict and fail together
+    (a rank that raised alone left its peers blocked in the exchange).  Later steps compare with the first step locally:
+    the order is a property of the model's autograd graph, which does not change; a rank that finds a change raises at once, and the
+    launcher (torchrun / mp.spawn) tears the job down when one worker exits -- the peers do not wait for a collective verdict that
+    would cost every step a host synchronisation."""
     sig = list(_ISSUED_TAGS)
     if _AR_ORDER["sig"] is None:
         theirs = [None] * dist.get_world_size(group)
@@ -182,7 +186,9 @@ def allreduce_grads(model_or_buffers, group=None):
         return
     bufs = model_or_buffers if isinstance(model_or_buffers, (list, tuple)) else [f.grad for f in flat_buffers(model_or_buffers)]
     started = {b.data_ptr(): w for b, w in _PENDING_AR}
-    if _PENDING_AR:
+    if overlap_active() and (_AR_ORDER["sig"] is None or _PENDING_AR):   # the first overlapped step: on EVERY rank, pending or not
+        if not _PENDING_AR:
+            _ISSUED_TAGS.clear()
         _check_issue_order(group)
     _PENDING_AR.clear()
     works = [started.pop(b.data_ptr(), None) or dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -298,6 +304,22 @@ class NativeComm:
         local.record_stream(self.stream)
         out.record_stream(self.stream)
         return out, done
+
+    def all_gather_into(self, out, local):
+        """The same into a caller-owned buffer ``out`` [world * B, ...] (a captured graph reads it: no allocation per step).  Returns
+        the done event; nothing is synchronised on the host."""
+        h = self._l.load()
+        if local.dtype not in (torch.float32, torch.int64) or out.dtype != local.dtype:
+            raise TypeError("NativeComm.all_gather_into: f32 embeddings or int64 labels, same dtype in and out")
+        if not (local.is_contiguous() and out.is_contiguous()) or out.numel() != self.world * local.numel():
+            raise ValueError("NativeComm.all_gather_into: contiguous buffers, out = world x local")
+        ready, done = self._events()
+        fn = h.bsclip_allgather_embeddings if local.dtype == torch.float32 else h.bsclip_allgather_labels
+        self._l.check(fn(self.comm, self._ct.c_void_p(local.data_ptr()), self._ct.c_void_p(out.data_ptr()), local.numel(),
+                         self._ct.c_void_p(self.stream.cuda_stream), self._ev(ready), self._ev(done)))
+        local.record_stream(self.stream)
+        out.record_stream(self.stream)
+        return done
 
     def all_reduce_sum_(self, flat):
         """In-place SUM over ranks of a flat f32 buffer; returns the done event."""

@@ -14,7 +14,6 @@ No process-group collective sits inside a captured region: with world_size > 1 t
 the collectives issued between them (``GraphedDistStep``).
 """
 import os
-import time
 
 import torch
 
@@ -23,20 +22,23 @@ import torch
 # watchdog thread polls the end events of the collectives it still lists (hipEventQuery, every ~100 ms): when such a poll
 # landed inside a global-mode capture the query failed, the watchdog rethrew from its own thread and the process died with
 # SIGABRT (ProcessGroupNCCL.cpp:2099, WorkNCCL::finishedGPUExecutionInternal).  torch.cuda.synchronize() completes the GPU work
-# but does not make the watchdog drop its Work objects, so whether a poll hits the capture window was a race.  Two measures,
-# either sufficient: (1) every capture here is "thread_local": only the capturing thread is held to the restricted call set,
-# the watchdog's queries stay legal; (2) ``quiesce_process_group`` before a capture: all device work done, then long enough
-# for the watchdog to retire everything it lists, so that it has nothing to query.
+# but does not make the watchdog drop its Work objects, so whether a poll hits the capture window was a race.  THE fix: every
+# capture here is "thread_local" -- only the capturing thread is held to the restricted call set, the watchdog's queries stay
+# legal (tests/test_90_dist_gpu.py::test_event_polling_thread_during_capture_is_legal makes the race deterministic).  Round 4 kept
+# a 0.35 s sleep beside it ("long enough for the watchdog to retire its list"): it rested on a torch-internal poll interval and
+# protected nothing that thread-local capture does not; it is gone (round 5), and "global" capture is refused while an NCCL process
+# group exists instead of being left as a way back into the race.
 CAPTURE_MODE = os.environ.get("BSCLIP_CAPTURE_MODE", "thread_local")
 
 
 def quiesce_process_group():
-    """No collective in flight and none on the ProcessGroupNCCL watchdog's list when a capture begins."""
+    """Device idle when a capture begins (the warm-up steps' collectives have executed); refuses the capture mode in which the
+    process group's watchdog thread would be held to the capture's restricted call set."""
     import torch.distributed as dist
     torch.cuda.synchronize()
-    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-        time.sleep(float(os.environ.get("BSCLIP_PG_QUIESCE_S", "0.35")))     # > 3 watchdog polls (100 ms each)
-        torch.cuda.synchronize()
+    if CAPTURE_MODE == "global" and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        raise RuntimeError("BSCLIP_CAPTURE_MODE=global with an NCCL process group: the group's watchdog thread polls events, which is "
+                           "illegal during a global-mode capture from any thread (the round-3 abort); use the default thread_local")
 
 
 class GraphedStep:
@@ -144,7 +146,17 @@ class GraphedStep:
 
 
 class _Tower:
-    __slots__ = ("name", "enc", "x", "stream", "gF", "gB", "emb", "z", "dz", "full", "flat", "work")
+    __slots__ = ("name", "enc", "x", "stream", "gF", "gB", "emb", "z", "dz", "full", "flat", "work", "comm")
+
+
+# BSCLIP_NATIVE_COMM=1: the W > 1 step's collectives through the C-ABI entry points (bsclip_allgather_embeddings /
+# bsclip_allgather_labels / bsclip_allreduce_grads: csrc/comm.hip, hip/dist.py NativeComm) instead of torch.distributed -- one RCCL
+# communicator and one communication stream PER TOWER (plus one for the labels), each collective ordered behind its tower's stream by
+# an event and announcing its completion by an event.  What that removes: ProcessGroupNCCL's single stream (a gather issued behind the
+# image tower's used to wait for the image tower: hence "shortest tower first" below), its watchdog thread, and the Work objects.
+# Default off: torch.distributed (the same RCCL underneath) stays the product path until an 8-GPU node has run both
+# (tests/test_90_dist_gpu.py holds the two paths bit-equal at world_size 1, the only size this box has).
+NATIVE_COMM = os.environ.get("BSCLIP_NATIVE_COMM", "0") == "1"
 
 
 class GraphedDistStep(GraphedStep):
@@ -165,11 +177,25 @@ class GraphedDistStep(GraphedStep):
     are the eager global-batch step: tests/test_90_dist_gpu.py holds the two to the same losses and parameters on two ranks,
     bit for bit."""
 
-    def __init__(self, model, optimizer, criterion, warmup=2, group=None):
+    def __init__(self, model, optimizer, criterion, warmup=2, group=None, native_comm=None):
         super().__init__(model, optimizer, criterion, warmup)
         self.group = group if group is not None else getattr(criterion, "group", None)
         self.towers = None
         self.gL = self.gC = None
+        self.native = NATIVE_COMM if native_comm is None else bool(native_comm)
+        self.label_comm = None
+        # bench.py --gpus N: (start, end) event pairs on the main stream around the waits for the gathers / the all-reduces of each
+        # replayed step AFTER the towers' own graphs have been waited for, i.e. the collective time the overlap did not hide
+        self.profile_waits = False
+        self.wait_events = []
+
+    def collective_wait_ms(self):
+        """(exposed all-gather wait, exposed all-reduce wait) in ms per profiled step (call after a device synchronisation)."""
+        if not self.wait_events:
+            return None
+        g = sum(a.elapsed_time(b) for a, b, _, _ in self.wait_events) / len(self.wait_events)
+        r = sum(c.elapsed_time(d) for _, _, c, d in self.wait_events) / len(self.wait_events)
+        return g, r
 
     _ORDER = {"text": 0, "dna": 1, "image": 2}    # issue order of the collectives: by the towers' duration, shortest first
 
@@ -205,7 +231,7 @@ class GraphedDistStep(GraphedStep):
                 continue
             t = _Tower()
             t.name, t.enc, t.x, t.stream = name, enc, x, _tower_stream(k, dev)
-            t.gF = t.gB = t.emb = t.z = t.dz = t.full = t.flat = t.work = None
+            t.gF = t.gB = t.emb = t.z = t.dz = t.full = t.flat = t.work = t.comm = None
             out.append(t)
         if len(out) < 2:
             raise ValueError("Too less element for calculating the contrastive loss.")
@@ -261,6 +287,11 @@ class GraphedDistStep(GraphedStep):
                 self.optimizer.step()
         finally:
             hdist._OVERLAP["on"] = was_on
+        if self.native:                         # one communicator + stream per tower, one for the labels (ids travel through the group)
+            from .dist import NativeComm
+            for t in towers:
+                t.comm = NativeComm(rank, W, group=self.group, device=dev)
+            self.label_comm = NativeComm(rank, W, group=self.group, device=dev)
         self.towers = towers
         self.graph = self.gL                    # "captured" marker for the base class's bookkeeping
 
@@ -268,7 +299,13 @@ class GraphedDistStep(GraphedStep):
         import torch.distributed as dist
         label = self.static[3]
         main = torch.cuda.current_stream()
-        works = [dist.all_gather_into_tensor(self.labels_full, label.contiguous(), group=self.group, async_op=True)]
+        native = self.native
+        prof = self.profile_waits
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if prof else None
+        if native:
+            dones = [self.label_comm.all_gather_into(self.labels_full, label.contiguous())]
+        else:
+            works = [dist.all_gather_into_tensor(self.labels_full, label.contiguous(), group=self.group, async_op=True)]
         for t in self.towers:                   # longest tower first
             t.stream.wait_stream(main)
             with torch.cuda.stream(t.stream):
@@ -276,13 +313,25 @@ class GraphedDistStep(GraphedStep):
         # The process group runs its collectives on ONE stream, in issue order: a gather issued behind the image tower's would wait
         # for the image tower (tools/dist_overlap_probe.py, round 4: the text tower's gather, ready at 3.8 ms, completed at 18.0).
         # So they are issued shortest tower first -- each with its tower's stream current, i.e. ordered behind that tower only.
+        # (Native path: every tower has its own communicator and stream; the same order is kept so that both paths pair up alike.)
         for t in sorted(self.towers, key=lambda t: self._ORDER[t.name]):
             with torch.cuda.stream(t.stream):
-                works.append(dist.all_gather_into_tensor(t.full, t.emb.detach(), group=self.group, async_op=True))
-        for w in works:
-            w.wait()                            # RCCL: `main` waits for the collective's stream; gloo (tests): the host does
+                if native:
+                    dones.append(t.comm.all_gather_into(t.full, t.emb.detach()))
+                else:
+                    works.append(dist.all_gather_into_tensor(t.full, t.emb.detach(), group=self.group, async_op=True))
         for t in self.towers:
             main.wait_stream(t.stream)
+        if prof:
+            ev[0].record(main)
+        if native:
+            for d in dones:
+                main.wait_event(d)
+        else:
+            for w in works:
+                w.wait()                        # RCCL: `main` waits for the collective's stream; gloo (tests): the host does
+        if prof:
+            ev[1].record(main)
         self.gL.replay()
         for t in self.towers:
             t.work = None
@@ -294,17 +343,34 @@ class GraphedDistStep(GraphedStep):
         for t in sorted(self.towers, key=lambda t: self._ORDER[t.name]):    # shortest backward first, as above; same order on every rank
             if t.gB is not None and t.flat is not None:
                 with torch.cuda.stream(t.stream):
-                    t.work = dist.all_reduce(t.flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    if native:
+                        t.work = t.comm.all_reduce_sum_(t.flat.grad)
+                    else:
+                        t.work = dist.all_reduce(t.flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for t in self.towers:
+            main.wait_stream(t.stream)
+        if prof:
+            ev[2].record(main)
         for t in self.towers:
             if t.work is not None:
-                t.work.wait()
-            main.wait_stream(t.stream)
+                if native:
+                    main.wait_event(t.work)
+                else:
+                    t.work.wait()
+        if prof:
+            ev[3].record(main)
+            self.wait_events.append(tuple(ev))
         self.gC.replay()
         if hasattr(self.optimizer, "sync_updated_slices"):
             self.optimizer.sync_updated_slices()      # sharded optimizer state (full fine-tuning): owners broadcast their slices
         return self.loss_buf
 
     def _drop(self):
+        if self.towers is not None:
+            for c in [t.comm for t in self.towers] + [self.label_comm]:
+                if c is not None:
+                    c.close()
+        self.label_comm = None
         self.graph = self.gL = self.gC = self.towers = None
 
     def __call__(self, image, dna, text, label):

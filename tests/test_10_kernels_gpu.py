@@ -317,8 +317,13 @@ def test_attention_fwd_bwd(ops, B, S, heads, masked):
     dqkv = torch.full((B * S, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
     ops.attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=bias)
     gq = gq.reshape(B * S, 3 * H)
+    # S = 1: dQ = dK = 0 exactly in the reference (one key: dS = P (dP - delta) = 0).  Since round 5 the key-owner phase starts the dP
+    # accumulator from -delta (the row constant as the MFMA chain's initial value), so dS is f32 rounding noise (~1e-7 of dP) instead
+    # of an exact zero there: errors are measured against the whole gradient's norm
+    floor = 1e-5 * gq.norm()
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
-        assert rel_err(dqkv[:, sl].float(), gq[:, sl]) < 1e-2, name
+        err = ((dqkv[:, sl].float() - gq[:, sl]).norm() / (gq[:, sl].norm() + floor)).item()
+        assert err < 1e-2, (name, err)
 
 
 @pytest.mark.parametrize("B,S,heads,q_rows", [(3, 197, 12, 1), (2, 133, 4, 40), (2, 20, 2, 1)])

@@ -118,11 +118,12 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, with_text, mode, mo
     assert rel_err(r0["flat"], flat) < {"fullft": 5e-3, "exact": 2e-5}.get(mode, 2e-3)
 
 
-def _graph_worker(rank, world, port, B, tmp, steps):
+def _graph_worker(rank, world, port, B, tmp, steps, backend="gloo", native=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)      # RCCL: one GPU per rank; gloo: both ranks share the one GPU
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from bioscanclip.hip import dist as hdist
     from bioscanclip.hip.graph import GraphedDistStep
     from bioscanclip.hip.optim import FusedAdamW
@@ -138,7 +139,7 @@ def _graph_worker(rank, world, port, B, tmp, steps):
         sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-3, total_steps=steps, pct_start=0.3, anneal_strategy="cos",
                                                     cycle_momentum=False)
         crit = GlobalBatchContrastiveLoss(torch.nn.CrossEntropyLoss(), 1 / 0.07)
-        g = GraphedDistStep(model, opt, crit, warmup=2) if mode == "graph" else None
+        g = GraphedDistStep(model, opt, crit, warmup=2, native_comm=native) if mode == "graph" else None
         losses = []
         for s in range(steps):
             image, dna, text, label = batches[s]
@@ -262,6 +263,30 @@ def test_two_rank_graphed_step_equals_eager(tmp_path):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("native", [False, True])
+def test_two_rccl_ranks_graphed_step_equals_eager(tmp_path, native):
+    """the per-tower-graph launch path rests on RCCL's STREAM semantics (each collective ordered behind the tower
+    stream current at issue, the loss / optimizer graphs behind the collectives) -- gloo, which carries the two-ranks-on-one-GPU
+    tests, blocks the host instead and cannot see a missing stream dependency.  This is the test that can: two real RCCL ranks on
+    two GPUs, GraphedDistStep (torch.distributed collectives, and the C-ABI ones) against the eager step, bit for bit.  It needs two
+    GPUs: SKIPPED on the one-GPU boxes this repo has been built and judged on so far -- until it has run somewhere, the overlapped
+    W > 1 path is unvalidated on RCCL above world_size 1 (INTEGRATION.md says so)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one RCCL rank each)")
+    world, B, steps = 2, 4, 8
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_graph_worker, args=(world, port, B, str(tmp_path), steps, "nccl", native), nprocs=world, join=True)
+    for r in range(world):
+        out = torch.load(os.path.join(str(tmp_path), f"graph_rank{r}.pt"))
+        assert out["eager"][0] == out["graph"][0], (r, out["eager"][0], out["graph"][0])
+        for k, v in out["eager"][1].items():
+            assert torch.equal(v, out["graph"][1][k]), (r, k)
+
+
+@pytest.mark.timeout(900)
 def test_rccl_collectives_at_world_size_one():
     """The one-GPU box cannot host two RCCL ranks, but it can run the REAL collectives: BSCLIP_FORCE_DIST=1 sends a
     world_size-1 bench job through init_process_group("nccl"), the tower-stream all-gathers, the per-encoder all-reduces
@@ -295,6 +320,17 @@ def test_rccl_collectives_at_world_size_one():
     g = json.loads(r.stdout.strip().splitlines()[-1])
     assert "per-tower captured hipGraphs" in g["config"]["launch_path"], g["config"]
     assert "capture failed" not in r.stderr
+    assert "torch.distributed" in g["config"]["collectives"], g["config"]
+    # ... and the same launch path with the collectives through the C-ABI entry points (BSCLIP_NATIVE_COMM=1: one RCCL communicator and
+    # one communication stream per tower, event-ordered; hip/graph.py): the same graphs, the same buffers -- bit-equal to the
+    # torch.distributed path (world_size 1 is what this box can prove)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--text", "--batch", "16", "--steps", "3", "--warmup", "3",
+                        "--no-cpu-baseline", "--no-extras"], env=dict(env, BSCLIP_NATIVE_COMM="1"), capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    gn = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "C-ABI" in gn["config"]["collectives"] and "capture failed" not in r.stderr, gn["config"]
+    assert gn["config"]["final_loss"] == g["config"]["final_loss"], (gn["config"], g["config"])
+    assert gn["dist"]["ranks"] == 1 and gn["dist"]["exposed_allgather_wait_ms_per_step"] >= 0.0, gn["dist"]
     # the graph leg runs 1 + 3 (eager, capture, first replay) + 3 + 3 = 10 steps: the eager comparison takes as many
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--text", "--batch", "16", "--steps", "3", "--warmup", "6",
                         "--no-graph", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=800)
