@@ -38,8 +38,8 @@ NODROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)  # pari
 TOL = {"dna_L2": (9.4e-3, 3.0e-2), "dna_L12": (1.22e-2, 8.6e-2), "txt_L4": (5.9e-3, 2.9e-2),
        "vit_L2": (1.23e-2, 2.7e-2), "vit_L12": (2.22e-2, 8.9e-2)}
 SELF_FACTOR = 1.5   # HIP-vs-emulating-oracle <= SELF_FACTOR x (emulating oracle f32-accumulate vs f64-accumulate), embedding AND gradients
-# (round 5, gradients: HIP vs emulation / emulation's own drift, worst tensor: dna_L2 1.37e-2 / 1.00e-2, dna_L12 5.46e-2 / 4.13e-2,
-# txt_L4 1.39e-2 / 1.45e-2, vit_L2 1.42e-2 / 1.15e-2, vit_L12 6.03e-2 / 5.22e-2: ratios 0.96 - 1.37)
+# (round 5, gradients on the GPU box, profiles/r05_b_parity.jsonl: HIP vs emulation / emulation's own drift, worst tensor: dna_L2 1.37e-2 /
+# 1.07e-2, dna_L12 5.49e-2 / 5.08e-2, txt_L4 1.39e-2 / 1.23e-2, vit_L2 1.42e-2 / 1.18e-2, vit_L12 6.03e-2 / 5.42e-2: ratios 1.08 - 1.29)
 
 
 def _log(rec):
