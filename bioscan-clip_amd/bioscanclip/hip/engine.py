@@ -292,6 +292,12 @@ class EncoderEngineBase:
         a3 = ops.split3_rows(a_f32, scratch, M=M, K=K)
         return ops.gemm(a3, w3, out, epi, M=M, K=3 * K, **kw)
 
+    def _ex_gemm3(self, a3, w3, out, epi, M, **kw):
+        """The same with the A operand already split: ``a3`` bf16 [>= M, >= 3K] = [hi | lo | hi], written by the producer itself (the
+        LayerNorm kernels' y_split3 / dx_split3 outputs, round 5) instead of a stand-alone split3_rows pass over an f32 tensor."""
+        K = w3.shape[1] // 3
+        return ops.gemm(a3[:M, :3 * K], w3, out, epi, M=M, K=3 * K, **kw)
+
     def _ex_weight_t(self, w_f32):
         """[hi | hi | lo] rows of the TRANSPOSE of a frozen f32 weight [N, K] -> bf16 [K, 3N]: the B operand of its dX GEMM."""
         w = w_f32.detach().to(self.device, F32).contiguous()
@@ -469,10 +475,10 @@ class ViTEngine(EncoderEngineBase):
         for l, lay in enumerate(self.layers):
             has = self._lora_index[l] is not None
             y32, qkv32, ctx32, z32 = ws["y32s"][l], ws["qkv32s"][l], ws["ctx32s"][l], ws["z32s"][l]
-            ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_bf16=ws["h1"][l], y_f32=y32, lora_a=self.lora_a(l),
-                              stats=ws["st1"][l])
+            # the LayerNorm writes the QKV GEMM's split operand itself (and the f32 copy the LoRA gradients read in the backward)
+            ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_f32=y32, y_split3=a3, stats=ws["st1"][l])
             ops.split3_weight(lay.qkv32, lay.wqkv3, lora_a=self.lora_a(l) if has else None, lora_b=self.lora_b(l) if has else None)
-            self._ex_gemm(y32, lay.wqkv3, qkv32, EPI_F32, a3, bias=lay.b_qkv)
+            self._ex_gemm3(a3, lay.wqkv3, qkv32, EPI_F32, M, bias=lay.b_qkv)
             ops.attn_fwd_f32(qkv32, B, S, self.heads, scale, ctx32, ws["lse"][l])
             if l == L - 1:   # token-0 rows only, as the default path (and as its backward expects)
                 self._ex_gemm(tok0(ctx32, H), lay.w3[0], tok0(x[2 * l + 1], H), EPI_RESID_F32, a3, bias=lay.b_proj,
@@ -484,8 +490,8 @@ class ViTEngine(EncoderEngineBase):
                 ops.gemm(g3, lay.w3[2], tok0(x[2 * l + 2], H), EPI_RESID_F32, bias=lay.b_fc2, resid=tok0(x[2 * l + 1], H), M=B)
                 continue
             self._ex_gemm(ctx32, lay.w3[0], x[2 * l + 1], EPI_RESID_F32, a3, bias=lay.b_proj, resid=x[2 * l])
-            ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_bf16=ws["h2"], y_f32=ws["y32"], stats=ws["st2"][l])
-            self._ex_gemm(ws["y32"], lay.w3[1], z32, EPI_F32, a3, bias=lay.b_fc1)
+            ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_split3=a3, stats=ws["st2"][l])
+            self._ex_gemm3(a3, lay.w3[1], z32, EPI_F32, M, bias=lay.b_fc1)
             g3 = ops.gelu_split3(z32, a3)
             ops.gemm(g3, lay.w3[2], x[2 * l + 2], EPI_RESID_F32, bias=lay.b_fc2, resid=x[2 * l + 1])
         ops.layernorm_fwd(tok0(x[-1], H), self.ln_f[0], self.ln_f[1], 1e-6, y_bf16=ws["clsn"], y_f32=ws["cls32"], stats=ws["st_f"])
@@ -637,6 +643,7 @@ class ViTEngine(EncoderEngineBase):
         dx.zero_()
         dx_c = tok0(dx, H)
         ops.layernorm_bwd(tok0(x[-1], H), ws["st_f"], self.ln_f[0], 0, g_gemm=ws["dcls32"], dx_f32=dx_c)
+        dx3 = False     # a3 holds the split of dx (written by the LayerNorm backward that produced dx: no split3_rows pass)
         for l in range(L - 1, -1, -1):
             lay = self.layers[l]
             if l == L - 1:    # token-0 rows only (see backward)
@@ -647,11 +654,14 @@ class ViTEngine(EncoderEngineBase):
                 ws["dctx32"].zero_()
                 self._ex_gemm(dx_c, lay.w3t[0], tok0(ws["dctx32"], H), EPI_F32, a3, M=B)
             else:
-                self._ex_gemm(dx, lay.w3t[2], ws["g32"], EPI_F32, a3)
+                if dx3:
+                    self._ex_gemm3(a3, lay.w3t[2], ws["g32"], EPI_F32, M)
+                else:
+                    self._ex_gemm(dx, lay.w3t[2], ws["g32"], EPI_F32, a3)
                 g3 = ops.dgelu_split3(ws["g32"], ws["z32s"][l], dst=a3)
                 ops.gemm(g3, lay.w3t[1], ws["dh32"], EPI_F32)
-                ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh32"], dx_f32=dx)
-                self._ex_gemm(dx, lay.w3t[0], ws["dctx32"], EPI_F32, a3)
+                ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh32"], dx_f32=dx, dx_split3=a3)
+                self._ex_gemm3(a3, lay.w3t[0], ws["dctx32"], EPI_F32, M)
             ops.attn_bwd_f32(ws["qkv32s"][l], ws["dctx32"], ws["ctx32s"][l], ws["lse"][l], B, S, self.heads, scale, ws["dqkv32"])
             has = self._lora_index[l] is not None
             if has:
@@ -661,7 +671,8 @@ class ViTEngine(EncoderEngineBase):
                 wt = ops.split3_transpose(lay.qkv32, lay.wqkvT3, 1, lora_a=self.lora_a(l) if has else None,
                                           lora_b=self.lora_b(l) if has else None)
                 self._ex_gemm(ws["dqkv32"], wt, ws["dh32"], EPI_F32, a3)
-                ops.layernorm_bwd(x[2 * l], ws["st1"][l], lay.ln1[0], 0, g_resid=dx, g_gemm=ws["dh32"], dx_f32=dx)
+                ops.layernorm_bwd(x[2 * l], ws["st1"][l], lay.ln1[0], 0, g_resid=dx, g_gemm=ws["dh32"], dx_f32=dx, dx_split3=a3)
+                dx3 = True
 
 # ======================================================================================================= BERT
 class BertEngine(EncoderEngineBase):
@@ -880,18 +891,17 @@ class BertEngine(EncoderEngineBase):
             has = self._lora_index[l] is not None
             qkv32, ctx32, z32 = ws["qkv32s"][l], ws["ctx32s"][l], ws["z32s"][l]
             ops.split3_weight(lay.qkv32, lay.wqkv3, lora_a=self.lora_a(l) if has else None, lora_b=self.lora_b(l) if has else None)
-            self._ex_gemm(ys[l], lay.wqkv3, qkv32, EPI_F32, a3, bias=lay.b_qkv)
+            self._ex_gemm3(a3, lay.wqkv3, qkv32, EPI_F32, M, bias=lay.b_qkv)     # a3 = split of ys[l], written by the LayerNorm before
             ops.attn_fwd_f32(qkv32, B, S, self.heads, 0.125, ctx32, ws["lse"][l], key_bias=key_bias,
                              dropout=self._drop(ws, self.p_attn, l, 1))
             self._ex_gemm(ctx32, lay.w3[0], ws["s1"][l], EPI_RESID_F32, a3, bias=lay.b_o, resid=ys[l],
                           dropout=self._drop(ws, self.p_hidden, l, 2))
-            ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_bf16=ws["ymb"], y_f32=ws["ym"], stats=ws["sta"][l])
-            self._ex_gemm(ws["ym"], lay.w3[1], z32, EPI_F32, a3, bias=lay.b_fc1)
+            ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_f32=ws["ym"], y_split3=a3, stats=ws["sta"][l])
+            self._ex_gemm3(a3, lay.w3[1], z32, EPI_F32, M, bias=lay.b_fc1)
             g3 = ops.gelu_split3(z32, a3)
             ops.gemm(g3, lay.w3[2], ws["s2"][l], EPI_RESID_F32, bias=lay.b_fc2, resid=ws["ym"],
                      dropout=self._drop(ws, self.p_hidden, l, 3))
-            ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_bf16=ws["yb"][l + 1], y_f32=ys[l + 1],
-                              lora_a=self._zero_a, stats=ws["stb"][l])
+            ops.layernorm_fwd(ws["s2"][l], lay.ln_b[0], lay.ln_b[1], self.eps, y_f32=ys[l + 1], y_split3=a3, stats=ws["stb"][l])
         out = torch.empty(B, self.out_dim, dtype=F32, device=self.device)
         ops.split3_weight(self.extra(0), ws["whead3"])
         if self.head == "mlm_softmax_mean":
@@ -941,14 +951,15 @@ class BertEngine(EncoderEngineBase):
             lay = self.layers[l]
             drop_b, drop_a = self._drop(ws, self.p_hidden, l, 3), self._drop(ws, self.p_hidden, l, 2)
             # a dX GEMM's operand carries the mask its Linear's forward output was dropped with; without dropout it IS the stream
+            # (round 5: the LayerNorm backward writes that operand split, [hi | lo | hi], straight into the GEMM's A buffer)
             ops.layernorm_bwd(ws["s2"][l], ws["stb"][l], lay.ln_b[0], 1, g_resid=g_resid, g_gemm=g_gemm, dx_f32=ws["ds"],
-                              dx_bf16=ws["dop32"] if drop_b else None, dropout=drop_b)
-            self._ex_gemm(ws["dop32"] if drop_b else ws["ds"], lay.w3t[2], ws["g32"], EPI_F32, a3)
+                              dx_split3=a3, dropout=drop_b)
+            self._ex_gemm3(a3, lay.w3t[2], ws["g32"], EPI_F32, M)
             g3 = ops.dgelu_split3(ws["g32"], ws["z32s"][l], dst=a3)
             ops.gemm(g3, lay.w3t[1], ws["dh32"], EPI_F32)
             ops.layernorm_bwd(ws["s1"][l], ws["sta"][l], lay.ln_a[0], 1, g_resid=ws["ds"], g_gemm=ws["dh32"], dx_f32=ws["ds1"],
-                              dx_bf16=ws["dop32"] if drop_a else None, dropout=drop_a)
-            self._ex_gemm(ws["dop32"] if drop_a else ws["ds1"], lay.w3t[0], ws["dctx32"], EPI_F32, a3)
+                              dx_split3=a3, dropout=drop_a)
+            self._ex_gemm3(a3, lay.w3t[0], ws["dctx32"], EPI_F32, M)
             ops.attn_bwd_f32(ws["qkv32s"][l], ws["dctx32"], ws["ctx32s"][l], ws["lse"][l], B, S, self.heads, 0.125, ws["dqkv32"],
                              key_bias=ws["key_bias"], dropout=self._drop(ws, self.p_attn, l, 1))
             has = self._lora_index[l] is not None
@@ -993,7 +1004,8 @@ class BertEngine(EncoderEngineBase):
         else:
             ops.layernorm_fwd(ws["emb"], self.ln_e[0], self.ln_e[1], self.eps, y_bf16=ws["yb"][0], y_f32=None if rb else ws["y"],
                               lora_a=self.lora_a(0), dropout=self._drop(ws, self.p_hidden, -1, 0),
-                              stats=ws["st_e"] if self.full_ft else None)
+                              stats=ws["st_e"] if self.full_ft else None,
+                              y_split3=ws["a3"] if self.exact() else None)     # exact mode: layer 0's QKV operand, already split
         ws["ids"], ws["type_ids"] = input_ids, token_type_ids
         if self.exact():
             return self._forward_exact(ws, key_bias)

@@ -51,7 +51,7 @@ SIGNATURES = {
     "bsclip_gemm_fp8": (I, [P, I, P, I, P, I, I, I, I, I, POINTER(EpiArgs), POINTER(Fp8Args), P]),
     "bsclip_quantize_rows_fp8": (I, [P, I, I, P, I, P, P]),
     "bsclip_lora_baug_set": (I, [P, I, I, P, P, P, P]),
-    "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, P, F, U, P]),
+    "bsclip_layernorm_fwd": (I, [P, I, I, I, I, P, P, F, P, I, P, P, I, P, P, F, U, P]),
     "bsclip_layernorm_fwd_fp8": (I, [P, I, I, I, I, P, P, F, P, I, P, I, P, P, P, F, U, P]),
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, F, U, I, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, P, F, U, P]),
@@ -64,7 +64,7 @@ SIGNATURES = {
     "bsclip_dgelu_split3": (I, [P, I, P, I, I, I, P, I, P, I, P]),
     "bsclip_split3_transpose": (I, [P, I, I, I, I, I, P, P, I, P, I, P]),
     "bsclip_softmax_meanpool_bwd_f32": (I, [P, P, P, I, I, I, P, I, P]),
-    "bsclip_lora_grad_f32_workspace_floats": (L, [I]),
+    "bsclip_lora_grad_f32_workspace_floats": (L, [I, I]),
     "bsclip_lora_grad_f32": (I, [P, I, P, I, I, I, P, P, P, P, P, P]),
     "bsclip_attn_bwd_f32": (I, [P, I, P, I, P, I, P, I, I, I, P, F, P, I, F, U, P]),
     "bsclip_exact_attn_set_impl": (I, [I]),

@@ -157,7 +157,8 @@ def set_gemm_persistent_grid(workgroups):
     check(_l.load().bsclip_gemm_set_persistent_grid(workgroups))
 
 
-def layernorm_fwd(x, gamma, beta, eps, y_bf16=None, y_f32=None, lora_a=None, stats=None, M=None, dropout=None):
+def layernorm_fwd(x, gamma, beta, eps, y_bf16=None, y_f32=None, lora_a=None, stats=None, M=None, dropout=None, y_split3=None):
+    """``y_split3`` (exact mode): bf16 [M, >= 3H] that receives the output as a split-bf16 GEMM operand [hi | lo | hi]."""
     ld_x = _rowmajor(x, "x")
     H = gamma.numel()
     M = x.shape[0] if M is None else M
@@ -175,9 +176,13 @@ def layernorm_fwd(x, gamma, beta, eps, y_bf16=None, y_f32=None, lora_a=None, sta
         _req(lora_a.dtype == F32 and lora_a.is_contiguous() and tuple(lora_a.shape) == (8, H), "lora_a must be f32 [8,H]")
     if stats is not None:
         _req(stats.dtype == F32 and stats.is_contiguous() and stats.numel() >= 2 * M, "stats must be f32 [M,2]")
+    ld_y3 = 0
+    if y_split3 is not None:
+        ld_y3 = _rowmajor(y_split3, "y_split3")
+        _req(y_split3.dtype == BF16 and y_split3.shape[0] >= M and y_split3.shape[1] >= 3 * H, "layernorm_fwd: y_split3 bf16 [M, >= 3H]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_layernorm_fwd(_p(x), ld_x, int(x.dtype == BF16), M, H, _p(gamma), _p(beta), float(eps),
-                                         _p(y_bf16), ld_y, _p(y_f32), _p(lora_a), _p(stats), dp, ds, _stream()))
+                                         _p(y_bf16), ld_y, _p(y_f32), _p(y_split3), ld_y3, _p(lora_a), _p(stats), dp, ds, _stream()))
 
 
 def layernorm_fwd_fp8(x, gamma, beta, eps, y_fp8, t_aug=None, y_f32=None, lora_a=None, stats=None, M=None, dropout=None):
@@ -205,10 +210,11 @@ def layernorm_fwd_fp8(x, gamma, beta, eps, y_fp8, t_aug=None, y_f32=None, lora_a
 
 
 def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lora_a=None, dx_f32=None, dx_bf16=None,
-                  M=None, dropout=None, in_dropout=None):
+                  M=None, dropout=None, in_dropout=None, dx_split3=None):
     """``g_resid`` / ``dx_f32`` are the residual-gradient stream in / out: f32, or bf16 (half the bytes; the dtype of each
     tensor is passed on as ``resid_flags``).  ``dx_bf16`` is the next dX GEMM's operand (carries ``dropout``'s mask); the exact
-    backward passes ``g_gemm`` and ``dx_bf16`` as f32 tensors."""
+    backward passes ``g_gemm`` and ``dx_bf16`` as f32 tensors, or takes the operand as ``dx_split3``: bf16 [M, >= 3H] = [hi | lo | hi],
+    the A operand of the next split-bf16 dX GEMM (instead of ``dx_bf16``)."""
     ld_x = _rowmajor(x, "x")
     H = gamma.numel()
     M = x.shape[0] if M is None else M
@@ -228,6 +234,10 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
     if dx_f32 is not None:
         ld_dx = _rowmajor(dx_f32, "dx_f32")
         _req(dx_f32.dtype in (F32, BF16) and dx_f32.shape[0] >= M and dx_f32.shape[1] >= H, "dx_f32 must be f32 / bf16 [M,>=H]")
+    if dx_split3 is not None:
+        _req(dx_bf16 is None and dx_split3.dtype == BF16 and dx_split3.shape[0] >= M and dx_split3.shape[1] >= 3 * H,
+             "dx_split3: bf16 [M, >= 3H], instead of dx_bf16")
+        dx_bf16 = dx_split3
     if dx_bf16 is not None:
         ld_dxb = _rowmajor(dx_bf16, "dx_bf16")
         _req(dx_bf16.dtype in (BF16, F32) and dx_bf16.shape[0] >= M and dx_bf16.shape[1] >= H, "dx_bf16 (bf16 / f32 operand) too small")
@@ -241,7 +251,8 @@ def layernorm_bwd(x, stats, gamma, mode, g_resid=None, g_gemm=None, dt=None, lor
                                          (1 if g_resid is not None and g_resid.dtype == BF16 else 0)
                                          | (2 if dx_f32 is not None and dx_f32.dtype == BF16 else 0)
                                          | (4 if g_gemm is not None and g_gemm.dtype == F32 else 0)
-                                         | (8 if dx_bf16 is not None and dx_bf16.dtype == F32 else 0), _stream()))
+                                         | (8 if dx_bf16 is not None and dx_bf16.dtype == F32 else 0)
+                                         | (16 if dx_split3 is not None else 0), _stream()))
 
 
 KEEP_WORDS = 16   # csrc/attn_common.h: 32-bit dropout keep words per (batch, head, query) row (2 lane halves x 8)
@@ -398,10 +409,10 @@ def lora_grad_f32(dqkv, y, M, H, lora_a, lora_b, dA, dB):
          "lora_grad_f32 shapes")
     _req(all(t.dtype == F32 and t.is_contiguous() for t in (lora_a, lora_b, dA, dB)) and tuple(lora_a.shape) == (8, H)
          and tuple(lora_b.shape) == (2, H, 4) and tuple(dA.shape) == (8, H) and tuple(dB.shape) == (2, H, 4), "lora_grad_f32: parameters")
-    key = (H, str(dqkv.device), torch.cuda.current_stream().cuda_stream)   # one workspace per launching stream (towers run concurrently)
+    key = (M, H, str(dqkv.device), torch.cuda.current_stream().cuda_stream)   # one workspace per launching stream (towers run concurrently)
     ws = _LG32_WS.get(key)
     if ws is None:
-        ws = _LG32_WS[key] = torch.empty(_l.load().bsclip_lora_grad_f32_workspace_floats(H), dtype=F32, device=dqkv.device)
+        ws = _LG32_WS[key] = torch.empty(_l.load().bsclip_lora_grad_f32_workspace_floats(M, H), dtype=F32, device=dqkv.device)
     check(_l.load().bsclip_lora_grad_f32(_p(dqkv), _rowmajor(dqkv, "dqkv"), _p(y), _rowmajor(y, "y"), M, H, _p(lora_a), _p(lora_b),
                                          _p(dA), _p(dB), _p(ws), _stream()))
 

@@ -253,6 +253,13 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // fullft.hip, internal: out0 / out1 [c] += sum_b partial[b][c] in a fixed order (columns < split go to out0, the rest to out1)
 void bsclip_launch_slab_reduce_add(const float* partial, int nblocks, int n, float* out0, float* out1, int split, hipStream_t s);
 
+// attn_x3.hip, internal: exact-mode attention on split-bf16 operands (argument checks: exact.hip's bsclip_attn_fwd_f32 / bwd_f32)
+void bsclip_launch_attn_fwd_x3(const float* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, float* ctx,
+                               int ld_ctx, float* lse, const DropCfg& drop, hipStream_t s);
+void bsclip_launch_attn_bwd_x3(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx, const float* lse,
+                               int B, int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv, const DropCfg& drop,
+                               hipStream_t s);
+
 // gemm.hip, internal: the fused InfoNCE products on the 256x256 ping-pong GEMM (see the EPI_LSE_PART / EPI_LOSS_W epilogues)
 int bsclip_gemm_infonce(int mode, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                         const int64_t* labels, const float* cnt, const float* lse_row, const float* lse_col, float* part,

@@ -12,7 +12,7 @@
 //                         form (v_mfma_f32_32x32x2_f32: exact f32 FMA chains at the vector-ALU peak rate without the LDS-broadcast
 //                         bottleneck of a one-row-per-thread kernel, which is kept as a second implementation:
 //                         bsclip_exact_attn_set_impl(1)); same dropout masks as the bf16 kernels
-//   ... and the exact backward: bsclip_dgelu_split3, bsclip_split3_transpose, bsclip_lora_grad_f32, bsclip_softmax_meanpool_bwd_f32.
+//   ... and the exact backward: bsclip_dgelu_split3, bsclip_split3_transpose, bsclip_softmax_meanpool_bwd_f32 (bsclip_lora_grad_f32: optim.hip).
 // Reference semantics: timm Attention / Mlp (image_encoder.py:108-109), HF BertSelfAttention / BertIntermediate (dna_encoder.py:105).
 #include <math.h>
 
@@ -526,104 +526,6 @@ __global__ __launch_bounds__(256) void softmax_meanpool_bwd_f32_kernel(const flo
         *reinterpret_cast<f32x4*>(dlogits + (size_t)row * ld_d + j * 256 + lane * 4) = p[j] * (g[j] - dot);
 }
 
-// LoRA gradients in f32 from the f32 dq / dv and the f32 LayerNorm output y (the forward folds W + B A, so t = A y is rebuilt here):
-//   t = A y, u_q = B_q^T dq, u_v = B_v^T dv;   dA_q += u_q y^T, dA_v += u_v y^T, dB_q += dq t_q^T, dB_v += dv t_v^T
-// (reference lora_layer.py:16-39).  Workgroup = a strided set of rows, LGR at a time; thread = NV columns; partial sums per workgroup
-// [16 H] = dA [8, H] | dB [2, H, 4], reduced in a fixed order by slab_reduce_add.
-constexpr int LGR = 4;
-template <int H>
-__global__ __launch_bounds__(256) void lora_grad_f32_kernel(const float* __restrict__ dqkv, int ld, const float* __restrict__ y, int ldy,
-                                                            int M, const float* __restrict__ A, const float* __restrict__ Bm,
-                                                            float* __restrict__ partial) {
-    constexpr int NV = H / 256;
-    __shared__ float red[4][LGR * 16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float a[8][NV], bq[NV][4], bv[NV][4], accA[8][NV], accQ[NV][4], accV[NV][4];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int c = tid + 256 * j;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            a[i][j] = A[(size_t)i * H + c];
-            accA[i][j] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bq[j][i] = Bm[(size_t)c * 4 + i];
-            bv[j][i] = Bm[((size_t)H + c) * 4 + i];
-            accQ[j][i] = accV[j][i] = 0.f;
-        }
-    }
-    for (int r0 = blockIdx.x * LGR; r0 < M; r0 += gridDim.x * LGR) {
-        float yv[LGR][NV], dq[LGR][NV], dv[LGR][NV], s[LGR][16];
-#pragma unroll
-        for (int r = 0; r < LGR; ++r) {
-            const bool ok = r0 + r < M;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = tid + 256 * j;
-                yv[r][j] = ok ? y[(size_t)(r0 + r) * ldy + c] : 0.f;
-                dq[r][j] = ok ? dqkv[(size_t)(r0 + r) * ld + c] : 0.f;
-                dv[r][j] = ok ? dqkv[(size_t)(r0 + r) * ld + 2 * H + c] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float t = 0.f;
-#pragma unroll
-                for (int j = 0; j < NV; ++j) t = fmaf(a[i][j], yv[r][j], t);
-                s[r][i] = wave_sum(t);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float uq = 0.f, uv = 0.f;
-#pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    uq = fmaf(dq[r][j], bq[j][i], uq);
-                    uv = fmaf(dv[r][j], bv[j][i], uv);
-                }
-                s[r][8 + i] = wave_sum(uq);
-                s[r][12 + i] = wave_sum(uv);
-            }
-        }
-        __syncthreads();   // the previous iteration's reads of red are done
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < LGR; ++r)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) red[wave][r * 16 + i] = s[r][i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < LGR; ++r) {
-            float f[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) f[i] = (red[0][r * 16 + i] + red[1][r * 16 + i]) + (red[2][r * 16 + i] + red[3][r * 16 + i]);
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) accA[i][j] = fmaf(f[8 + i], yv[r][j], accA[i][j]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    accQ[j][i] = fmaf(dq[r][j], f[i], accQ[j][i]);
-                    accV[j][i] = fmaf(dv[r][j], f[4 + i], accV[j][i]);
-                }
-            }
-        }
-    }
-    float* out = partial + (size_t)blockIdx.x * 16 * H;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int c = tid + 256 * j;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) out[(size_t)i * H + c] = accA[i][j];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            out[8 * H + (size_t)c * 4 + i] = accQ[j][i];
-            out[8 * H + ((size_t)H + c) * 4 + i] = accV[j][i];
-        }
-    }
-}
-
 // f32 attention backward on the vector ALU, one workgroup per (batch, head), two phases over the same LDS:
 //   A  K, V resident; one query row per thread: delta = dO . O, p = exp(s - lse), dS = p (f dO.v - delta), dQ = scale dS K
 //   B  Q, dO resident; one key row per thread:  dV = (p f)^T dO, dK = scale dS^T Q
@@ -777,7 +679,7 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_f32_kernel(const float* _
 
 static int g_exact_attn_impl = 0;
 extern "C" int bsclip_exact_attn_set_impl(int impl) {
-    BSCLIP_REQUIRE(impl == 0 || impl == 1, "bsclip_exact_attn_set_impl: %d (0 = f32 MFMA, 1 = vector ALU)", impl);
+    BSCLIP_REQUIRE(impl >= 0 && impl <= 2, "bsclip_exact_attn_set_impl: %d (0 = split-bf16 MFMA, 1 = vector ALU, 2 = f32 MFMA)", impl);
     g_exact_attn_impl = impl;
     return BSCLIP_OK;
 }
@@ -848,7 +750,12 @@ extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, i
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_attn_fwd_f32: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (g_exact_attn_impl == 0) {   // the matrix-pipe form (f32 MFMA); impl 1 = the one-row-per-thread vector-ALU kernel
+    if (g_exact_attn_impl == 0) {   // round 5: split-bf16 operands on the bf16 matrix cores (attn_x3.hip), 16 x the f32 MFMA rate
+        bsclip_launch_attn_fwd_x3(qkv, ld_qkv, B, S, heads, key_bias, scale, ctx, ld_ctx, lse, drop, s);
+        BSCLIP_LAUNCH_CHECK();
+        return BSCLIP_OK;
+    }
+    if (g_exact_attn_impl == 2) {   // f32 operands on the matrix pipe (round 4); impl 1 = the one-row-per-thread vector-ALU kernel
         if (drop.thr16)
             hipLaunchKernelGGL((attn_fwd_mf32_kernel<true>), dim3(B * heads), dim3(MF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale,
                                ctx, ld_ctx, lse, drop);
@@ -908,26 +815,6 @@ extern "C" int bsclip_softmax_meanpool_bwd_f32(const float* logits, const float*
     return BSCLIP_OK;
 }
 
-constexpr int LG32_BLOCKS = 512;
-extern "C" int64_t bsclip_lora_grad_f32_workspace_floats(int H) { return (int64_t)LG32_BLOCKS * 16 * H; }
-
-extern "C" int bsclip_lora_grad_f32(const float* dqkv, int ld_dqkv, const float* y, int ld_y, int M, int H, const float* lora_a,
-                                    const float* lora_b, float* dA, float* dB, float* workspace, void* stream) {
-    BSCLIP_REQUIRE(dqkv && y && lora_a && lora_b && dA && dB && workspace, "bsclip_lora_grad_f32: null pointer");
-    BSCLIP_REQUIRE(M > 0 && (H == 768 || H == 512) && ld_dqkv >= 3 * H && ld_y >= H, "bsclip_lora_grad_f32: M=%d H=%d ld_dqkv=%d ld_y=%d", M,
-                   H, ld_dqkv, ld_y);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int blocks = min(LG32_BLOCKS, ceil_div(M, LGR));
-    if (H == 768)
-        hipLaunchKernelGGL((lora_grad_f32_kernel<768>), dim3(blocks), dim3(256), 0, s, dqkv, ld_dqkv, y, ld_y, M, lora_a, lora_b, workspace);
-    else
-        hipLaunchKernelGGL((lora_grad_f32_kernel<512>), dim3(blocks), dim3(256), 0, s, dqkv, ld_dqkv, y, ld_y, M, lora_a, lora_b, workspace);
-    BSCLIP_LAUNCH_CHECK();
-    bsclip_launch_slab_reduce_add(workspace, blocks, 16 * H, dA, dB, 8 * H, s);
-    BSCLIP_LAUNCH_CHECK();
-    return BSCLIP_OK;
-}
-
 extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx,
                                    const float* lse, int B, int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv,
                                    float dropout_p, uint32_t dropout_seed, void* stream) {
@@ -943,6 +830,11 @@ extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dc
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (g_exact_attn_impl == 0) {
+        bsclip_launch_attn_bwd_x3(qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx, lse, B, S, heads, key_bias, scale, dqkv, ld_dqkv, drop, s);
+        BSCLIP_LAUNCH_CHECK();
+        return BSCLIP_OK;
+    }
+    if (g_exact_attn_impl == 2) {
         if (drop.thr16)
             hipLaunchKernelGGL((attn_bwd_mf32_kernel<true>), dim3(B * heads), dim3(MF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx,
                                lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop);

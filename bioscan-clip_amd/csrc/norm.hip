@@ -67,7 +67,10 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
                                                                   float* __restrict__ y_f32,
                                                                   const float* __restrict__ lora_a,
                                                                   float* __restrict__ stats, DropCfg drop,
-                                                                  bf16_t* __restrict__ t_aug = nullptr, int ld_t = 0) {
+                                                                  bf16_t* __restrict__ t_aug = nullptr, int ld_t = 0,
+                                                                  bf16_t* __restrict__ y3 = nullptr, int ld_y3 = 0) {
+    // y3 (exact mode, round 5): the output as the split-bf16 GEMM operand [hi | lo | hi] (bf16 [M, 3H]) -- what a stand-alone
+    // split3_rows pass over y_f32 used to produce
     constexpr int NV = H / 256;
     BSCLIP_DROP_RESOLVE(drop);
     const int lane = threadIdx.x & 63;
@@ -125,6 +128,20 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_fwd_kernel(const void* __r
             for (int j = 0; j < NV; ++j)
                 st_stream(y_f32 + (size_t)row * H + j * 256 + lane * 4, v[j]);
         }
+        if (y3) {
+            bf16_t* r3 = y3 + (size_t)row * ld_y3 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                uint2 hi, lo;
+                hi.x = pack_bf2(v[j][0], v[j][1]);
+                hi.y = pack_bf2(v[j][2], v[j][3]);
+                lo.x = pack_bf2(v[j][0] - bf2f(hi.x & 0xffff), v[j][1] - bf2f(hi.x >> 16));
+                lo.y = pack_bf2(v[j][2] - bf2f(hi.y & 0xffff), v[j][3] - bf2f(hi.y >> 16));
+                st_stream(r3 + j * 256, hi);
+                st_stream(r3 + H + j * 256, lo);
+                st_stream(r3 + 2 * H + j * 256, hi);
+            }
+        }
         if (y_bf16) {
             bf16_t* yr = y_bf16 + (size_t)row * ld_y;
             if constexpr (Y_FP8) {
@@ -179,7 +196,9 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
     // resid_flags: bit 0 = g_resid is bf16, bit 1 = dx_res is bf16 (the residual-gradient stream kept in bf16: 2 instead of
     // 4 bytes per element read and written by every LayerNorm backward -- the kernel is HBM-bound)
     // bit 2 = g_gemm is f32, bit 3 = the operand output ("dx_bf16") is f32: the exact backward (exact.hip) keeps both in f32
-    const bool gr_bf16 = resid_flags & 1, dr_bf16 = resid_flags & 2, gg_f32 = resid_flags & 4, op_f32 = resid_flags & 8;
+    // bit 4 (exact mode, round 5) = the operand output is the split-bf16 GEMM operand [hi | lo | hi] (bf16 [M, ld_dxb >= 3H]) instead of
+    //         the f32 tensor a stand-alone split3_rows pass would read
+    const bool gr_bf16 = resid_flags & 1, dr_bf16 = resid_flags & 2, gg_f32 = resid_flags & 4, op_f32 = resid_flags & 8, op_s3 = resid_flags & 16;
     BSCLIP_DROP_RESOLVE(drop);
     BSCLIP_DROP_RESOLVE(in_drop);
     constexpr int NV = H / 256;
@@ -279,6 +298,18 @@ __global__ __launch_bounds__(LN_BLOCK) void layernorm_bwd_kernel(const void* __r
             if (dx_bf16) {
                 // gradient w.r.t. the output of the Linear whose forward result was dropped with this (p, seed)
                 if (drop.thr16) d = drop4(drop, (unsigned)row * H + j * 256 + lane * 4, d);
+                if (op_s3) {
+                    bf16_t* r3 = static_cast<bf16_t*>(dx_bf16) + (size_t)row * ld_dxb + j * 256 + lane * 4;
+                    uint2 hi, lo;
+                    hi.x = pack_bf2(d[0], d[1]);
+                    hi.y = pack_bf2(d[2], d[3]);
+                    lo.x = pack_bf2(d[0] - bf2f(hi.x & 0xffff), d[1] - bf2f(hi.x >> 16));
+                    lo.y = pack_bf2(d[2] - bf2f(hi.y & 0xffff), d[3] - bf2f(hi.y >> 16));
+                    st_stream(r3, hi);
+                    st_stream(r3 + H, lo);
+                    st_stream(r3 + 2 * H, hi);
+                    continue;
+                }
                 if (op_f32) {
                     st_stream(static_cast<float*>(dx_bf16) + (size_t)row * ld_dxb + j * 256 + lane * 4, d);
                     continue;
@@ -348,18 +379,20 @@ int ln_grid(int M, int resident_per_cu = 8) {
 
 #define LN_FWD_LAUNCH(HH, XB, LO)                                                                              \
     hipLaunchKernelGGL((layernorm_fwd_kernel<HH, XB, LO>), dim3(ln_grid(M, LO ? 5 : 8)), dim3(LN_BLOCK), 0, s, x, ld_x, M, \
-                       gamma, beta, eps, static_cast<bf16_t*>(y_bf16), ld_y, y_f32, lora_a, stats, drop)
+                       gamma, beta, eps, static_cast<bf16_t*>(y_bf16), ld_y, y_f32, lora_a, stats, drop,               \
+                       static_cast<bf16_t*>(nullptr), 0, static_cast<bf16_t*>(y_split3), ld_y3)
 
 extern "C" int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma,
-                                    const float* beta, float eps, void* y_bf16, int ld_y, float* y_f32,
-                                    const float* lora_a, float* stats, float dropout_p, uint32_t dropout_seed,
-                                    void* stream) {
+                                    const float* beta, float eps, void* y_bf16, int ld_y, float* y_f32, void* y_split3, int ld_y3,
+                                    const float* lora_a, float* stats, float dropout_p, uint32_t dropout_seed, void* stream) {
     BSCLIP_REQUIRE(x && gamma && beta && M > 0, "bsclip_layernorm_fwd: null/empty input");
     BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_fwd: H=%d (supported: 768, 512)", H);
     BSCLIP_REQUIRE(ld_x >= H && ld_x % 4 == 0, "bsclip_layernorm_fwd: ld_x=%d", ld_x);
     BSCLIP_REQUIRE(!y_bf16 || (ld_y % 4 == 0 && ld_y >= H + (lora_a ? BSCLIP_KPAD : 0)),
                    "bsclip_layernorm_fwd: ld_y=%d too small for H=%d%s", ld_y, H, lora_a ? "+KPAD" : "");
     BSCLIP_REQUIRE(!lora_a || y_bf16, "bsclip_layernorm_fwd: lora_a needs y_bf16");
+    BSCLIP_REQUIRE(!y_split3 || (ld_y3 >= 3 * H && ld_y3 % 4 == 0 && (reinterpret_cast<uintptr_t>(y_split3) & 7) == 0),
+                   "bsclip_layernorm_fwd: y_split3 bf16 [M, ld_y3 >= 3H], 8-byte aligned (ld_y3=%d)", ld_y3);
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_layernorm_fwd: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -417,12 +450,12 @@ extern "C" int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const f
     BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_layernorm_bwd: H=%d (supported: 768, 512)", H);
     BSCLIP_REQUIRE(g_resid || g_gemm, "bsclip_layernorm_bwd: no incoming gradient");
     BSCLIP_REQUIRE(mode == 0 || mode == 1, "bsclip_layernorm_bwd: mode=%d", mode);
-    BSCLIP_REQUIRE(resid_flags >= 0 && resid_flags <= 15, "bsclip_layernorm_bwd: resid_flags=%d", resid_flags);
+    BSCLIP_REQUIRE(resid_flags >= 0 && resid_flags <= 31 && !((resid_flags & 16) && (resid_flags & 8)), "bsclip_layernorm_bwd: resid_flags=%d", resid_flags);
     BSCLIP_REQUIRE((dt == nullptr) == (lora_a == nullptr), "bsclip_layernorm_bwd: dt and lora_a go together");
     BSCLIP_REQUIRE(!g_gemm || (ld_g >= H && ld_g % 4 == 0), "bsclip_layernorm_bwd: ld_g=%d", ld_g);
     BSCLIP_REQUIRE(!g_resid || (ld_gr >= H && ld_gr % 4 == 0), "bsclip_layernorm_bwd: ld_gr=%d", ld_gr);
     BSCLIP_REQUIRE(!dx_f32 || (ld_dx >= H && ld_dx % 4 == 0), "bsclip_layernorm_bwd: ld_dx=%d", ld_dx);
-    BSCLIP_REQUIRE(!dx_bf16 || (ld_dxb >= H && ld_dxb % 4 == 0), "bsclip_layernorm_bwd: ld_dxb=%d", ld_dxb);
+    BSCLIP_REQUIRE(!dx_bf16 || (ld_dxb >= ((resid_flags & 16) ? 3 * H : H) && ld_dxb % 4 == 0), "bsclip_layernorm_bwd: ld_dxb=%d", ld_dxb);
     BSCLIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "bsclip_layernorm_bwd: dropout_p=%f", dropout_p);
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     BSCLIP_REQUIRE(in_dropout_p >= 0.f && in_dropout_p < 1.f, "bsclip_layernorm_bwd: in_dropout_p=%f", in_dropout_p);

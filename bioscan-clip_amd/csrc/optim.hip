@@ -5,6 +5,8 @@
 //   adamw     : torch.optim.AdamW defaults (scripts/train_cl.py:158), one launch over the flat trainable buffer.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -69,12 +71,17 @@ __device__ __forceinline__ float reduce4(float (&p)[4], int lane) {
 // The waves of a workgroup come in pairs: the even wave of a pair owns the q half of a row (dq, B_q, t_q), the odd wave the v
 // half.  With both halves in one wave the kernel held 2 x (B + accumulators) = 192 VGPRs plus the rows in flight and ran at two
 // waves per SIMD, HBM latency exposed (59 us for 155 MB); a half is 96 + rows, three waves per SIMD.
-template <int H>
-__global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t* __restrict__ dqkv, int ld,
-                                                                    const bf16_t* __restrict__ haug, int ld_h, int M,
+// F32IN (exact mode, round 5): dqkv is f32 [M, ld] and t comes from an f32 [M, 8] buffer (haug = that buffer, ld_h = 8) -- the same
+// kernel on the exact backward's operands; the first f32 version (one workgroup per row group, 16 wave reductions per row, two
+// barriers per four rows) took 640 us per layer at B = 256 against this kernel's 41 us on bf16 rows.
+template <int H, bool F32IN = false>
+__global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const void* __restrict__ dqkv_, int ld,
+                                                                    const void* __restrict__ haug_, int ld_h, int M,
                                                                     const float* __restrict__ lora_b,
                                                                     float* __restrict__ dt,
                                                                     float* __restrict__ partial) {
+    const bf16_t* dqkv = static_cast<const bf16_t*>(dqkv_);
+    const bf16_t* haug = static_cast<const bf16_t*>(haug_);
     constexpr int NV = H / 256;
     __shared__ float red[2 * NV * 16 * 64];
     const int lane = threadIdx.x & 63;
@@ -97,26 +104,41 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t*
 
     // Rows are software-pipelined three deep: a wave keeps the loads of its next PF half-rows in flight while it reduces one.
     constexpr int PF = 3;
-    uint2 rx[PF][NV];
-    uint2 rt[PF];
+    using row_t = std::conditional_t<F32IN, f32x4, uint2>;
+    row_t rx[PF][NV];
+    row_t rt[PF];
     auto fetch = [&](int slot, int row) {
-        const bf16_t* g = dqkv + (size_t)row * ld + is_v * 2 * H;
+        if constexpr (F32IN) {
+            const float* g = static_cast<const float*>(dqkv_) + (size_t)row * ld + is_v * 2 * H;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) rx[slot][j] = *reinterpret_cast<const uint2*>(g + j * 256 + lane * 4);
-        rt[slot] = *reinterpret_cast<const uint2*>(haug + (size_t)row * ld_h + H + 4 * is_v);  // this half's t (4), broadcast
+            for (int j = 0; j < NV; ++j) rx[slot][j] = *reinterpret_cast<const f32x4*>(g + j * 256 + lane * 4);
+            rt[slot] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(haug_) + (size_t)row * ld_h + 4 * is_v);
+        } else {
+            const bf16_t* g = dqkv + (size_t)row * ld + is_v * 2 * H;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) rx[slot][j] = *reinterpret_cast<const uint2*>(g + j * 256 + lane * 4);
+            rt[slot] = *reinterpret_cast<const uint2*>(haug + (size_t)row * ld_h + H + 4 * is_v);  // this half's t (4), broadcast
+        }
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p)
         if (pair + p * npairs < M) fetch(p, pair + p * npairs);
     auto body = [&](int slot, int row) {
         f32x4 dx[NV];
+        f32x4 tx;
+        if constexpr (F32IN) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j)
-            dx[j] = f32x4{bf2f(rx[slot][j].x & 0xffff), bf2f(rx[slot][j].x >> 16), bf2f(rx[slot][j].y & 0xffff),
-                          bf2f(rx[slot][j].y >> 16)};
-        const uint2 tu = rt[slot];
+            for (int j = 0; j < NV; ++j) dx[j] = rx[slot][j];
+            tx = rt[slot];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                dx[j] = f32x4{bf2f(rx[slot][j].x & 0xffff), bf2f(rx[slot][j].x >> 16), bf2f(rx[slot][j].y & 0xffff),
+                              bf2f(rx[slot][j].y >> 16)};
+            const uint2 tu = rt[slot];
+            tx = f32x4{bf2f(tu.x & 0xffff), bf2f(tu.x >> 16), bf2f(tu.y & 0xffff), bf2f(tu.y >> 16)};
+        }
         if (row + PF * npairs < M) fetch(slot, row + PF * npairs);
-        const f32x4 tx = {bf2f(tu.x & 0xffff), bf2f(tu.x >> 16), bf2f(tu.y & 0xffff), bf2f(tu.y >> 16)};
         f32x4 px = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NV; ++j)
@@ -155,10 +177,11 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const bf16_t*
 }
 
 // pass 2: dA[8,H] += dt^T y.  Y_FP8: y is the fp8 e4m3 LN output (row stride ld_h bytes) instead of bf16.
-template <int H, bool Y_FP8 = false>
-__global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __restrict__ haug, int ld_h, int M,
+template <int H, bool Y_FP8 = false, bool Y_F32 = false>
+__global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const void* __restrict__ haug_, int ld_h, int M,
                                                                  const float* __restrict__ dt,
                                                                  float* __restrict__ partial) {
+    const bf16_t* haug = static_cast<const bf16_t*>(haug_);
     constexpr int NV = H / 256;
     __shared__ float red[8 * NV * 4 * 64];
     const int lane = threadIdx.x & 63;
@@ -174,7 +197,7 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __
     constexpr int PF = 3;
     for (int row0 = wave; row0 < M; row0 += PF * nwaves) {
         f32x4 d0[PF], d1[PF];
-        uint2 yr[PF][NV];
+        std::conditional_t<Y_F32, f32x4, uint2> yr[PF][NV];
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int row = min(row0 + p * nwaves, M - 1);
@@ -182,7 +205,9 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __
             d1[p] = *reinterpret_cast<const f32x4*>(dt + (size_t)row * 8 + 4);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                if constexpr (Y_FP8) {
+                if constexpr (Y_F32) {
+                    yr[p][j] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(haug_) + (size_t)row * ld_h + j * 256 + lane * 4);
+                } else if constexpr (Y_FP8) {
                     yr[p][j].x = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(haug) +
                                                                     (size_t)row * ld_h + j * 256 + lane * 4);
                     yr[p][j].y = 0;
@@ -197,7 +222,9 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 f32x4 y;
-                if constexpr (Y_FP8)
+                if constexpr (Y_F32)
+                    y = yr[p][j];
+                else if constexpr (Y_FP8)
                     y = f32x4{fp8_to_f32(yr[p][j].x, 0), fp8_to_f32(yr[p][j].x, 1), fp8_to_f32(yr[p][j].x, 2), fp8_to_f32(yr[p][j].x, 3)};
                 else
                     y = f32x4{bf2f(yr[p][j].x & 0xffff), bf2f(yr[p][j].x >> 16), bf2f(yr[p][j].y & 0xffff), bf2f(yr[p][j].y >> 16)};
@@ -224,6 +251,39 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const bf16_t* __
     __syncthreads();
     for (int idx = threadIdx.x; idx < 8 * NV * 4 * 64; idx += LG_BLOCK)
         partial[(size_t)blockIdx.x * (8 * NV * 4 * 64) + idx] = red[idx];
+}
+
+// t[row, 0:8] = y[row, :] . A[0:8, :]^T in f32 (exact mode: the forward folds W + B A into the weight, so t is rebuilt for the backward):
+// one wave per row, A in LDS as in the LayerNorm kernels
+template <int H>
+__global__ __launch_bounds__(LG_BLOCK) void lora_t_f32_kernel(const float* __restrict__ y, int ld_y, int M, const float* __restrict__ A,
+                                                              float* __restrict__ t) {
+    constexpr int NV = H / 256;
+    __shared__ __attribute__((aligned(16))) float sA[8 * H];
+    for (int i = threadIdx.x * 4; i < 8 * H; i += LG_BLOCK * 4) *reinterpret_cast<f32x4*>(sA + i) = *reinterpret_cast<const f32x4*>(A + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LG_BLOCK + threadIdx.x) >> 6, nwaves = (gridDim.x * LG_BLOCK) >> 6;
+    for (int row = wave; row < M; row += nwaves) {
+        asm volatile("" ::: "memory");   // sA is loop-invariant: keep its reads out of the registers
+        f32x4 v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(y + (size_t)row * ld_y + j * 256 + lane * 4);
+        float p[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sA + r * H + j * 256 + lane * 4);
+                d += (v[j][0] * a[0] + v[j][1] * a[1]) + (v[j][2] * a[2] + v[j][3] * a[3]);
+            }
+            p[r] = d;
+        }
+        const float tt = reduce8(p, lane);  // lane group (bits 5,4,3) owns r
+        const float tl = __shfl(tt, ((lane >> 2) & 1) * 32 + ((lane >> 1) & 1) * 16 + (lane & 1) * 8, 64);
+        if (lane < 8) t[(size_t)row * 8 + lane] = tl;
+    }
 }
 
 // Sum the per-workgroup slabs in a fixed order (bitwise reproducible) and accumulate into dBq/dBv/dA.
@@ -432,6 +492,48 @@ extern "C" int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, in
         hipLaunchKernelGGL((lora_grad_da_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, pb);
         hipLaunchKernelGGL((lora_grad_reduce_kernel<512>), dim3(16 * 512 / 32), dim3(256), 0, s, pa, pb,
                            blocks, dA, dBq, dBv);
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+// exact mode (BSCLIP_PARITY=2): f32 dq / dv and the f32 LayerNorm output y; t = A y is rebuilt (the forward folds W + B A), then the
+// kernels of bsclip_lora_grad on f32 rows.  workspace: [t: 8 M][dt: 8 M][slabs: LG_MAX_BLOCKS * 16 H] floats.
+// Reference lora_layer.py:16-39 / image_encoder.py:44-47 / dna_encoder.py:47-49:
+//   u_q = B_q^T dq, u_v = B_v^T dv;  dA_q += u_q y^T, dA_v += u_v y^T, dB_q += dq t_q^T, dB_v += dv t_v^T
+extern "C" int64_t bsclip_lora_grad_f32_workspace_floats(int M, int H) {
+    return M > 0 && H > 0 ? 16 * (int64_t)((M + 3) / 4 * 4) + (int64_t)LG_MAX_BLOCKS * 16 * H : -1;
+}
+
+extern "C" int bsclip_lora_grad_f32(const float* dqkv, int ld_dqkv, const float* y, int ld_y, int M, int H, const float* lora_a,
+                                    const float* lora_b, float* dA, float* dB, float* workspace, void* stream) {
+    BSCLIP_REQUIRE(dqkv && y && lora_a && lora_b && dA && dB && workspace, "bsclip_lora_grad_f32: null pointer");
+    BSCLIP_REQUIRE(M > 0 && (H == 768 || H == 512) && ld_dqkv >= 3 * H && ld_dqkv % 4 == 0 && ld_y >= H && ld_y % 4 == 0,
+                   "bsclip_lora_grad_f32: M=%d H=%d ld_dqkv=%d ld_y=%d", M, H, ld_dqkv, ld_y);
+    BSCLIP_REQUIRE(((reinterpret_cast<uintptr_t>(dqkv) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(lora_a) |
+                     reinterpret_cast<uintptr_t>(lora_b) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
+                   "bsclip_lora_grad_f32: dqkv, y, lora_a, lora_b and workspace must be 16-byte aligned (vector loads)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int blocks = ceil_div(M, 4 * 8);
+    if (blocks > LG_MAX_BLOCKS) blocks = LG_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    const size_t Mp = (size_t)(M + 3) / 4 * 4;
+    float* t = workspace;
+    float* dt = workspace + 8 * Mp;
+    float* pa = workspace + 16 * Mp;
+    float* pb = pa + (size_t)LG_MAX_BLOCKS * 8 * H;
+    float* dBq = dB;
+    float* dBv = dB + (size_t)H * 4;
+    if (H == 768) {
+        hipLaunchKernelGGL((lora_t_f32_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, y, ld_y, M, lora_a, t);
+        hipLaunchKernelGGL((lora_grad_dt_db_kernel<768, true>), dim3(blocks), dim3(LG_BLOCK), 0, s, dqkv, ld_dqkv, t, 8, M, lora_b, dt, pa);
+        hipLaunchKernelGGL((lora_grad_da_kernel<768, false, true>), dim3(blocks), dim3(LG_BLOCK), 0, s, y, ld_y, M, dt, pb);
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<768>), dim3(16 * 768 / 32), dim3(256), 0, s, pa, pb, blocks, dA, dBq, dBv);
+    } else {
+        hipLaunchKernelGGL((lora_t_f32_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, y, ld_y, M, lora_a, t);
+        hipLaunchKernelGGL((lora_grad_dt_db_kernel<512, true>), dim3(blocks), dim3(LG_BLOCK), 0, s, dqkv, ld_dqkv, t, 8, M, lora_b, dt, pa);
+        hipLaunchKernelGGL((lora_grad_da_kernel<512, false, true>), dim3(blocks), dim3(LG_BLOCK), 0, s, y, ld_y, M, dt, pb);
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<512>), dim3(16 * 512 / 32), dim3(256), 0, s, pa, pb, blocks, dA, dBq, dBv);
     }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;

@@ -178,6 +178,8 @@ int bsclip_attn_bwd_pers_diag(const void* qkv, int ld_qkv, const void* dctx, int
  *   y_bf16 [M, ld_y]  (nullable): bf16(y) in cols [0,H); if lora_a != NULL cols [H,H+8) = bf16(y . lora_a^T) and
  *                     cols [H+8, H+BSCLIP_KPAD) = 0 (the K-augmentation block consumed by the QKV GEMM).
  *   y_f32  [M, H]     (nullable): f32 copy (post-LN residual stream of BERT).
+ *   y_split3 [M, ld_y3 >= 3H] bf16 (nullable; exact mode, ABI 9): the output as the A operand of a split-bf16 GEMM, [hi | lo | hi] with
+ *                     hi = bf16(y), lo = bf16(y - hi) -- what bsclip_split3_rows makes of y_f32 in a second pass.
  *   stats  [M, 2]     (nullable): (mean, rstd) saved for backward.
  *   x_bf16 != 0: x is bf16 [M, ld_x] instead of f32 (MLM transform LN after GELU).
  * bwd (gamma/beta frozen -> only dx): dy = g_resid(f32, nullable) + g_gemm(bf16, nullable) + dt[M,8] . lora_a
@@ -191,7 +193,7 @@ int bsclip_attn_bwd_pers_diag(const void* qkv, int ld_qkv, const void* dctx, int
  *   in_dropout_p > 0 (full fine-tuning, BertEmbeddings): the LN's own OUTPUT was dropped in forward with (p, seed); the
  *   assembled dy is masked the same way before it is differentiated. */
 int bsclip_layernorm_fwd(const void* x, int ld_x, int x_bf16, int M, int H, const float* gamma, const float* beta,
-                         float eps, void* y_bf16, int ld_y, float* y_f32, const float* lora_a, float* stats,
+                         float eps, void* y_bf16, int ld_y, float* y_f32, void* y_split3, int ld_y3, const float* lora_a, float* stats,
                          float dropout_p, uint32_t dropout_seed, void* stream);
 /* fp8 operand variant (configs[4]): y_fp8 [M, ld_y bytes] = e4m3(LN(x)) (scale 1, saturated), t_aug bf16 [M, ld_t] = the LoRA
  * block (t in cols [0,8), zeros to col 64) when lora_a != NULL -- the operands of bsclip_gemm_fp8.  Other arguments as above. */
@@ -199,7 +201,9 @@ int bsclip_layernorm_fwd_fp8(const void* x, int ld_x, int x_bf16, int M, int H, 
                              float eps, void* y_fp8, int ld_y, void* t_aug, int ld_t, float* y_f32, const float* lora_a,
                              float* stats, float dropout_p, uint32_t dropout_seed, void* stream);
 /* resid_flags: the residual-gradient stream (g_resid in, dx_f32 out) may be kept in bf16 -- bit 0: g_resid is bf16 [M, ld_gr],
- *   bit 1: dx_f32 points to a bf16 [M, ld_dx] buffer (the undropped gradient, rounded once); 0 = both f32. */
+ *   bit 1: dx_f32 points to a bf16 [M, ld_dx] buffer (the undropped gradient, rounded once); 0 = both f32.
+ *   Exact mode: bit 2: g_gemm is f32; bit 3: the operand output dx_bf16 is f32 [M, ld_dxb]; bit 4 (ABI 9, excludes bit 3): the operand
+ *   output is the split-bf16 GEMM operand [hi | lo | hi], bf16 [M, ld_dxb >= 3H]. */
 int bsclip_layernorm_bwd(const void* x, int ld_x, int x_bf16, const float* stats, const float* gamma, int M, int H,
                          const void* g_resid, int ld_gr, const void* g_gemm, int ld_g, const float* dt,
                          const float* lora_a, int mode, void* dx_f32, int ld_dx, void* dx_bf16, int ld_dxb,
@@ -251,7 +255,8 @@ int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, c
  *   softmax_meanpool_bwd_f32: bsclip_softmax_meanpool_bwd with f32 dlogits [B*S, ld_d]
  *   lora_grad_f32: dA [8, H] += (B^T dq | B^T dv) y^T, dB [2, H, 4] += (dq | dv)^T (A y) from dqkv f32 [M, ld_dqkv] ([dq | dk | dv]) and
  *                  the LayerNorm output y f32 [M, ld_y] (reference lora_layer.py:16-39); workspace:
- *                  bsclip_lora_grad_f32_workspace_floats(H) floats; sums in a fixed order
+ *                  bsclip_lora_grad_f32_workspace_floats(M, H) floats (t and dt [M, 8] + the per-workgroup slabs); sums in a fixed order
+ *                  (round 5: t = A y by one pass, then bsclip_lora_grad's pipelined wave-per-row kernels on f32 rows)
  *   attn_bwd_f32:  dqkv f32 [B*S, ld_dqkv] from qkv f32, dctx f32, the forward's ctx f32 (delta = dctx . ctx) and lse; f32-operand
  *                  MFMA, the forward's dropout masks; argument meaning as bsclip_attn_bwd.
  * bsclip_layernorm_bwd takes the f32 GEMM gradient / writes the f32 operand through resid_flags bits 2 / 3. */
@@ -269,11 +274,12 @@ int bsclip_split3_transpose(const float* src, int ld_src, int R, int C, int Rp, 
                             void* dst, int ld_dst, void* stream);
 int bsclip_softmax_meanpool_bwd_f32(const float* logits, const float* stats, const float* d_pooled, int B, int S, int C, float* dlogits,
                                     int ld_d, void* stream);
-int64_t bsclip_lora_grad_f32_workspace_floats(int H);
+int64_t bsclip_lora_grad_f32_workspace_floats(int M, int H);
 int bsclip_lora_grad_f32(const float* dqkv, int ld_dqkv, const float* y, int ld_y, int M, int H, const float* lora_a, const float* lora_b,
                          float* dA, float* dB, float* workspace, void* stream);
-/* 0 (default) = f32 attention on the matrix pipe (v_mfma_f32_32x32x2_f32), 1 = the one-row-per-thread vector-ALU kernels (a second
- * implementation of the same arithmetic, kept to test against; 2 - 4 x slower) */
+/* 0 (default, round 5) = split-bf16 operands on the bf16 matrix cores (csrc/attn_x3.hip: every product as hi.hi + lo.hi + hi.lo, f32 softmax
+ * arithmetic; ~2^-16 per product, 16 x the f32 MFMA rate), 2 = f32 operands on the matrix pipe (v_mfma_f32_32x32x2_f32, round 4's default),
+ * 1 = the one-row-per-thread vector-ALU kernels -- 1 and 2 are exact-f32 second implementations kept to test against */
 int bsclip_exact_attn_set_impl(int impl);
 int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx, const float* lse, int B,
                         int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv, float dropout_p,
