@@ -148,7 +148,7 @@ int bsclip_gemm_pers_diag(const void* A, int lda, const void* B, int ldb, void* 
  * diag[B*heads*4*8]; tools/attn_phases.py */
 int bsclip_attn_bwd_diag(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
                          int heads, float scale, void* dqkv, int ld_dqkv, unsigned long long* diag, void* stream);
-/* Round 4 experiment, NOT a product kernel since ABI 9 (the pair is a wash against bsclip_attn_fwd / bsclip_attn_bwd):
+/* Round 4 experiment, NOT a product kernel since ABI 9 (the pair is a wash against bsclip_attn_fwd / bsclip_attn_bwd, docs/HISTORY.md 6.0):
  * the same attention with a backward that forms every product once (csrc/attn_sweep.hip: key-owner waves sweep the query
  * blocks, a dQ wave follows; 20 MFMAs + 16 exp per 32x32 tile pair instead of 32 + 32).  delta = rowsum(P . dP) is taken from
  * the forward's OUTPUT, which therefore leaves O to 16 mantissa bits -- ctx = bf16(O) (the out-projection's operand, as before)
