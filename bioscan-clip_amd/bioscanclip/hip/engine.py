@@ -479,7 +479,7 @@ class ViTEngine(EncoderEngineBase):
             ops.layernorm_fwd(x[2 * l], lay.ln1[0], lay.ln1[1], 1e-6, y_f32=y32, y_split3=a3, stats=ws["st1"][l])
             ops.split3_weight(lay.qkv32, lay.wqkv3, lora_a=self.lora_a(l) if has else None, lora_b=self.lora_b(l) if has else None)
             self._ex_gemm3(a3, lay.wqkv3, qkv32, EPI_F32, M, bias=lay.b_qkv)
-            ops.attn_fwd_f32(qkv32, B, S, self.heads, scale, ctx32, ws["lse"][l])
+            ops.attn_fwd_f32(qkv32, B, S, self.heads, scale, ctx32, ws["lse"][l], ctx_split3=a3 if l < L - 1 else None)
             if l == L - 1:   # token-0 rows only, as the default path (and as its backward expects)
                 self._ex_gemm(tok0(ctx32, H), lay.w3[0], tok0(x[2 * l + 1], H), EPI_RESID_F32, a3, bias=lay.b_proj,
                               resid=tok0(x[2 * l], H))
@@ -489,7 +489,7 @@ class ViTEngine(EncoderEngineBase):
                 g3 = ops.gelu_split3(z32, a3, M=B)
                 ops.gemm(g3, lay.w3[2], tok0(x[2 * l + 2], H), EPI_RESID_F32, bias=lay.b_fc2, resid=tok0(x[2 * l + 1], H), M=B)
                 continue
-            self._ex_gemm(ctx32, lay.w3[0], x[2 * l + 1], EPI_RESID_F32, a3, bias=lay.b_proj, resid=x[2 * l])
+            self._ex_gemm3(a3, lay.w3[0], x[2 * l + 1], EPI_RESID_F32, M, bias=lay.b_proj, resid=x[2 * l])   # a3: written by the attention kernel
             ops.layernorm_fwd(x[2 * l + 1], lay.ln2[0], lay.ln2[1], 1e-6, y_split3=a3, stats=ws["st2"][l])
             self._ex_gemm3(a3, lay.w3[1], z32, EPI_F32, M, bias=lay.b_fc1)
             g3 = ops.gelu_split3(z32, a3)
@@ -662,7 +662,8 @@ class ViTEngine(EncoderEngineBase):
                 ops.gemm(g3, lay.w3t[1], ws["dh32"], EPI_F32)
                 ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh32"], dx_f32=dx, dx_split3=a3)
                 self._ex_gemm3(a3, lay.w3t[0], ws["dctx32"], EPI_F32, M)
-            ops.attn_bwd_f32(ws["qkv32s"][l], ws["dctx32"], ws["ctx32s"][l], ws["lse"][l], B, S, self.heads, scale, ws["dqkv32"])
+            ops.attn_bwd_f32(ws["qkv32s"][l], ws["dctx32"], ws["ctx32s"][l], ws["lse"][l], B, S, self.heads, scale, ws["dqkv32"],
+                             dqkv_split3=a3 if l > 0 else None)      # the QKV dX GEMM's operand, written split by the attention kernel
             has = self._lora_index[l] is not None
             if has:
                 ops.lora_grad_f32(ws["dqkv32"], ws["y32s"][l], M, H, self.lora_a(l), self.lora_b(l), self.lora_a(l, grad=True),
@@ -670,7 +671,7 @@ class ViTEngine(EncoderEngineBase):
             if l > 0:  # nothing trainable sits below block 0
                 wt = ops.split3_transpose(lay.qkv32, lay.wqkvT3, 1, lora_a=self.lora_a(l) if has else None,
                                           lora_b=self.lora_b(l) if has else None)
-                self._ex_gemm(ws["dqkv32"], wt, ws["dh32"], EPI_F32, a3)
+                self._ex_gemm3(a3, wt, ws["dh32"], EPI_F32, M)
                 ops.layernorm_bwd(x[2 * l], ws["st1"][l], lay.ln1[0], 0, g_resid=dx, g_gemm=ws["dh32"], dx_f32=dx, dx_split3=a3)
                 dx3 = True
 
@@ -893,9 +894,9 @@ class BertEngine(EncoderEngineBase):
             ops.split3_weight(lay.qkv32, lay.wqkv3, lora_a=self.lora_a(l) if has else None, lora_b=self.lora_b(l) if has else None)
             self._ex_gemm3(a3, lay.wqkv3, qkv32, EPI_F32, M, bias=lay.b_qkv)     # a3 = split of ys[l], written by the LayerNorm before
             ops.attn_fwd_f32(qkv32, B, S, self.heads, 0.125, ctx32, ws["lse"][l], key_bias=key_bias,
-                             dropout=self._drop(ws, self.p_attn, l, 1))
-            self._ex_gemm(ctx32, lay.w3[0], ws["s1"][l], EPI_RESID_F32, a3, bias=lay.b_o, resid=ys[l],
-                          dropout=self._drop(ws, self.p_hidden, l, 2))
+                             dropout=self._drop(ws, self.p_attn, l, 1), ctx_split3=a3)
+            self._ex_gemm3(a3, lay.w3[0], ws["s1"][l], EPI_RESID_F32, M, bias=lay.b_o, resid=ys[l],
+                           dropout=self._drop(ws, self.p_hidden, l, 2))
             ops.layernorm_fwd(ws["s1"][l], lay.ln_a[0], lay.ln_a[1], self.eps, y_f32=ws["ym"], y_split3=a3, stats=ws["sta"][l])
             self._ex_gemm3(a3, lay.w3[1], z32, EPI_F32, M, bias=lay.b_fc1)
             g3 = ops.gelu_split3(z32, a3)
@@ -961,7 +962,7 @@ class BertEngine(EncoderEngineBase):
                               dx_split3=a3, dropout=drop_a)
             self._ex_gemm3(a3, lay.w3t[0], ws["dctx32"], EPI_F32, M)
             ops.attn_bwd_f32(ws["qkv32s"][l], ws["dctx32"], ws["ctx32s"][l], ws["lse"][l], B, S, self.heads, 0.125, ws["dqkv32"],
-                             key_bias=ws["key_bias"], dropout=self._drop(ws, self.p_attn, l, 1))
+                             key_bias=ws["key_bias"], dropout=self._drop(ws, self.p_attn, l, 1), dqkv_split3=a3 if l > 0 else None)
             has = self._lora_index[l] is not None
             if has:
                 ops.lora_grad_f32(ws["dqkv32"], ys[l], M, H, self.lora_a(l), self.lora_b(l), self.lora_a(l, grad=True),
@@ -969,7 +970,7 @@ class BertEngine(EncoderEngineBase):
             if l > 0:  # embeddings are frozen: nothing to do below layer 0
                 wt = ops.split3_transpose(lay.qkv32, lay.wqkvT3, 1, lora_a=self.lora_a(l) if has else None,
                                           lora_b=self.lora_b(l) if has else None)
-                self._ex_gemm(ws["dqkv32"], wt, ws["dh32"], EPI_F32, a3)
+                self._ex_gemm3(a3, wt, ws["dh32"], EPI_F32, M)
                 g_resid, g_gemm = ws["ds1"], ws["dh32"]
         ops.set_dropout_step(None)
 

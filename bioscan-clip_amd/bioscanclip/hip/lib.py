@@ -60,13 +60,13 @@ SIGNATURES = {
     "bsclip_split3_weight": (I, [P, I, I, I, P, P, I, P, I, P]),
     "bsclip_gelu_split3": (I, [P, I, I, I, P, I, P, I, P, I, P]),
     "bsclip_meanpool_tokens_f32": (I, [P, I, I, I, P, P]),
-    "bsclip_attn_fwd_f32": (I, [P, I, I, I, I, P, F, P, I, P, F, U, P]),
+    "bsclip_attn_fwd_f32": (I, [P, I, I, I, I, P, F, P, I, P, P, I, F, U, P]),
     "bsclip_dgelu_split3": (I, [P, I, P, I, I, I, P, I, P, I, P]),
     "bsclip_split3_transpose": (I, [P, I, I, I, I, I, P, P, I, P, I, P]),
     "bsclip_softmax_meanpool_bwd_f32": (I, [P, P, P, I, I, I, P, I, P]),
     "bsclip_lora_grad_f32_workspace_floats": (L, [I, I]),
     "bsclip_lora_grad_f32": (I, [P, I, P, I, I, I, P, P, P, P, P, P]),
-    "bsclip_attn_bwd_f32": (I, [P, I, P, I, P, I, P, I, I, I, P, F, P, I, F, U, P]),
+    "bsclip_attn_bwd_f32": (I, [P, I, P, I, P, I, P, I, I, I, P, F, P, I, P, I, F, U, P]),
     "bsclip_exact_attn_set_impl": (I, [I]),
     "bsclip_im2col_patch16": (I, [P, I, P, I, I, P]),
     "bsclip_mask_to_bias": (I, [P, I, P, P]),

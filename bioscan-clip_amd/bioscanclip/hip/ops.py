@@ -343,16 +343,21 @@ def meanpool_tokens_f32(x, B, S, out):
     check(_l.load().bsclip_meanpool_tokens_f32(_p(x), B, S, H, _p(out), _stream()))
 
 
-def attn_fwd_f32(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None):
+def attn_fwd_f32(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, ctx_split3=None):
+    """``ctx_split3``: bf16 [>= B S, >= 3 heads 64] that receives ctx as the out-projection GEMM's split operand [hi | lo | hi]."""
     ld_qkv, ld_ctx = _rowmajor(qkv, "qkv"), _rowmajor(ctx, "ctx")
+    ld_c3 = 0
+    if ctx_split3 is not None:
+        ld_c3 = _rowmajor(ctx_split3, "ctx_split3")
+        _req(ctx_split3.dtype == BF16 and ctx_split3.shape[0] >= B * S and ctx_split3.shape[1] >= 3 * heads * 64, "attn_fwd_f32: ctx_split3")
     _req(qkv.dtype == F32 and ctx.dtype == F32 and lse.dtype == F32, "attn_fwd_f32 dtypes")
     _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64 and ctx.shape[0] >= B * S and ctx.shape[1] >= heads * 64
          and lse.numel() >= B * heads * S, "attn_fwd_f32 shapes")
     if key_bias is not None:
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
-    check(_l.load().bsclip_attn_fwd_f32(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), ld_ctx, _p(lse), dp, ds,
-                                        _stream()))
+    check(_l.load().bsclip_attn_fwd_f32(_p(qkv), ld_qkv, B, S, heads, _p(key_bias), float(scale), _p(ctx), ld_ctx, _p(lse),
+                                        _p(ctx_split3), ld_c3, dp, ds, _stream()))
 
 
 # ---- exact backward (BSCLIP_PARITY=2): f32 gradients, split operands on the dX / dW GEMMs (csrc/exact.hip) ----
@@ -422,8 +427,13 @@ def exact_attn_set_impl(impl):
     check(_l.load().bsclip_exact_attn_set_impl(int(impl)))
 
 
-def attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None):
+def attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None, dqkv_split3=None):
+    """``dqkv_split3``: bf16 [>= B S, >= 9 heads 64] that receives [dq | dk | dv] as the QKV dX GEMM's split operand [hi | lo | hi]."""
     _req(all(t.dtype == F32 for t in (qkv, dctx, ctx, lse, dqkv)), "attn_bwd_f32 dtypes")
+    ld_d3 = 0
+    if dqkv_split3 is not None:
+        ld_d3 = _rowmajor(dqkv_split3, "dqkv_split3")
+        _req(dqkv_split3.dtype == BF16 and dqkv_split3.shape[0] >= B * S and dqkv_split3.shape[1] >= 9 * heads * 64, "attn_bwd_f32: dqkv_split3")
     _req(qkv.shape[0] >= B * S and qkv.shape[1] >= 3 * heads * 64 and dqkv.shape[0] >= B * S and dqkv.shape[1] >= 3 * heads * 64
          and ctx.shape[0] >= B * S and ctx.shape[1] >= heads * 64 and dctx.shape[0] >= B * S and dctx.shape[1] >= heads * 64
          and lse.numel() >= B * heads * S, "attn_bwd_f32 shapes")
@@ -431,8 +441,8 @@ def attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, scale, dqkv, key_bias=None, d
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
     check(_l.load().bsclip_attn_bwd_f32(_p(qkv), _rowmajor(qkv, "qkv"), _p(dctx), _rowmajor(dctx, "dctx"), _p(ctx), _rowmajor(ctx, "ctx"),
-                                        _p(lse), B, S, heads, _p(key_bias), float(scale), _p(dqkv), _rowmajor(dqkv, "dqkv"), dp, ds,
-                                        _stream()))
+                                        _p(lse), B, S, heads, _p(key_bias), float(scale), _p(dqkv), _rowmajor(dqkv, "dqkv"),
+                                        _p(dqkv_split3), ld_d3, dp, ds, _stream()))
 
 
 def im2col_patch16(image, cols):

@@ -81,11 +81,32 @@ __device__ __forceinline__ void store_dt_f32(const f32x16 (&acc)[2], float mul, 
                 f32x4{acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul, acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul};
 }
 
+// the same result as the A operand of a split-bf16 GEMM: row3[c] = hi, row3[K + c] = lo, row3[2 K + c] = hi (c = column of the [M, K] matrix:
+// the layout bsclip_split3_rows produces; hi = bf16(x), lo = bf16(x - hi)) -- the consumer GEMM needs no stand-alone split pass
+__device__ __forceinline__ void store_dt_split3(const f32x16 (&acc)[2], float mul, bf16_t* row3, int K, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float x0 = acc[dt][4 * g + 0] * mul, x1 = acc[dt][4 * g + 1] * mul, x2 = acc[dt][4 * g + 2] * mul, x3 = acc[dt][4 * g + 3] * mul;
+            uint2 hi, lo;
+            hi.x = pack_bf2(x0, x1);
+            hi.y = pack_bf2(x2, x3);
+            lo.x = pack_bf2(x0 - bf_lo(hi.x), x1 - bf_hi(hi.x));
+            lo.y = pack_bf2(x2 - bf_lo(hi.y), x3 - bf_hi(hi.y));
+            bf16_t* p = row3 + 32 * dt + 8 * g + 4 * h;
+            *reinterpret_cast<uint2*>(p) = hi;
+            *reinterpret_cast<uint2*>(p + K) = lo;
+            *reinterpret_cast<uint2*>(p + 2 * K) = hi;
+        }
+}
+
 template <int NB, bool DROP>
 __global__ __launch_bounds__(X3_WAVES * 64, 2) void attn_fwd_x3_kernel(const float* __restrict__ qkv, int ld, int S, int heads,
                                                                      const float* __restrict__ key_bias, float scale,
                                                                      float* __restrict__ ctx, int ld_ctx, float* __restrict__ lse,
-                                                                     DropCfg drop) {
+                                                                     DropCfg drop, bf16_t* __restrict__ ctx3, int ld_c3) {
     constexpr int SP = NB * 32, RM = SP * ROWB;
     BSCLIP_DROP_RESOLVE(drop);
     __shared__ __attribute__((aligned(16))) char smem[4 * RM + SP * 4];
@@ -175,6 +196,7 @@ __global__ __launch_bounds__(X3_WAVES * 64, 2) void attn_fwd_x3_kernel(const flo
         const int q = q0 + (lane & 31);
         if (q < S) {
             store_dt_f32(o, 1.0f / sum, ctx + (size_t)(b * S + q) * ld_ctx + hd * 64, lane);
+            if (ctx3 != nullptr) store_dt_split3(o, 1.0f / sum, ctx3 + (size_t)(b * S + q) * ld_c3 + hd * 64, HW, lane);   // the out-projection's operand
             if (h == 0) lse[((size_t)b * heads + hd) * S + q] = (__log2f(sum) - nm2) * LN2;  // natural-log LSE
         }
     }
@@ -185,7 +207,8 @@ __global__ __launch_bounds__(X3_WAVES * 64, 2) void attn_bwd_x3_kernel(const flo
                                                                      int ld_dc, const float* __restrict__ ctx, int ld_c,
                                                                      const float* __restrict__ lse, int S, int heads,
                                                                      const float* __restrict__ key_bias, float scale,
-                                                                     float* __restrict__ dqkv, int ld_d, DropCfg drop) {
+                                                                     float* __restrict__ dqkv, int ld_d, DropCfg drop,
+                                                                     bf16_t* __restrict__ dqkv3, int ld_d3) {
     constexpr int SP = NB * 32, RM = SP * ROWB;
     BSCLIP_DROP_RESOLVE(drop);
     __shared__ __attribute__((aligned(16))) char smem[4 * RM + 3 * SP * 4];
@@ -275,7 +298,10 @@ __global__ __launch_bounds__(X3_WAVES * 64, 2) void attn_bwd_x3_kernel(const flo
             }
         }
         const int q = q0 + (lane & 31);
-        if (q < S) store_dt_f32(dq, scale, dqb + (size_t)q * ld_d, lane);
+        if (q < S) {
+            store_dt_f32(dq, scale, dqb + (size_t)q * ld_d, lane);
+            if (dqkv3 != nullptr) store_dt_split3(dq, scale, dqkv3 + (size_t)(b * S + q) * ld_d3 + hd * 64, 3 * HW, lane);   // [dq | dk | dv] as the dX GEMM's operand
+        }
     }
     __syncthreads();
     // ---------------- phase 2 staging: Q, dO (hi | lo) ----------------
@@ -343,6 +369,11 @@ __global__ __launch_bounds__(X3_WAVES * 64, 2) void attn_bwd_x3_kernel(const flo
         if (key < S) {
             store_dt_f32(dk, scale, dqb + (size_t)key * ld_d + HW, lane);
             store_dt_f32(dv, 1.0f, dqb + (size_t)key * ld_d + 2 * HW, lane);
+            if (dqkv3 != nullptr) {
+                bf16_t* r3 = dqkv3 + (size_t)(b * S + key) * ld_d3 + hd * 64;
+                store_dt_split3(dk, scale, r3 + HW, 3 * HW, lane);
+                store_dt_split3(dv, 1.0f, r3 + 2 * HW, 3 * HW, lane);
+            }
         }
     }
 }
@@ -353,15 +384,15 @@ __global__ __launch_bounds__(X3_WAVES * 64, 2) void attn_bwd_x3_kernel(const flo
     case NBV:                                                                                                                   \
         if (drop.thr16)                                                                                                         \
             hipLaunchKernelGGL((attn_fwd_x3_kernel<NBV, true>), dim3(B * heads), dim3(X3_WAVES * 64), 0, s, qkv, ld_qkv, S, heads, key_bias, \
-                               scale, ctx, ld_ctx, lse, drop);                                                                  \
+                               scale, ctx, ld_ctx, lse, drop, ctx3, ld_c3);                                                     \
         else                                                                                                                    \
             hipLaunchKernelGGL((attn_fwd_x3_kernel<NBV, false>), dim3(B * heads), dim3(X3_WAVES * 64), 0, s, qkv, ld_qkv, S, heads, key_bias, \
-                               scale, ctx, ld_ctx, lse, drop);                                                                  \
+                               scale, ctx, ld_ctx, lse, drop, ctx3, ld_c3);                                                     \
         break;
 
 // internal (called by exact.hip's bsclip_attn_fwd_f32 / bsclip_attn_bwd_f32 after their argument checks)
 void bsclip_launch_attn_fwd_x3(const float* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, float* ctx,
-                               int ld_ctx, float* lse, const DropCfg& drop, hipStream_t s) {
+                               int ld_ctx, float* lse, const DropCfg& drop, bf16_t* ctx3, int ld_c3, hipStream_t s) {
     switch ((S + 31) / 32) {
         X3_FWD_CASE(1) X3_FWD_CASE(2) X3_FWD_CASE(3) X3_FWD_CASE(4) X3_FWD_CASE(5) X3_FWD_CASE(6) X3_FWD_CASE(7)
     }
@@ -371,15 +402,15 @@ void bsclip_launch_attn_fwd_x3(const float* qkv, int ld_qkv, int B, int S, int h
     case NBV:                                                                                                                   \
         if (drop.thr16)                                                                                                         \
             hipLaunchKernelGGL((attn_bwd_x3_kernel<NBV, true>), dim3(B * heads), dim3(X3_WAVES * 64), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, \
-                               ld_ctx, lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop);                                    \
+                               ld_ctx, lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop, dqkv3, ld_d3);                      \
         else                                                                                                                    \
             hipLaunchKernelGGL((attn_bwd_x3_kernel<NBV, false>), dim3(B * heads), dim3(X3_WAVES * 64), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, \
-                               ld_ctx, lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop);                                    \
+                               ld_ctx, lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop, dqkv3, ld_d3);                      \
         break;
 
 void bsclip_launch_attn_bwd_x3(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx, const float* lse,
                                int B, int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv, const DropCfg& drop,
-                               hipStream_t s) {
+                               bf16_t* dqkv3, int ld_d3, hipStream_t s) {
     switch ((S + 31) / 32) {
         X3_BWD_CASE(1) X3_BWD_CASE(2) X3_BWD_CASE(3) X3_BWD_CASE(4) X3_BWD_CASE(5) X3_BWD_CASE(6) X3_BWD_CASE(7)
     }

@@ -255,10 +255,10 @@ void bsclip_launch_slab_reduce_add(const float* partial, int nblocks, int n, flo
 
 // attn_x3.hip, internal: exact-mode attention on split-bf16 operands (argument checks: exact.hip's bsclip_attn_fwd_f32 / bwd_f32)
 void bsclip_launch_attn_fwd_x3(const float* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, float* ctx,
-                               int ld_ctx, float* lse, const DropCfg& drop, hipStream_t s);
+                               int ld_ctx, float* lse, const DropCfg& drop, bf16_t* ctx3, int ld_c3, hipStream_t s);
 void bsclip_launch_attn_bwd_x3(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx, const float* lse,
                                int B, int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv, const DropCfg& drop,
-                               hipStream_t s);
+                               bf16_t* dqkv3, int ld_d3, hipStream_t s);
 
 // gemm.hip, internal: the fused InfoNCE products on the 256x256 ping-pong GEMM (see the EPI_LSE_PART / EPI_LOSS_W epilogues)
 int bsclip_gemm_infonce(int mode, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,

@@ -739,9 +739,18 @@ extern "C" int bsclip_meanpool_tokens_f32(const float* x, int B, int S, int H, f
     return BSCLIP_OK;
 }
 
+// ctx_split3 / dqkv_split3 (nullable, round 5): the output once more as the A operand of the next split-bf16 GEMM ([hi | lo | hi], bf16
+// [B S, ld >= 3 x width]) -- written by the split-bf16 kernels themselves (impl 0), by a split pass behind the f32 kernels (impl 1 / 2)
+static void split3_after(const float* src, int ld_src, int M, int K, void* dst, int ld_dst, hipStream_t s) {
+    const size_t n = (size_t)M * (K / 4);
+    hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, M, K, static_cast<bf16_t*>(dst), ld_dst);
+}
+
 extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, float* ctx,
-                                   int ld_ctx, float* lse, float dropout_p, uint32_t dropout_seed, void* stream) {
+                                   int ld_ctx, float* lse, void* ctx_split3, int ld_c3, float dropout_p, uint32_t dropout_seed, void* stream) {
     BSCLIP_REQUIRE(qkv && ctx && lse, "bsclip_attn_fwd_f32: null pointer");
+    BSCLIP_REQUIRE(!ctx_split3 || (ld_c3 >= 3 * heads * 64 && ld_c3 % 4 == 0 && (reinterpret_cast<uintptr_t>(ctx_split3) & 7) == 0),
+                   "bsclip_attn_fwd_f32: ctx_split3 bf16 [B S, ld_c3 >= 3 heads 64], 8-byte aligned (ld_c3=%d)", ld_c3);
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= AF_SMAX, "bsclip_attn_fwd_f32: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 4 == 0 && ld_ctx >= heads * 64 && ld_ctx % 4 == 0,
                    "bsclip_attn_fwd_f32: ld_qkv=%d ld_ctx=%d", ld_qkv, ld_ctx);
@@ -751,7 +760,7 @@ extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, i
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (g_exact_attn_impl == 0) {   // round 5: split-bf16 operands on the bf16 matrix cores (attn_x3.hip), 16 x the f32 MFMA rate
-        bsclip_launch_attn_fwd_x3(qkv, ld_qkv, B, S, heads, key_bias, scale, ctx, ld_ctx, lse, drop, s);
+        bsclip_launch_attn_fwd_x3(qkv, ld_qkv, B, S, heads, key_bias, scale, ctx, ld_ctx, lse, drop, static_cast<bf16_t*>(ctx_split3), ld_c3, s);
         BSCLIP_LAUNCH_CHECK();
         return BSCLIP_OK;
     }
@@ -762,6 +771,7 @@ extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, i
         else
             hipLaunchKernelGGL((attn_fwd_mf32_kernel<false>), dim3(B * heads), dim3(MF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale,
                                ctx, ld_ctx, lse, drop);
+        if (ctx_split3) split3_after(ctx, ld_ctx, B * S, heads * 64, ctx_split3, ld_c3, s);
         BSCLIP_LAUNCH_CHECK();
         return BSCLIP_OK;
     }
@@ -771,6 +781,7 @@ extern "C" int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, i
     else
         hipLaunchKernelGGL((attn_fwd_f32_kernel<false>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, S, heads, key_bias, scale, ctx,
                            ld_ctx, lse, drop);
+    if (ctx_split3) split3_after(ctx, ld_ctx, B * S, heads * 64, ctx_split3, ld_c3, s);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }
@@ -817,8 +828,10 @@ extern "C" int bsclip_softmax_meanpool_bwd_f32(const float* logits, const float*
 
 extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx,
                                    const float* lse, int B, int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv,
-                                   float dropout_p, uint32_t dropout_seed, void* stream) {
+                                   void* dqkv_split3, int ld_d3, float dropout_p, uint32_t dropout_seed, void* stream) {
     BSCLIP_REQUIRE(qkv && dctx && ctx && lse && dqkv, "bsclip_attn_bwd_f32: null pointer");
+    BSCLIP_REQUIRE(!dqkv_split3 || (ld_d3 >= 9 * heads * 64 && ld_d3 % 4 == 0 && (reinterpret_cast<uintptr_t>(dqkv_split3) & 7) == 0),
+                   "bsclip_attn_bwd_f32: dqkv_split3 bf16 [B S, ld_d3 >= 9 heads 64], 8-byte aligned (ld_d3=%d)", ld_d3);
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= AF_SMAX, "bsclip_attn_bwd_f32: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
     BSCLIP_REQUIRE(ld_qkv >= 3 * heads * 64 && ld_qkv % 4 == 0 && ld_dqkv >= 3 * heads * 64 && ld_dqkv % 4 == 0 && ld_ctx >= heads * 64 &&
                        ld_ctx % 4 == 0 && ld_dctx >= heads * 64 && ld_dctx % 4 == 0,
@@ -830,7 +843,8 @@ extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dc
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (g_exact_attn_impl == 0) {
-        bsclip_launch_attn_bwd_x3(qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx, lse, B, S, heads, key_bias, scale, dqkv, ld_dqkv, drop, s);
+        bsclip_launch_attn_bwd_x3(qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx, lse, B, S, heads, key_bias, scale, dqkv, ld_dqkv, drop,
+                                  static_cast<bf16_t*>(dqkv_split3), ld_d3, s);
         BSCLIP_LAUNCH_CHECK();
         return BSCLIP_OK;
     }
@@ -841,6 +855,7 @@ extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dc
         else
             hipLaunchKernelGGL((attn_bwd_mf32_kernel<false>), dim3(B * heads), dim3(MF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx,
                                lse, S, heads, key_bias, scale, dqkv, ld_dqkv, drop);
+        if (dqkv_split3) split3_after(dqkv, ld_dqkv, B * S, 3 * heads * 64, dqkv_split3, ld_d3, s);
         BSCLIP_LAUNCH_CHECK();
         return BSCLIP_OK;
     }
@@ -850,6 +865,7 @@ extern "C" int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dc
     else
         hipLaunchKernelGGL((attn_bwd_f32_kernel<false>), dim3(B * heads), dim3(AF_THREADS), 0, s, qkv, ld_qkv, dctx, ld_dctx, ctx, ld_ctx, lse,
                            S, heads, key_bias, scale, dqkv, ld_dqkv, drop);
+    if (dqkv_split3) split3_after(dqkv, ld_dqkv, B * S, 3 * heads * 64, dqkv_split3, ld_d3, s);
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
 }

@@ -243,8 +243,11 @@ int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, c
  *                  nullable; the MLM transform's GELU feeds a LayerNorm, not a GEMM); codes (nullable) u8 [M, ld_codes]: the 8-bit
  *                  gelu' side band the default backward reads
  *   meanpool_tokens_f32: x f32 [B*S, H] -> out f32 [B, H], the mean over each sequence's S tokens (language_encoder.py:89)
- *   attn_fwd_f32:  qkv f32 [B*S, ld_qkv] ([q | k | v], heads*64 each) -> ctx f32 [B*S, ld_ctx], lse f32 [B, heads, S]; f32 arithmetic
- *                  (f32-operand MFMA, S <= 224), the bf16 kernels' dropout masks; argument meaning as bsclip_attn_fwd.
+ *   attn_fwd_f32:  qkv f32 [B*S, ld_qkv] ([q | k | v], heads*64 each) -> ctx f32 [B*S, ld_ctx], lse f32 [B, heads, S]; f32 softmax
+ *                  arithmetic, every product exact to ~2^-16 (bsclip_exact_attn_set_impl: split-bf16 operands by default, f32-operand
+ *                  MFMA / vector ALU as second implementations; S <= 224), the bf16 kernels' dropout masks; argument meaning as
+ *                  bsclip_attn_fwd.  ctx_split3 (nullable): ctx once more as bf16 [B*S, ld_c3 >= 3 heads 64] = [hi | lo | hi], the
+ *                  out-projection GEMM's split operand (no stand-alone bsclip_split3_rows pass)
  * The exact backward (BSCLIP_PARITY=2) keeps every gradient in f32 and runs its dX / dW GEMMs on split operands as well:
  *   dgelu_split3:  dact f32 [M, N], z f32 [M, N] (fc1 pre-activation) -> dact * gelu'(z) as bf16 [M, 3N] = [hi | lo | hi] (dst nullable)
  *                  and / or f32 [M, ld_out32] (out32 nullable)
@@ -257,9 +260,10 @@ int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, c
  *                  the LayerNorm output y f32 [M, ld_y] (reference lora_layer.py:16-39); workspace:
  *                  bsclip_lora_grad_f32_workspace_floats(M, H) floats (t and dt [M, 8] + the per-workgroup slabs); sums in a fixed order
  *                  (round 5: t = A y by one pass, then bsclip_lora_grad's pipelined wave-per-row kernels on f32 rows)
- *   attn_bwd_f32:  dqkv f32 [B*S, ld_dqkv] from qkv f32, dctx f32, the forward's ctx f32 (delta = dctx . ctx) and lse; f32-operand
- *                  MFMA, the forward's dropout masks; argument meaning as bsclip_attn_bwd.
- * bsclip_layernorm_bwd takes the f32 GEMM gradient / writes the f32 operand through resid_flags bits 2 / 3. */
+ *   attn_bwd_f32:  dqkv f32 [B*S, ld_dqkv] from qkv f32, dctx f32, the forward's ctx f32 (delta = dctx . ctx) and lse; the forward's
+ *                  implementation and dropout masks; argument meaning as bsclip_attn_bwd.  dqkv_split3 (nullable): [dq | dk | dv] once
+ *                  more as bf16 [B*S, ld_d3 >= 9 heads 64] = [hi | lo | hi], the QKV dX GEMM's split operand
+ * bsclip_layernorm_bwd takes the f32 GEMM gradient / writes the f32 or the split operand through resid_flags bits 2 / 3 / 4. */
 int bsclip_split3_rows(const float* src, int ld_src, int M, int K, void* dst, int ld_dst, void* stream);
 int bsclip_split3_weight(const float* w, int ld_w, int N, int K, const float* lora_a, const float* lora_b, int H, void* dst, int ld_dst,
                          void* stream);
@@ -267,7 +271,7 @@ int bsclip_gelu_split3(const float* z, int ld_z, int M, int N, void* dst, int ld
                        void* stream);
 int bsclip_meanpool_tokens_f32(const float* x, int B, int S, int H, float* out, void* stream);
 int bsclip_attn_fwd_f32(const float* qkv, int ld_qkv, int B, int S, int heads, const float* key_bias, float scale, float* ctx, int ld_ctx,
-                        float* lse, float dropout_p, uint32_t dropout_seed, void* stream);
+                        float* lse, void* ctx_split3, int ld_c3, float dropout_p, uint32_t dropout_seed, void* stream);
 int bsclip_dgelu_split3(const float* dact, int ld_dact, const float* z, int ld_z, int M, int N, void* dst, int ld_dst, float* out32,
                         int ld_out32, void* stream);
 int bsclip_split3_transpose(const float* src, int ld_src, int R, int C, int Rp, int order, const float* lora_a, const float* lora_b, int H,
@@ -282,8 +286,8 @@ int bsclip_lora_grad_f32(const float* dqkv, int ld_dqkv, const float* y, int ld_
  * 1 = the one-row-per-thread vector-ALU kernels -- 1 and 2 are exact-f32 second implementations kept to test against */
 int bsclip_exact_attn_set_impl(int impl);
 int bsclip_attn_bwd_f32(const float* qkv, int ld_qkv, const float* dctx, int ld_dctx, const float* ctx, int ld_ctx, const float* lse, int B,
-                        int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv, float dropout_p,
-                        uint32_t dropout_seed, void* stream);
+                        int S, int heads, const float* key_bias, float scale, float* dqkv, int ld_dqkv, void* dqkv_split3, int ld_d3,
+                        float dropout_p, uint32_t dropout_seed, void* stream);
 
 /* ---- embeddings ------------------------------------------------------------------------------------------------
  * im2col for timm PatchEmbed Conv2d(3,768,k=16,s=16): image f32 [B,3,224,224] -> bf16 [B*196, 768], column

@@ -702,7 +702,10 @@ def test_exact_attention_fwd_bwd_f32(ops, B, S, heads, masked, impl):
     lse = torch.empty(B, heads, S, device="cuda")
     ops.exact_attn_set_impl(impl)        # (tests/conftest.py resets the switch after every GPU test)
     tol_out, tol_lse, tol_g = {0: (5e-5, 1e-5, 2e-4), 2: (TOL_F32, 1e-6, 3e-5)}[impl]
-    ops.attn_fwd_f32(qkv, B, S, heads, scale, ctx, lse, key_bias=bias)
+    c3 = torch.full((B * S, 3 * H + 8), float("nan"), device="cuda", dtype=torch.bfloat16)[:, :3 * H]
+    ops.attn_fwd_f32(qkv, B, S, heads, scale, ctx, lse, key_bias=bias, ctx_split3=c3)
+    # the split output IS the split of the f32 output: [hi | lo | hi] as bsclip_split3_rows builds it (the out-projection GEMM's operand)
+    assert torch.equal(c3, ops.split3_rows(ctx, torch.empty(B * S, 3 * H, device="cuda", dtype=torch.bfloat16)))
     qf = qkv.double().reshape(B, S, 3 * H).requires_grad_(True)
     ref, ref_lse = _attn_ref(qf, B, S, heads, scale, None if bias is None else bias.double())
     assert rel_err(ctx, ref.float()) < tol_out and rel_err(lse, ref_lse.float()) < tol_lse, (rel_err(ctx, ref.float()), rel_err(lse, ref_lse.float()))
@@ -710,7 +713,9 @@ def test_exact_attention_fwd_bwd_f32(ops, B, S, heads, masked, impl):
     (gq,) = torch.autograd.grad(ref, qf, dctx.double())
     gq = gq.reshape(B * S, 3 * H).float()
     dqkv = torch.full((B * S, 3 * H), float("nan"), device="cuda")
-    ops.attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, scale, dqkv, key_bias=bias)
+    d3 = torch.full((B * S, 9 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.attn_bwd_f32(qkv, dctx, ctx, lse, B, S, heads, scale, dqkv, key_bias=bias, dqkv_split3=d3)
+    assert torch.equal(d3, ops.split3_rows(dqkv, torch.empty(B * S, 9 * H, device="cuda", dtype=torch.bfloat16)))
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
         # S = 1: dq = dk = 0 in the reference (one key: dS = P (dP - delta) = 0); here dP and delta are two f32 summation orders of
         # the same dot product, so dS is rounding noise (1e-7 of the gradient's scale): measured against the whole gradient then
