@@ -596,7 +596,7 @@ def main():
                                        if getattr(graphed, "native", False) else "torch.distributed (ProcessGroupNCCL = RCCL), issued from the tower streams"),
                        "numerics": {0: "default: bf16 GEMM / attention operands, bf16 residual and residual-gradient streams",
                                     1: "BSCLIP_PARITY=1: f32 residual / residual-gradient streams (diagnostic run)",
-                                    2: "BSCLIP_PARITY=2: exact mode -- split-bf16 operands on every GEMM, f32 attention (diagnostic run: "
+                                    2: "BSCLIP_PARITY=2: exact mode -- split-bf16 operands on every GEMM and attention product (diagnostic run: "
                                        "1e-3 parity with the f32 reference, not the benchmark configuration)"}[
                                         2 if _engine.EXACT_FORWARD else 0 if _engine.GRAD_STREAM_BF16 else 1],
                        "final_loss": round(final_loss, 6)},
@@ -642,10 +642,10 @@ def main():
                 xm = side_measurement(device, True, False, 256, steps=max(4, a.steps // 4), parity=2)
                 out["exact_mode_ms_per_step"] = xm["ms_per_step"]
                 out["exact_mode"] = ("BSCLIP_PARITY=2: the step that meets north_star's 1e-3 against the f32 reference on embeddings, loss and every "
-                                     "gradient (forward AND backward GEMMs on split-bf16 operands = 3 x the K, LoRA folded in f32, exact-erf GELU, "
-                                     "f32-operand MFMA attention forward / backward, f32 LoRA gradients; golden 10-step trajectory within "
-                                     "1e-3, tests/test_20_encoders_gpu.py); same workload as the headline: what bf16 operands buy is the "
-                                     "headline's ms_per_step against this")
+                                     "gradient (forward AND backward GEMMs and every attention product on split-bf16 operands = 3 x the MFMA work, "
+                                     "LoRA folded in f32, exact-erf GELU, f32 softmax / LayerNorm / LoRA-gradient arithmetic; golden 10-step "
+                                     "trajectory within 1e-3, tests/test_20_encoders_gpu.py); same workload as the headline: what bf16 operands "
+                                     "buy is the headline's ms_per_step against this (round 4: 158 ms with f32-operand MFMA attention)")
                 out["parity_mode"] = ("BSCLIP_PARITY=1: f32 residual and residual-gradient streams + split-bf16 patch embedding, same workload "
                                       "as the headline (what the default's bf16 streams buy: headline ms_per_step vs this); trunk GEMM and "
                                       "attention operands stay bf16 in both (DESIGN.md 4)")

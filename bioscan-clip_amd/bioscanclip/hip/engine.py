@@ -49,8 +49,9 @@ ATTN_KEEP_BITS = os.environ.get("BSCLIP_ATTN_KEEP_BITS", "1") != "0"
 # take bf16 operands.
 # BSCLIP_PARITY=2 / set_parity_mode(2): the EXACT mode (round 4, csrc/exact.hip) -- every GEMM of the forward and of the backward
 # on split-bf16 operands (hi + lo, K tripled: exact to ~2^-16 on the bf16 matrix cores), LoRA folded into the weight in f32,
-# exact-erf GELU, attention forward / backward and the LoRA gradients in f32 on the vector ALU, f32 streams.  Embeddings, loss and
-# every gradient within 1e-3 of the f32 reference at depth 12 (measured <= 1.5e-4, tests/test_20_encoders_gpu.py).
+# exact-erf GELU, every attention product on split operands too (round 5, csrc/attn_x3.hip: f32 in / out, f32 softmax arithmetic), f32
+# LoRA gradients, f32 streams; the LayerNorm and attention kernels write the next GEMM's split operand themselves.  Embeddings, loss
+# and every gradient within 1e-3 of the f32 reference at depth 12 (measured <= 1.6e-4, tests/test_20_encoders_gpu.py).
 # LoRA-regime ViT / BERT engines only (fp8 and full fine-tuning keep their own paths, on the f32 streams).
 EXACT_FORWARD = False
 if os.environ.get("BSCLIP_PARITY", "0") in ("1", "2"):
@@ -458,7 +459,7 @@ class ViTEngine(EncoderEngineBase):
 
     # -------------------------------------------------------------------------------------------- forward
     def _forward_exact(self, image, ws):
-        """BSCLIP_PARITY=2: the same block sequence with every Linear on split-bf16 operands, f32 attention, exact-erf GELU; what
+        """BSCLIP_PARITY=2: the same block sequence with every Linear and every attention product on split-bf16 operands (f32 in / out), exact-erf GELU; what
         ``_backward_exact`` reads -- per layer the f32 LN1 output, q | k | v, attention output and fc1 pre-activation, the
         LayerNorm statistics, lse, the f32 residual stream -- stays resident."""
         B, H, S, M, L, FF = image.shape[0], self.H, self.S, ws["M"], len(self.layers), self.FF
@@ -627,7 +628,7 @@ class ViTEngine(EncoderEngineBase):
 
     def _backward_exact(self, dout):
         """BSCLIP_PARITY=2: the backward of ``_forward_exact`` with every gradient in f32 -- dX GEMMs on split operands against the
-        transposed split weights (LoRA folded: W + B A), exact gelu' from the f32 pre-activation, f32 attention backward, f32 LoRA
+        transposed split weights (LoRA folded: W + B A), exact gelu' from the f32 pre-activation, the attention backward on split operands (f32 in / out), f32 LoRA
         gradients, the head's dW on operands split along the batch."""
         ws = self.ws
         B, M, H, S, L = ws["B"], ws["M"], self.H, self.S, len(self.layers)
@@ -880,7 +881,7 @@ class BertEngine(EncoderEngineBase):
 
     def _forward_exact(self, ws, key_bias):
         """BSCLIP_PARITY=2 (see ViTEngine._forward_exact): the layers after the embedding LayerNorm (which has just written the f32
-        layer input ys[0]) with every Linear on split-bf16 operands, f32 attention, exact-erf GELU; dropout sites and seeds as in
+        layer input ys[0]) with every Linear and every attention product on split-bf16 operands (f32 in / out), exact-erf GELU; dropout sites and seeds as in
         the default path; what ``_backward_exact`` reads stays resident in f32."""
         B, S, M, H, L, FF = ws["B"], ws["S"], ws["M"], self.H, len(self.layers), self.FF
         a3, ys = ws["a3"], ws["ys"]

@@ -423,7 +423,8 @@ def lora_grad_f32(dqkv, y, M, H, lora_a, lora_b, dA, dB):
 
 
 def exact_attn_set_impl(impl):
-    """0 = f32 attention on the matrix pipe (default), 1 = the vector-ALU kernels (second implementation, for tests)."""
+    """0 = split-bf16 operands on the bf16 matrix cores (default, csrc/attn_x3.hip); 2 = f32-operand MFMA, 1 = vector-ALU kernels (exact-f32
+    second implementations, for tests)."""
     check(_l.load().bsclip_exact_attn_set_impl(int(impl)))
 
 

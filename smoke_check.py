@@ -50,7 +50,7 @@ def run_smoke():
     assert e_img < 1.37e-2 and e_dna < 7.1e-3 and e_loss < 1.8e-3 and e_par < 1.17e-2, "HIP step disagrees with the CPU oracle"
     assert q_img < 8.8e-3 and q_dna < 3.3e-3, "HIP step disagrees with the bf16-rounding-aware oracle"
 
-    # the exact mode (BSCLIP_PARITY=2: split-bf16 operands on every GEMM of the forward AND the backward, f32 attention, exact GELU,
+    # the exact mode (BSCLIP_PARITY=2: split-bf16 operands on every GEMM of the forward AND the backward, attention products on split operands too, exact GELU,
     # f32 LoRA gradients): the same step from the same starting point, against north_star's 1e-3
     from bioscanclip.hip import engine
     prev = engine.set_parity_mode(2, model)
