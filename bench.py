@@ -208,16 +208,18 @@ def time_families(B, device, reps=3):
             dctx = torch.randn(B * S, 768, device=device).bfloat16()
             dqkv = torch.empty(B * S, 2304, device=device, dtype=torch.bfloat16)
             drop = (p, 1234) if p else None
-            ops.attn_fwd(qkv, B, S, 12, 0.125, ctx, lse, dropout=drop)
-            bufs.append((S, qkv, ctx, lse, dctx, dqkv, drop, cnt))
+            # with dropout the forward leaves its keep decisions as bit words and the backward reads them: the engines' path (round 5)
+            bits = torch.zeros(B * 12 * S * ops.KEEP_WORDS, device=device, dtype=torch.int32) if p else None
+            ops.attn_fwd(qkv, B, S, 12, 0.125, ctx, lse, dropout=drop, keep_bits=bits)
+            bufs.append((S, qkv, ctx, lse, dctx, dqkv, drop, bits, cnt))
 
         def mix():
-            for S, qkv, ctx, lse, dctx, dqkv, drop, cnt in bufs:
+            for S, qkv, ctx, lse, dctx, dqkv, drop, bits, cnt in bufs:
                 for _ in range(cnt):
                     if bwd:
-                        ops.attn_bwd(qkv, dctx, lse, B, S, 12, 0.125, dqkv, dropout=drop)
+                        ops.attn_bwd(qkv, dctx, lse, B, S, 12, 0.125, dqkv, dropout=drop, keep_bits=bits)
                     else:
-                        ops.attn_fwd(qkv, B, S, 12, 0.125, ctx, lse, dropout=drop)
+                        ops.attn_fwd(qkv, B, S, 12, 0.125, ctx, lse, dropout=drop, keep_bits=bits)
         n = sum(b[-1] for b in bufs)
         fl = sum(4.0 * B * 12 * b[0] * b[0] * 64 * b[-1] for b in bufs) / n * (2.5 if bwd else 1.0)
         return mix, n, fl
