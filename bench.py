@@ -252,6 +252,26 @@ def time_families(B, device, reps=3):
     return out
 
 
+def parity_distances():
+    """Distances to the f32 reference of the three numerics configurations, as the GPU parity tests measured them at depth 12
+    (tests/test_20_encoders_gpu.py appends them to gpurun_out/parity.jsonl; the copy under profiles/ travels with the tree): this process
+    times the configurations, it does not re-measure their distances (the f32 oracle of a 12-layer tower is a minute of CPU time)."""
+    path = os.path.join(ROOT, "profiles", "parity_latest.jsonl")
+    rec = {}
+    try:
+        for line in open(path):
+            d = json.loads(line)
+            if "emb_vs_f32_oracle" in d and "worst_grad" in d:
+                rec[d["test"]] = {"embedding": float("%.3g" % d["emb_vs_f32_oracle"]), "worst_gradient_tensor": float("%.3g" % d["worst_grad"])}
+    except Exception as exc:   # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    pick = lambda keys: {k.split("_", 2)[-1] if k.startswith(("parity_mode_", "exact_forward_")) else k: rec[k] for k in keys if k in rec}
+    return {"default": pick(["vit_L12", "dna_L12", "txt_L4"]), "parity1": pick(["parity_mode_vit_L12", "parity_mode_dna_L12"]),
+            "exact": pick(["exact_forward_vit_L12", "exact_forward_dna_L12", "exact_forward_txt_L4"]),
+            "source": "relative L2 distance to the f32 CPU oracle (= the imported reference's fixtures, tests/golden) of the full-depth encoders' "
+                      "embeddings and of the worst trainable-gradient tensor, measured by the -m gpu parity tests: profiles/parity_latest.jsonl"}
+
+
 def thread_cpu_seconds():
     """{tid: (name, user + system CPU seconds)} of every thread of this process (/proc/self/task): who burns the host."""
     out = {}
@@ -648,6 +668,15 @@ def main():
                                      "LoRA folded in f32, exact-erf GELU, f32 softmax / LayerNorm / LoRA-gradient arithmetic; golden 10-step "
                                      "trajectory within 1e-3, tests/test_20_encoders_gpu.py); same workload as the headline: what bf16 operands "
                                      "buy is the headline's ms_per_step against this (round 4: 158 ms with f32-operand MFMA attention)")
+                dist_ = parity_distances()
+                out["numerics_modes"] = {   # the three configurations on one line, time beside distance
+                    "default (bf16 operands, bf16 streams)": {"ms_per_step": out["ms_per_step"], "rel_err_vs_f32_reference": dist_.get("default")},
+                    "BSCLIP_PARITY=1 (f32 streams)": {"ms_per_step": pm["ms_per_step"], "rel_err_vs_f32_reference": dist_.get("parity1")},
+                    "BSCLIP_PARITY=2 (exact: split-bf16 operands everywhere)": {"ms_per_step": xm["ms_per_step"], "rel_err_vs_f32_reference": dist_.get("exact")},
+                    "no_cheaper_middle": "tools/site_sensitivity.py / profiles/r05_site_sensitivity.log: no subset of rounding sites carries the "
+                                         "default's distance (every site within +-15 % of it; everything but the MLP still 5.6e-3), so no "
+                                         "BSCLIP_PARITY=3 exists (DESIGN.md 4)",
+                    "distances_source": dist_.get("source", dist_.get("error"))}
                 out["parity_mode"] = ("BSCLIP_PARITY=1: f32 residual and residual-gradient streams + split-bf16 patch embedding, same workload "
                                       "as the headline (what the default's bf16 streams buy: headline ms_per_step vs this); trunk GEMM and "
                                       "attention operands stay bf16 in both (DESIGN.md 4)")
