@@ -42,6 +42,10 @@ PATCH_SPLIT = os.environ.get("BSCLIP_PATCH_SPLIT", "1") != "0"
 # Attention-probs dropout (BERT towers, train mode): the forward kernel leaves its keep decisions as bit words, the backward reads them
 # instead of re-hashing (csrc/attn_common.h KEEP_WORDS).  "0" = re-hash in the backward (round 4's form; identical masks and gradients).
 ATTN_KEEP_BITS = os.environ.get("BSCLIP_ATTN_KEEP_BITS", "1") != "0"
+# LoRA gradients: the attention backward leaves dt = dq B_q | dv B_v and dB = (dq | dv)^T t as per-head / per-sequence partial sums taken
+# from its accumulators (csrc/attn.hip LoraPart), bsclip_lora_grad_heads reduces them -- instead of bsclip_lora_grad's pass that reads dq
+# and dv back from HBM.  "0" = that pass (round 4's form; the same sums up to f32 accumulation order).
+ATTN_LORA = os.environ.get("BSCLIP_ATTN_LORA", "1") != "0"
 
 
 # BSCLIP_PARITY=1 / set_parity_mode(1): f32 residual stream, f32 residual-gradient stream, split-bf16 patch embedding -- at the
@@ -433,6 +437,7 @@ class ViTEngine(EncoderEngineBase):
         ws["dctx"] = z(M, H)
         ws["dqkv"] = z(M, 3 * H)
         ws["dt"] = z(M, 8, dt=F32)
+        ws["dtp"], ws["dbp"] = z(self.heads, M, 8, dt=F32), z(B * self.heads, 2, 4, 64, dt=F32)   # LoRA partial sums (ATTN_LORA)
         Bp = _pad64(B)
         ws["dout_bf"] = torch.zeros(B, self.out_dim, dtype=BF16, device=dev)
         ws["dout_t"] = torch.zeros(self.out_dim, Bp, dtype=BF16, device=dev)
@@ -609,14 +614,17 @@ class ViTEngine(EncoderEngineBase):
                 ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=R, g_gemm=ws["dh"],
                                   dx_f32=None if g16 else dx, dx_bf16=dxb)
                 ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
-            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
-                         q_rows=1 if l == L - 1 else 0)
             lb = self.lora_b(l)
+            part = lb is not None and ATTN_LORA and not self.fp8    # dt / dB partial sums out of the attention backward
+            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
+                         q_rows=1 if l == L - 1 else 0, lora=(ws["h1"][l][:, H:], lb, ws["dtp"], ws["dbp"]) if part else None)
             if lb is not None:
                 gb = self.lora_b(l, grad=True)
                 if self.fp8:
                     ops.lora_grad_fp8(ws["dqkv"], ws["h1_8"][l], ws["t"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True),
                                       gb[0], gb[1])
+                elif part:
+                    ops.lora_grad_heads(ws["h1"][l], M, H, B, ws["dtp"], ws["dbp"], ws["dt"], self.lora_a(l, grad=True), gb[0], gb[1])
                 else:
                     ops.lora_grad(ws["dqkv"], ws["h1"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gb[0], gb[1])
             if l > 0:  # nothing trainable sits below block 0 (patch-embed, cls, pos are frozen)
@@ -811,6 +819,7 @@ class BertEngine(EncoderEngineBase):
         ws["dctx"] = z(M, H)
         ws["dqkv"] = z(M, 3 * H)
         ws["dt"] = z(M, 8, dt=F32)
+        ws["dtp"], ws["dbp"] = z(self.heads, M, 8, dt=F32), z(B * self.heads, 2, 4, 64, dt=F32)   # LoRA partial sums (ATTN_LORA)
         if self.head == "mlm_softmax_mean":
             ws["head_splits"], Mp = split_plan(M, self.out_dim, H)
             if ws["head_splits"] > 1:
@@ -1099,15 +1108,19 @@ class BertEngine(EncoderEngineBase):
                               dx_f32=None if one_a else ws["ds1"], dx_bf16=ws["dsb"], dropout=drop_a)
             ops.gemm(ws["dsb"], lay.w_o_t, ws["dctx"], EPI_BF16)
             drop_p = self._drop(ws, self.p_attn, l, 1)
-            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
-                         key_bias=ws["key_bias"], dropout=drop_p,
-                         keep_bits=ws["kbits"][l] if drop_p is not None and ws["kbits"] is not None else None)
             lb = self.lora_b(l)
+            kb = ws["kbits"][l] if drop_p is not None and ws["kbits"] is not None else None
+            part = lb is not None and ATTN_LORA and not self.fp8 and (drop_p is None or kb is not None)
+            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"],
+                         key_bias=ws["key_bias"], dropout=drop_p, keep_bits=kb,
+                         lora=(ws["yb"][l][:, H:], lb, ws["dtp"], ws["dbp"]) if part else None)
             if lb is not None:
                 gbb = self.lora_b(l, grad=True)
                 if self.fp8:
                     ops.lora_grad_fp8(ws["dqkv"], ws["yb8"][l], ws["t"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True),
                                       gbb[0], gbb[1])
+                elif part:
+                    ops.lora_grad_heads(ws["yb"][l], M, H, B, ws["dtp"], ws["dbp"], ws["dt"], self.lora_a(l, grad=True), gbb[0], gbb[1])
                 else:
                     ops.lora_grad(ws["dqkv"], ws["yb"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gbb[0], gbb[1])
             if l > 0:  # embeddings are frozen: nothing to do below layer 0

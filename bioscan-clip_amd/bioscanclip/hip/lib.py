@@ -56,6 +56,7 @@ SIGNATURES = {
     "bsclip_layernorm_bwd": (I, [P, I, I, P, P, I, I, P, I, P, I, P, P, I, P, I, P, I, F, U, F, U, I, P]),
     "bsclip_attn_fwd": (I, [P, I, I, I, I, P, F, P, I, P, I, P, F, U, P]),
     "bsclip_attn_bwd": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, P, F, U, P]),
+    "bsclip_attn_bwd_lora": (I, [P, I, P, I, P, I, I, I, P, F, P, I, I, P, P, I, P, P, P, F, U, P]),
     "bsclip_split3_rows": (I, [P, I, I, I, P, I, P]),
     "bsclip_split3_weight": (I, [P, I, I, I, P, P, I, P, I, P]),
     "bsclip_gelu_split3": (I, [P, I, I, I, P, I, P, I, P, I, P]),
@@ -95,6 +96,7 @@ SIGNATURES = {
     "bsclip_augment_images": (I, [P, P, I, L, P, I, P, P]),
     "bsclip_lora_grad_workspace_floats": (L, [I]),
     "bsclip_lora_grad": (I, [P, I, P, I, I, I, P, P, P, P, P, P, P]),
+    "bsclip_lora_grad_heads": (I, [P, I, I, I, I, P, P, P, P, P, P, P, P]),
     "bsclip_lora_grad_fp8": (I, [P, I, P, I, P, I, I, I, P, P, P, P, P, P, P]),
     "bsclip_colsum": (I, [P, I, I, I, I, P, P]),
     "bsclip_transpose_bf16": (I, [P, I, I, I, P, I, P]),

@@ -278,8 +278,11 @@ def attn_fwd(qkv, B, S, heads, scale, ctx, lse, key_bias=None, dropout=None, q_r
                                     int(q_rows), _p(keep_bits), dp, ds, _stream()))
 
 
-def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None, q_rows=0, keep_bits=None):
-    """``keep_bits``: the words the forward of the SAME (seed, step) left; None = re-hash the decisions (same masks, slower)."""
+def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=None, q_rows=0, keep_bits=None, lora=None):
+    """``keep_bits``: the words the forward of the SAME (seed, step) left; None = re-hash the decisions (same masks, slower).
+    ``lora`` = (t_aug, lora_b, dt_partial, db_partial): also leave the LoRA gradients' partial sums (``lora_grad_heads`` reduces them):
+    t_aug bf16 [>= B S, >= 8] with t in columns 0..7 (a view of the LayerNorm output's t block), lora_b f32 [2, H, 4], dt_partial f32
+    [heads, B S, 8], db_partial f32 [B heads, 2, 4, 64]."""
     ld_qkv, ld_ctx, ld_d = _rowmajor(qkv, "qkv"), _rowmajor(dctx, "dctx"), _rowmajor(dqkv, "dqkv")
     _keep_bits_ok(keep_bits, B, S, heads, "attn_bwd")
     _req(all(t.dtype == BF16 for t in (qkv, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
@@ -289,6 +292,18 @@ def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=No
     if key_bias is not None:
         _req(key_bias.dtype == F32 and key_bias.is_contiguous() and key_bias.numel() >= B * S, "key_bias f32 [B,S]")
     dp, ds = (0.0, 0) if dropout is None else (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF)
+    if lora is not None:
+        t_aug, lora_b, dtp, dbp = lora
+        ld_t = _rowmajor(t_aug, "t_aug")
+        _req(t_aug.dtype == BF16 and t_aug.shape[0] >= B * S and t_aug.shape[1] >= 8, "attn_bwd: t_aug bf16 [>= B S, >= 8]")
+        _req(lora_b.dtype == F32 and lora_b.is_contiguous() and tuple(lora_b.shape) == (2, heads * 64, 4), "attn_bwd: lora_b f32 [2,H,4]")
+        _req(dtp.dtype == F32 and dtp.is_contiguous() and dtp.numel() >= heads * B * S * 8
+             and dbp.dtype == F32 and dbp.is_contiguous() and dbp.numel() >= B * heads * 512, "attn_bwd: dt_partial / db_partial sizes")
+        _req(dp == 0.0 or keep_bits is not None, "attn_bwd: the LoRA partials under dropout need the forward's keep_bits")
+        check(_l.load().bsclip_attn_bwd_lora(_p(qkv), ld_qkv, _p(dctx), ld_ctx, _p(lse), B, S, heads, _p(key_bias), float(scale), _p(dqkv),
+                                             ld_d, int(q_rows), _p(keep_bits), _p(t_aug), ld_t, _p(lora_b), _p(dtp), _p(dbp), dp, ds,
+                                             _stream()))
+        return
     check(_l.load().bsclip_attn_bwd(_p(qkv), ld_qkv, _p(dctx), ld_ctx, _p(lse), B, S, heads, _p(key_bias),
                                     float(scale), _p(dqkv), ld_d, int(q_rows), _p(keep_bits), dp, ds, _stream()))
 
@@ -603,6 +618,19 @@ def lora_grad(dqkv, h_aug, M, H, lora_b, dt, dA, dBq, dBv):
     check(_l.load().bsclip_lora_grad(_p(dqkv), _rowmajor(dqkv, "dqkv"), _p(h_aug), _rowmajor(h_aug, "h_aug"), M, H,
                                      _p(lora_b), _p(dt), _p(dA), _p(dBq), _p(dBv),
                                      _p(_lora_grad_workspace(H, dqkv.device)), _stream()))
+
+
+def lora_grad_heads(h_aug, M, H, B, dt_partial, db_partial, dt, dA, dBq, dBv):
+    """``lora_grad`` from the partial sums ``attn_bwd(..., lora=...)`` left: dt [M, 8], dBq / dBv and dA accumulate as ``lora_grad``."""
+    heads = H // 64
+    _req(h_aug.dtype == BF16 and h_aug.shape[0] >= M and h_aug.shape[1] >= H and M % B == 0, "lora_grad_heads: h_aug bf16 [M, >= H]")
+    _req(dt_partial.dtype == F32 and dt_partial.is_contiguous() and dt_partial.numel() >= heads * M * 8
+         and db_partial.dtype == F32 and db_partial.is_contiguous() and db_partial.numel() >= B * heads * 512, "lora_grad_heads: partials")
+    _req(dt.dtype == F32 and dt.is_contiguous() and dt.numel() >= 8 * M, "dt f32 [M,8]")
+    _req(dA.dtype == F32 and dA.is_contiguous() and tuple(dA.shape) == (8, H), "dA f32 [8,H]")
+    _req(all(t.dtype == F32 and t.is_contiguous() and tuple(t.shape) == (H, 4) for t in (dBq, dBv)), "dB f32 [H,4]")
+    check(_l.load().bsclip_lora_grad_heads(_p(h_aug), _rowmajor(h_aug, "h_aug"), M, H, B, _p(dt_partial), _p(db_partial), _p(dt), _p(dA),
+                                           _p(dBq), _p(dBv), _p(_lora_grad_workspace(H, h_aug.device)), _stream()))
 
 
 def lora_grad_fp8(dqkv, y_fp8, t_aug, M, H, lora_b, dt, dA, dBq, dBv):

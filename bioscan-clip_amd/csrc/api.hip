@@ -14,7 +14,7 @@ void bsclip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bsclip_last_error(void) { return g_err; }
-extern "C" int bsclip_abi_version(void) { return 9; }  // 9: bsclip_attn_fwd2 / bsclip_attn_bwd2 leave the product library (diagnostic library only); 8: exact mode (split-operand GEMM helpers, f32 attention forward / backward, f32 LoRA gradients; layernorm_bwd resid_flags bits 2 / 3); 7: bsclip_attn_fwd2 / bsclip_attn_bwd2 (key-owner-sweep attention backward); 6: persistent GEMM (set_tile 8, set_persistent_grid), bsclip_clock_probe; 5: adamw_step_dev step word is uint32 (device-advanced), dropout step passes through the mixer; 4: layernorm_bwd in_dropout, fp8 / pipeline / comm / full-FT entry points, 8-bit gelu side band
+extern "C" int bsclip_abi_version(void) { return 10; }  // 10: bsclip_attn_bwd_lora / bsclip_lora_grad_heads (LoRA dt / dB partial sums out of the attention backward); 9: bsclip_attn_fwd2 / bsclip_attn_bwd2 leave the product library (diagnostic library only); 8: exact mode (split-operand GEMM helpers, f32 attention forward / backward, f32 LoRA gradients; layernorm_bwd resid_flags bits 2 / 3); 7: bsclip_attn_fwd2 / bsclip_attn_bwd2 (key-owner-sweep attention backward); 6: persistent GEMM (set_tile 8, set_persistent_grid), bsclip_clock_probe; 5: adamw_step_dev step word is uint32 (device-advanced), dropout step passes through the mixer; 4: layernorm_bwd in_dropout, fp8 / pipeline / comm / full-FT entry points, 8-bit gelu side band
 
 // ---- dropout step word ------------------------------------------------------------------------------------------
 static thread_local const unsigned* g_drop_step = nullptr;

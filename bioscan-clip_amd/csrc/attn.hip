@@ -189,14 +189,46 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
 // BITS (DROP only): the dropout decisions come from the keep-bit words the forward left (attn_common.h KEEP_WORDS) instead of being
 // re-hashed per element pair (query-owner phase) / per element (key-owner phase).  PRE (no dropout): the key-owner phase starts the
 // dP accumulator from -delta ("row constants as the initial accumulator", cdna_hip_programming.md, attention backward): dS = P dP'.
-template <int NB, bool DROP, bool DIAG = false, int TAIL = 32, bool BITS = false, bool PRE = false>
+//
+// LORA (round 5): the kernel also leaves what the rank-4 LoRA branches on q and v need from dq / dv while those still sit in the
+// accumulators -- lora_grad's first pass (optim.hip lora_grad_dt_db_kernel) read dq and dv back from HBM for it (155 MB per ViT layer):
+//   dt_partial[head][token][0:4 | 4:8] = dq_head . Bq_head | dv_head . Bv_head   (this head's 64 of the 768 terms; summed over heads later)
+//   db_partial[item][q | v][j][d]      = sum_token t[token][j] * dq | dv[token][d]  (this item's tokens; summed over the batch later)
+// Both are MFMA products.  dt: the accumulator tile (d on rows, token on the lane) is the B operand as it stands (k = d), the A operand
+// is B^T of the head -- hi + lo bf16 parts of the f32 master, so the product is the f32 one up to accumulation order.  db contracts
+// over tokens, which sit on the LANES of the accumulator: the bf16 tile goes through a small per-wave LDS tile ([32 tokens][32 d], 72-byte
+// rows) and comes back token-strided with ds_read_b64_tr_b16.  Only 4 accumulator rows (j) of either product are used; the rows of
+// the small A operands past j = 3 are zero.
+struct LoraPart {
+    const bf16_t* t;     // [tokens, ld_t]: t_q at columns 0..3, t_v at 4..7 (the LayerNorm's t block of the QKV GEMM's operand)
+    int ld_t;
+    const float* b;      // LoRA-B master [2][heads * 64][4]
+    float* dtp;          // [heads][tokens][8]
+    float* dbp;          // [B * heads][2][4][64]
+};
+constexpr int LORA_TILE = 32 * 72;   // bytes of one wave's transposition tile
+
+// the 8 k-elements of a [4][len] bf16 row-major table as an MFMA A fragment: row j = lane & 31 (zero for j >= 4), elements in the k order
+// of pack8() / frag_tr: c0 + 8 (jj >> 2) + 4 (lane >> 5) + (jj & 3)
+__device__ __forceinline__ bf16x8 small_frag(const bf16_t* tab, int len, int c0, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    uint2 a = {0u, 0u}, b = {0u, 0u};
+    if (j < 4) {
+        a = *reinterpret_cast<const uint2*>(tab + j * len + c0 + 4 * h);
+        b = *reinterpret_cast<const uint2*>(tab + j * len + c0 + 8 + 4 * h);
+    }
+    return __builtin_bit_cast(bf16x8, u32x4{a.x, a.y, b.x, b.y});
+}
+
+template <int NB, bool DROP, bool DIAG = false, int TAIL = 32, bool BITS = false, bool PRE = false, bool LORA = false>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld,
                                                                    const bf16_t* __restrict__ dctx, int ld_ctx,
                                                                    const float* __restrict__ lse, int S, int heads,
                                                                    const float* __restrict__ key_bias, float scale,
                                                                    bf16_t* __restrict__ dqkv, int ld_d, DropCfg drop,
                                                                    int nqb, unsigned long long* diag = nullptr,
-                                                                   const unsigned* __restrict__ kbits = nullptr) {
+                                                                   const unsigned* __restrict__ kbits = nullptr,
+                                                                   LoraPart lp = LoraPart{}) {
     static_assert(!(BITS && !DROP) && !(PRE && DROP), "BITS needs dropout, PRE excludes it");
     constexpr int SP = NB * 32;
     constexpr int RM = SP * ROWB;
@@ -207,13 +239,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         }
     };
     stamp(0);
-    __shared__ __attribute__((aligned(16))) char smem[2 * RM + 3 * SP * 4 + (BITS ? NB * SP * 4 : 0)];
+    constexpr int KB_BYTES = BITS ? NB * SP * 4 : 0;
+    constexpr int LORA_BYTES = LORA ? ATT_WAVES * LORA_TILE + 2 * 2 * 4 * 64 * 2 + 8 * SP * 2 : 0;
+    __shared__ __attribute__((aligned(16))) char smem[2 * RM + 3 * SP * 4 + KB_BYTES + LORA_BYTES];
     char* sR0 = smem;       // phase 1: K | phase 2: Q
     char* sR1 = smem + RM;  // phase 1: V | phase 2: dO
     float* sLse = reinterpret_cast<float*>(smem + 2 * RM);
     float* sDelta = sLse + SP;
     float* sBias = sDelta + SP;
     [[maybe_unused]] unsigned* sKb = reinterpret_cast<unsigned*>(sBias + SP);   // BITS, phase 2: keep words [key tile][query]
+    [[maybe_unused]] char* sTr = smem + 2 * RM + 3 * SP * 4 + KB_BYTES;           // LORA: per-wave transposition tiles, then the dB sums
+    [[maybe_unused]] bf16_t* sBt = reinterpret_cast<bf16_t*>(sTr + ATT_WAVES * LORA_TILE);   // B^T of the head: [q | v][hi | lo][j][d]
+    [[maybe_unused]] bf16_t* sTt = sBt + 2 * 2 * 4 * 64;                          // t^T of the item: [8 j][SP tokens], zero past S
 
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -234,6 +271,70 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         sBias[k] = (k < S) ? (key_bias ? key_bias[(size_t)b * S + k] * (1.0f / scale) : 0.f) : -INFINITY;
         sLse[k] = (k < S) ? lse[((size_t)b * heads + hd) * S + k] * LOG2E : INFINITY;  // padded queries -> p = 0
     }
+    if constexpr (LORA) {
+        for (int i = tid; i < 2 * 64 * 4; i += ATT_WAVES * 64) {   // i = (is_v * 64 + d) * 4 + j of the master
+            const int is_v = i >> 8, d = (i >> 2) & 63, j = i & 3;
+            const float x = lp.b[((size_t)is_v * HW + hd * 64 + d) * 4 + j];
+            const bf16_t hi = f2bf(x);
+            sBt[((is_v * 2 + 0) * 4 + j) * 64 + d] = hi;
+            sBt[((is_v * 2 + 1) * 4 + j) * 64 + d] = f2bf(x - bf2f(hi));
+        }
+        for (int tok = tid; tok < SP; tok += ATT_WAVES * 64) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (tok < S) v = *reinterpret_cast<const u32x4*>(lp.t + (size_t)(b * S + tok) * lp.ld_t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sTt[j * SP + tok] = (bf16_t)((v[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        }
+    }
+    // LoRA partial products of one 32-token block whose dq (is_v = 0) or dv (1) sits in acc (d on rows, token on the lane), already scaled
+    [[maybe_unused]] auto lora_part = [&](const f32x16 (&acc)[2], int is_v, int tok0, f32x4 (&kacc)[2]) {
+        char* tile = sTr + wave * LORA_TILE;
+        const bf16_t* bt = sBt + is_v * (2 * 4 * 64);
+        const bf16_t* tt = sTt + is_v * 4 * SP;
+        f32x16 dtacc = zero16();
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 xb = pack8(acc[dt], s2);   // k = d = 32 dt + 16 s2 + (pack8 order)
+                dtacc = mfma32(small_frag(bt, 64, 32 * dt + 16 * s2, lane), xb, dtacc);
+                dtacc = mfma32(small_frag(bt + 4 * 64, 64, 32 * dt + 16 * s2, lane), xb, dtacc);
+            }
+        const int tok = tok0 + (lane & 31);
+        if (h == 0 && tok < S)   // accumulator rows 0..3 = j, on lane half 0
+            *reinterpret_cast<f32x4*>(lp.dtp + (((size_t)hd * (gridDim.x / heads) + b) * S + tok) * 8 + 4 * is_v) =
+                f32x4{dtacc[0], dtacc[1], dtacc[2], dtacc[3]};
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // [token][d - 32 dt] bf16, 72-byte rows
+                uint2 o;
+                o.x = pack_bf2(acc[dt][4 * g + 0], acc[dt][4 * g + 1]);
+                o.y = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
+                *reinterpret_cast<uint2*>(tile + (lane & 31) * 72 + (8 * g + 4 * h) * 2) = o;
+            }
+            f32x16 dbacc = zero16();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)   // dB^T[j, d] += t^T[j, token] x[token, d]: the tile read token-strided
+                dbacc = mfma32(small_frag(tt, SP, tok0 + 16 * s2, lane), frag_tr_lin(tile, 72, 0, 16 * s2, lane), dbacc);
+            kacc[dt] += f32x4{dbacc[0], dbacc[1], dbacc[2], dbacc[3]};
+        }
+    };
+    // a phase's dB^T sums of the 4 waves -> db_partial[item][is_v][j][d]; call with all the workgroup's threads
+    [[maybe_unused]] auto lora_flush = [&](const f32x4 (&kacc)[2], int is_v) {
+        float* mine = reinterpret_cast<float*>(sTr + wave * LORA_TILE);
+        if (h == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine[j * 64 + 32 * dt + lane] = kacc[dt][j];
+        }
+        __syncthreads();
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) v += reinterpret_cast<const float*>(sTr + w * LORA_TILE)[tid];
+        lp.dbp[((size_t)bh * 2 + is_v) * 256 + tid] = v;
+    };
     stage_wait();
     __syncthreads();
     stamp(1);
@@ -247,8 +348,13 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             bf16_t* o = dqb + (size_t)q * ld_d + 32 * (lane >> 5);
 #pragma unroll
             for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(o + 8 * c) = u32x4{0u, 0u, 0u, 0u};
+            if constexpr (LORA) {
+                if (lane < 32)
+                    *reinterpret_cast<f32x4*>(lp.dtp + (((size_t)hd * (gridDim.x / heads) + b) * S + q) * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     }
+    [[maybe_unused]] f32x4 kacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
     for (int blk = wave; blk < nqb; blk += ATT_WAVES) {
         asm volatile("" ::: "memory");  // LDS tiles are loop-invariant: stop LICM from hoisting ~100 fragment registers
@@ -368,11 +474,25 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             }
         }
         const int q = q0 + (lane & 31);
-        if (q < S) store_dt(dq, scale, dqb + (size_t)q * ld_d, lane);
+        if constexpr (LORA) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[dt][r] *= scale;
+            lora_part(dq, 0, q0, kacc);
+            if (q < S) store_dt(dq, 1.0f, dqb + (size_t)q * ld_d, lane);
+        } else {
+            if (q < S) store_dt(dq, scale, dqb + (size_t)q * ld_d, lane);
+        }
         if (blk == wave) stamp(7);
     }
     stamp(2);
-    __syncthreads();
+    if constexpr (LORA) {
+        lora_flush(kacc, 0);   // (its barrier is the phase boundary)
+        kacc[0] = kacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        __syncthreads();
+    }
     stamp(3);
     // ---------------- phase 2 staging: Q, dO row-major ----------------
     stage_tile<SP>(qb, ld, S, sR0, wave, lane);
@@ -473,11 +593,13 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         for (int qt = 0; qt < nfull; ++qt) qtile(qt, std::false_type{});
         if (nfull < nqb) qtile(nqb - 1, std::true_type{});
         const int key = k0 + (lane & 31);
+        if constexpr (LORA) lora_part(dv, 1, k0, kacc);
         if (key < S) {
             store_dt(dk, scale, dqb + (size_t)key * ld_d + HW, lane);
             store_dt(dv, 1.0f, dqb + (size_t)key * ld_d + 2 * HW, lane);
         }
     }
+    if constexpr (LORA) lora_flush(kacc, 1);
     stamp(5);
 }
 
@@ -569,18 +691,21 @@ extern "C" int bsclip_attn_fwd2(const void* qkv, int ld_qkv, int B, int S, int h
 }
 #endif  // BSCLIP_DIAG
 
-#define ATTN_BWD_LAUNCH(NBV, DR, TL, BT, PR)                                                                     \
-    hipLaunchKernelGGL((attn_bwd_kernel<NBV, DR, false, TL, BT, PR>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s, \
+#define ATTN_BWD_LAUNCH(NBV, DR, TL, BT, PR, LR)                                                                 \
+    hipLaunchKernelGGL((attn_bwd_kernel<NBV, DR, false, TL, BT, PR, LR>), dim3(B * heads), dim3(ATT_WAVES * 64), 0, s, \
                        static_cast<const bf16_t*>(qkv), ld_qkv, static_cast<const bf16_t*>(dctx), ld_ctx, lse, S, heads, \
                        key_bias, scale, static_cast<bf16_t*>(dqkv), ld_dqkv, drop, nqb, static_cast<unsigned long long*>(nullptr), \
-                       static_cast<const unsigned*>(keep_bits))
-// dropout: from the forward's keep words when the caller has them, re-hashed otherwise; no dropout: delta preloaded (PRE)
+                       static_cast<const unsigned*>(keep_bits), lp)
+// dropout: from the forward's keep words when the caller has them, re-hashed otherwise; no dropout: delta preloaded (PRE).
+// The LoRA partial products ride on the two forms the engines run (keep words / preloaded delta).
 #define ATTN_BWD_PICK(NBV, TL)                                                                                   \
     do {                                                                                                         \
-        if (drop.thr16 && keep_bits) ATTN_BWD_LAUNCH(NBV, true, TL, true, false);                                \
-        else if (drop.thr16) ATTN_BWD_LAUNCH(NBV, true, TL, false, false);                                       \
-        else if (g_attn_preload) ATTN_BWD_LAUNCH(NBV, false, TL, false, true);                                   \
-        else ATTN_BWD_LAUNCH(NBV, false, TL, false, false);                                                      \
+        if (lp.dtp && drop.thr16) ATTN_BWD_LAUNCH(NBV, true, TL, true, false, true);                             \
+        else if (lp.dtp) ATTN_BWD_LAUNCH(NBV, false, TL, false, true, true);                                     \
+        else if (drop.thr16 && keep_bits) ATTN_BWD_LAUNCH(NBV, true, TL, true, false, false);                    \
+        else if (drop.thr16) ATTN_BWD_LAUNCH(NBV, true, TL, false, false, false);                                \
+        else if (g_attn_preload) ATTN_BWD_LAUNCH(NBV, false, TL, false, true, false);                            \
+        else ATTN_BWD_LAUNCH(NBV, false, TL, false, false, false);                                               \
     } while (0)
 #define ATTN_BWD_CASE(NBV)                                                                                       \
     case NBV:                                                                                                    \
@@ -589,9 +714,9 @@ extern "C" int bsclip_attn_fwd2(const void* qkv, int ld_qkv, int B, int S, int h
 // A/B switch of the round-5 "row constant as the initial accumulator" form of the no-dropout key-owner phase (default on)
 static const bool g_attn_preload = !(getenv("BSCLIP_ATTN_PRELOAD") && atoi(getenv("BSCLIP_ATTN_PRELOAD")) == 0);
 
-extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
-                               int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
-                               const void* keep_bits, float dropout_p, uint32_t dropout_seed, void* stream) {
+static int attn_bwd_launch(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S, int heads,
+                           const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows, const void* keep_bits,
+                           float dropout_p, uint32_t dropout_seed, LoraPart lp, void* stream) {
     BSCLIP_REQUIRE(qkv && dctx && lse && dqkv, "bsclip_attn_bwd: null pointer");
     BSCLIP_REQUIRE((reinterpret_cast<uintptr_t>(keep_bits) & 15) == 0, "bsclip_attn_bwd: keep_bits must be 16-byte aligned");
     BSCLIP_REQUIRE(B > 0 && heads > 0 && S > 0 && S <= 224, "bsclip_attn_bwd: B=%d heads=%d S=%d (S <= 224)", B, heads, S);
@@ -602,6 +727,7 @@ extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, in
     BSCLIP_REQUIRE(q_rows >= 0 && q_rows <= S, "bsclip_attn_bwd: q_rows=%d (0 = all, <= S)", q_rows);
     const int nqb = q_rows > 0 ? (q_rows + 31) / 32 : (S + 31) / 32;
     const DropCfg drop = make_drop(dropout_p, dropout_seed);
+    BSCLIP_REQUIRE(!lp.dtp || !drop.thr16 || keep_bits, "bsclip_attn_bwd_lora: with dropout the forward's keep_bits are required");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // S = 133 gains 5 % from the trimmed last tile; at S = 197 the trimmed instantiation schedules worse (268.6 vs 265.0 us)
     if (S == 133) {
@@ -614,6 +740,27 @@ extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, in
     }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;
+}
+
+extern "C" int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B,
+                               int S, int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
+                               const void* keep_bits, float dropout_p, uint32_t dropout_seed, void* stream) {
+    return attn_bwd_launch(qkv, ld_qkv, dctx, ld_ctx, lse, B, S, heads, key_bias, scale, dqkv, ld_dqkv, q_rows, keep_bits, dropout_p,
+                           dropout_seed, LoraPart{}, stream);
+}
+
+// bsclip_attn_bwd that also leaves the per-head / per-item partial sums of the LoRA gradients (see LoraPart): bsclip_lora_grad_heads
+// reduces them.  t_aug: the bf16 [B S, ld_t] block whose columns 0..7 hold t = y A^T (q ranks, then v ranks).
+extern "C" int bsclip_attn_bwd_lora(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
+                                    int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows,
+                                    const void* keep_bits, const void* t_aug, int ld_t, const float* lora_b, float* dt_partial,
+                                    float* db_partial, float dropout_p, uint32_t dropout_seed, void* stream) {
+    BSCLIP_REQUIRE(t_aug && lora_b && dt_partial && db_partial, "bsclip_attn_bwd_lora: null pointer");
+    BSCLIP_REQUIRE(ld_t >= 8 && ld_t % 8 == 0 && (reinterpret_cast<uintptr_t>(t_aug) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(dt_partial) & 15) == 0 && (reinterpret_cast<uintptr_t>(lora_b) & 3) == 0,
+                   "bsclip_attn_bwd_lora: t_aug / dt_partial must be 16-byte aligned, ld_t=%d a multiple of 8", ld_t);
+    return attn_bwd_launch(qkv, ld_qkv, dctx, ld_ctx, lse, B, S, heads, key_bias, scale, dqkv, ld_dqkv, q_rows, keep_bits, dropout_p,
+                           dropout_seed, LoraPart{static_cast<const bf16_t*>(t_aug), ld_t, lora_b, dt_partial, db_partial}, stream);
 }
 
 #ifdef BSCLIP_DIAG

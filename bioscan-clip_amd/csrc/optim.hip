@@ -290,16 +290,18 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_t_f32_kernel(const float* __res
 // Slab A (8H floats): index k*64 + l, k = [is_v][j][i][r];  slab B (8H floats): index ((r*NV + j)*4 + i)*64 + l.
 // Workgroup = 32 consecutive slab elements x 8 slab-groups; thread (i, p) sums slabs p, p+8, ... and the 8 partial
 // sums are combined in p order through LDS.
+// first_block = SLAB / 32 with a grid of SLAB / 32 workgroups sums the dA slabs only (bsclip_lora_grad_heads: dB comes from the
+// attention kernel's partials).
 template <int H>
 __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __restrict__ pa,
                                                                 const float* __restrict__ pb, int nblocks,
                                                                 float* __restrict__ dA, float* __restrict__ dBq,
-                                                                float* __restrict__ dBv) {
+                                                                float* __restrict__ dBv, int first_block = 0) {
     constexpr int NV = H / 256;
     constexpr int SLAB = 8 * H;
     __shared__ float red[8][32];
     const int i = threadIdx.x & 31, p = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + i;  // < 2*SLAB by construction (grid = 2*SLAB/32)
+    const int idx = (blockIdx.x + first_block) * 32 + i;  // < 2*SLAB by construction (grid = 2*SLAB/32)
     const bool second = idx >= SLAB;
     const int e = second ? idx - SLAB : idx;
     const float* src = (second ? pb : pa) + e;
@@ -329,6 +331,51 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __re
         const int ii = k & 3, j = (k >> 2) % NV, r = (k >> 2) / NV;
         dA[(size_t)r * H + j * 256 + l * 4 + ii] += s;
     }
+}
+
+// Sums what bsclip_attn_bwd_lora left (attn.hip LoraPart), in a fixed order:
+//   workgroups [0, nA):  dt[row][0:8] = sum_head dt_partial[head][row][0:8]        (thread = (row, 4-rank half); 12 loads in flight)
+//   the rest:            dB[q | v][head * 64 + d][j] += sum_item db_partial[item][q | v][j][d]   (as lora_grad_reduce_kernel: 32
+//                        consecutive elements x 8 item groups per workgroup, combined in group order through LDS)
+__global__ __launch_bounds__(256) void lora_heads_reduce_kernel(const float* __restrict__ dtp, const float* __restrict__ dbp, int M,
+                                                                 int heads, int items, int nA, float* __restrict__ dt,
+                                                                 float* __restrict__ dBq, float* __restrict__ dBv) {
+    if ((int)blockIdx.x < nA) {
+        const int g = blockIdx.x * 256 + threadIdx.x, row = g >> 1, half = g & 1;
+        if (row >= M) return;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int hd = 0; hd < heads; hd += 4) {   // heads is a multiple of 4 (8 or 12)
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(dtp + ((size_t)(hd + u) * M + row) * 8 + 4 * half);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        *reinterpret_cast<f32x4*>(dt + (size_t)row * 8 + 4 * half) = s;
+        return;
+    }
+    __shared__ float red[8][32];
+    const int i = threadIdx.x & 31, p = threadIdx.x >> 5;
+    const int e = ((int)blockIdx.x - nA) * 32 + i;   // < heads * 512 by construction
+    const size_t stride = (size_t)heads * 512;
+    const float* src = dbp + e;
+    float s = 0.f;
+    int b = p;
+    for (; b + 56 < items; b += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + 8 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < items; b += 8) s += src[(size_t)b * stride];
+    red[p][i] = s;
+    __syncthreads();
+    if (p != 0) return;
+    s = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + ((red[4][i] + red[5][i]) + (red[6][i] + red[7][i]));
+    const int hd = e >> 9, is_v = (e >> 8) & 1, j = (e >> 6) & 3, d = e & 63;
+    float* dst = (is_v ? dBv : dBq) + (size_t)(hd * 64 + d) * 4 + j;
+    *dst += s;
 }
 
 // out[n] += sum_r g[r, n] without atomics (bitwise reproducible) and without a workspace.
@@ -492,6 +539,40 @@ extern "C" int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, in
         hipLaunchKernelGGL((lora_grad_da_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, pb);
         hipLaunchKernelGGL((lora_grad_reduce_kernel<512>), dim3(16 * 512 / 32), dim3(256), 0, s, pa, pb,
                            blocks, dA, dBq, dBv);
+    }
+    BSCLIP_LAUNCH_CHECK();
+    return BSCLIP_OK;
+}
+
+// bsclip_lora_grad when the attention backward already left dt / dB as partial sums (bsclip_attn_bwd_lora): reduce them, then the dA pass.
+// dt_partial f32 [heads][M][8], db_partial f32 [B * heads][2][4][64] (B sequences of M / B tokens; item = sequence * heads + head).
+extern "C" int bsclip_lora_grad_heads(const void* h, int ld_h, int M, int H, int B, const float* dt_partial,
+                                      const float* db_partial, float* dt, float* dA, float* dBq, float* dBv, float* workspace,
+                                      void* stream) {
+    BSCLIP_REQUIRE(h && dt_partial && db_partial && dt && dA && dBq && dBv && workspace && M > 0 && B > 0 && M % B == 0,
+                   "bsclip_lora_grad_heads: null/empty input (M=%d B=%d)", M, B);
+    BSCLIP_REQUIRE(H == 768 || H == 512, "bsclip_lora_grad_heads: H=%d (supported: 768, 512)", H);
+    BSCLIP_REQUIRE(ld_h >= H && ld_h % 8 == 0, "bsclip_lora_grad_heads: ld_h=%d", ld_h);
+    BSCLIP_REQUIRE(((reinterpret_cast<uintptr_t>(dt_partial) | reinterpret_cast<uintptr_t>(dt)) & 15) == 0,
+                   "bsclip_lora_grad_heads: dt_partial and dt must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int heads = H / 64;
+    int blocks = ceil_div(M, 4 * 8);
+    if (blocks > LG_MAX_BLOCKS) blocks = LG_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    const bf16_t* hh = static_cast<const bf16_t*>(h);
+    float* pb = workspace + (size_t)LG_MAX_BLOCKS * 8 * H;
+    const int nA = ceil_div(2 * M, 256);
+    hipLaunchKernelGGL(lora_heads_reduce_kernel, dim3(nA + heads * 512 / 32), dim3(256), 0, s, dt_partial, db_partial, M, heads, B, nA,
+                       dt, dBq, dBv);
+    if (H == 768) {
+        hipLaunchKernelGGL((lora_grad_da_kernel<768>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, pb);
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<768>), dim3(8 * 768 / 32), dim3(256), 0, s, (const float*)nullptr, pb, blocks, dA,
+                           dBq, dBv, 8 * 768 / 32);
+    } else {
+        hipLaunchKernelGGL((lora_grad_da_kernel<512>), dim3(blocks), dim3(LG_BLOCK), 0, s, hh, ld_h, M, dt, pb);
+        hipLaunchKernelGGL((lora_grad_reduce_kernel<512>), dim3(8 * 512 / 32), dim3(256), 0, s, (const float*)nullptr, pb, blocks, dA,
+                           dBq, dBv, 8 * 512 / 32);
     }
     BSCLIP_LAUNCH_CHECK();
     return BSCLIP_OK;

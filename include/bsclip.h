@@ -231,6 +231,17 @@ int bsclip_attn_fwd(const void* qkv, int ld_qkv, int B, int S, int heads, const 
 int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S,
                     int heads, const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows, const void* keep_bits,
                     float dropout_p, uint32_t dropout_seed, void* stream);
+/* bsclip_attn_bwd that also leaves, from dq and dv while they are still in the accumulators, the partial sums of the rank-4 LoRA
+ * gradients on q and v (ABI 10; the first pass of bsclip_lora_grad re-read dq and dv from HBM for them):
+ *   dt_partial f32 [heads, B*S, 8]:       [h][m][0:4] = dq[m, head h] . B_q[head h],  [h][m][4:8] = dv[m, head h] . B_v[head h]
+ *   db_partial f32 [B*heads, 2, 4, 64]:   [b*heads+h][q|v][j][d] = sum over the tokens of sequence b of t[m][j (+4 for v)] * dq|dv[m][64 h + d]
+ * t_aug: bf16 [B*S, ld_t], t = y A^T in columns 0..7 (the LayerNorm's block of the QKV operand), 16-byte aligned, ld_t % 8 == 0;
+ * lora_b f32 [2, heads*64, 4] as bsclip_lora_grad.  With dropout the forward's keep_bits are required.  The products run on the matrix
+ * pipe with B as hi + lo bf16 parts: f32 results up to accumulation order.  bsclip_lora_grad_heads reduces the partials. */
+int bsclip_attn_bwd_lora(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, const float* lse, int B, int S, int heads,
+                         const float* key_bias, float scale, void* dqkv, int ld_dqkv, int q_rows, const void* keep_bits,
+                         const void* t_aug, int ld_t, const float* lora_b, float* dt_partial, float* db_partial, float dropout_p,
+                         uint32_t dropout_seed, void* stream);
 
 /* ---- "exact" forward mode (BSCLIP_PARITY=2; csrc/exact.hip): every trunk GEMM on split-bf16 operands, f32 attention -----------
  * A bf16 MFMA GEMM is exact to ~2^-16 when both operands are carried as hi + lo (hi = bf16(x), lo = bf16(x - hi)) and the product is
@@ -396,6 +407,11 @@ int bsclip_augment_images(const void* src_u8, const int32_t* records, int B, int
 int64_t bsclip_lora_grad_workspace_floats(int H);
 int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, int ld_h, int M, int H, const float* lora_b,
                      float* dt, float* dA, float* dBq, float* dBv, float* workspace, void* stream);
+/* lora_grad from the partial sums of bsclip_attn_bwd_lora (B sequences, M = B*S tokens, heads = H / 64): dt[M,8] = sum over heads of
+ * dt_partial, dBq / dBv += sum over sequences of db_partial, then dA += dt^T h[:, :H] as bsclip_lora_grad.  Same workspace; fixed
+ * summation order (bitwise reproducible). */
+int bsclip_lora_grad_heads(const void* h, int ld_h, int M, int H, int B, const float* dt_partial, const float* db_partial, float* dt,
+                           float* dA, float* dBq, float* dBv, float* workspace, void* stream);
 /* lora_grad with the fp8 operand layout: y_fp8 [M, ld_y bytes] (LN output, e4m3) and t_aug bf16 [M, ld_t] (t in cols [0,8)) */
 int bsclip_lora_grad_fp8(const void* dqkv, int ld_dqkv, const void* y_fp8, int ld_y, const void* t_aug, int ld_t, int M,
                          int H, const float* lora_b, float* dt, float* dA, float* dBq, float* dBv, float* workspace,

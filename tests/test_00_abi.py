@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/bsclip.h but not exported"
-    assert handle.bsclip_abi_version() == 9
+    assert handle.bsclip_abi_version() == 10
 
 
 def test_ctypes_table_matches_header():

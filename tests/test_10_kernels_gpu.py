@@ -509,6 +509,62 @@ def test_lora_grad(ops, H):
     assert rel_err(dA, 2 * ref_dt.t() @ y) < 1e-4
 
 
+@pytest.mark.parametrize("B,S,heads,p,q_rows", [(3, 197, 12, 0.0, 0), (3, 133, 12, 0.1, 0), (2, 197, 12, 0.0, 1), (5, 20, 8, 0.1, 0),
+                                                (2, 64, 8, 0.0, 0), (9, 1, 12, 0.0, 0), (2, 224, 12, 0.1, 0), (2, 100, 8, 0.0, 40)])
+def test_lora_grad_from_attention_partials(ops, B, S, heads, p, q_rows):
+    """bsclip_attn_bwd_lora + bsclip_lora_grad_heads (round 5: dt and dB as MFMA products of dq / dv while they sit in the attention
+    backward's accumulators, per head and per sequence, reduced in a fixed order) against bsclip_attn_bwd + bsclip_lora_grad, which read
+    dq and dv back from HBM: the same dqkv bit for bit, dt / dA / dB to f32 accumulation order (B enters as hi + lo bf16 parts)."""
+    H, M = heads * 64, B * S
+    qkv = dev(rnd(M, 3 * H, seed=1).bfloat16())
+    h = dev(rnd(M, H + 64, seed=2).bfloat16())
+    lb = dev(rnd(2, H, 4, seed=3, scale=0.1))
+    dctx = dev(rnd(M, H, seed=4).bfloat16())
+    if q_rows:
+        keep = torch.zeros(B, S, 1, dtype=torch.bool)
+        keep[:, :q_rows] = True
+        dctx = torch.where(dev(keep.reshape(M, 1)), dctx, torch.zeros_like(dctx))
+    drop = (p, 777) if p else None
+    ctx = torch.empty(M, H, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, heads, S, device="cuda")
+    bits = torch.zeros(B * heads * S * ops.KEEP_WORDS, device="cuda", dtype=torch.int32) if p else None
+    ops.attn_fwd(qkv, B, S, heads, 0.125, ctx, lse, dropout=drop, keep_bits=bits)
+
+    def grads():
+        return (torch.full((M, 8), float("nan"), device="cuda"), torch.zeros(8, H, device="cuda"), torch.zeros(H, 4, device="cuda"),
+                torch.zeros(H, 4, device="cuda"))
+    ref_d = torch.empty(M, 3 * H, device="cuda", dtype=torch.bfloat16)
+    ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, ref_d, dropout=drop, q_rows=q_rows, keep_bits=bits)
+    rdt, rdA, rdBq, rdBv = grads()
+    ops.lora_grad(ref_d, h, M, H, lb, rdt, rdA, rdBq, rdBv)
+
+    dqkv = torch.full((M, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dtp = torch.full((heads, M, 8), float("nan"), device="cuda")
+    dbp = torch.full((B * heads, 2, 4, 64), float("nan"), device="cuda")
+    ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv, dropout=drop, q_rows=q_rows, keep_bits=bits, lora=(h[:, H:], lb, dtp, dbp))
+    assert torch.equal(dqkv, ref_d)
+    assert torch.isfinite(dtp).all() and torch.isfinite(dbp).all()
+    dt, dA, dBq, dBv = grads()
+    ops.lora_grad_heads(h, M, H, B, dtp, dbp, dt, dA, dBq, dBv)
+    # direct f64 products from the same bf16 dq / dv
+    dq, dv = ref_d[:, :H].double(), ref_d[:, 2 * H:].double()
+    t = h[:, H:H + 8].double()
+    want_dt = torch.cat([dq @ lb[0].double(), dv @ lb[1].double()], 1)
+    for name, got, old, want in (("dt", dt, rdt, want_dt), ("dA", dA, rdA, want_dt.t() @ h[:, :H].double()),
+                                 ("dBq", dBq, rdBq, dq.t() @ t[:, :4]), ("dBv", dBv, rdBv, dv.t() @ t[:, 4:])):
+        floor = 1e-6 * want.norm() + 1e-30
+        err = ((got.double() - want).norm() / (want.norm() + floor)).item()
+        err_old = ((old.double() - want).norm() / (want.norm() + floor)).item()
+        assert err < 2e-5, (name, err, err_old)
+    ops.lora_grad_heads(h, M, H, B, dtp, dbp, dt, dA, dBq, dBv)   # accumulates into dA / dB like lora_grad, dt is overwritten
+    assert rel_err(dA, 2 * want_dt.t().float() @ h[:, :H].float()) < 1e-4 and rel_err(dBv, 2 * (dv.t() @ t[:, 4:]).float()) < 1e-4
+    again = grads()
+    ops.lora_grad_heads(h, M, H, B, dtp, dbp, *again)            # fixed summation order: bit-reproducible
+    first = grads()
+    ops.lora_grad_heads(h, M, H, B, dtp, dbp, *first)
+    assert all(torch.equal(a, b) for a, b in zip(again, first))
+
+
 def test_small_ops(ops):
     g16 = dev(rnd(1000, 768, seed=1).bfloat16())
     out = torch.zeros(768, device="cuda")

@@ -34,6 +34,17 @@ for name, S, p in (("vit", 197, 0.0), ("dna", 133, 0.1), ("dna-nodrop", 133, 0.0
     if p:
         cases += [("fwd+bits", lambda: ops.attn_fwd(qkv, Bk, S, hk, 0.125, ctx, lse, dropout=drop, keep_bits=bits)),
                   ("bwd+bits", lambda: ops.attn_bwd(qkv, dctx, lse, Bk, S, hk, 0.125, dqkv, dropout=drop, keep_bits=bits))]
+    if not HEAD:   # the LoRA partial sums out of the backward (round 5) and the two reductions that follow / the pass they replace
+        M = B * S
+        h = torch.randn(M, H + 64, device="cuda").bfloat16()
+        lb = torch.randn(2, H, 4, device="cuda") * 0.1
+        dtp, dbp = torch.empty(heads, M, 8, device="cuda"), torch.empty(B * heads, 2, 4, 64, device="cuda")
+        dt, dA = torch.empty(M, 8, device="cuda"), torch.zeros(8, H, device="cuda")
+        dBq, dBv = torch.zeros(H, 4, device="cuda"), torch.zeros(H, 4, device="cuda")
+        cases += [("bwd+lora", lambda: ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv, dropout=drop, keep_bits=bits,
+                                                    lora=(h[:, H:], lb, dtp, dbp))),
+                  ("lora_grad", lambda: ops.lora_grad(dqkv, h, M, H, lb, dt, dA, dBq, dBv)),
+                  ("lora_heads", lambda: ops.lora_grad_heads(h, M, H, B, dtp, dbp, dt, dA, dBq, dBv))]
     for what, fn in cases:
         fn()
         best = 1e9
@@ -51,4 +62,8 @@ for name, S, p in (("vit", 197, 0.0), ("dna", 133, 0.1), ("dna-nodrop", 133, 0.0
             f"bwd {res['bwd']*1e3:7.1f} us ({2.5*fl/res['bwd']/1e9:6.1f} TF at 5 products)")
     if p:
         line += f"   |  keep-bit words: fwd {res['fwd+bits']*1e3:7.1f} us   bwd {res['bwd+bits']*1e3:7.1f} us"
+    if "bwd+lora" in res:
+        base = res["bwd+bits"] if p else res["bwd"]
+        line += (f"\n{'':11s} LoRA partials: bwd {res['bwd+lora']*1e3:7.1f} us (+{(res['bwd+lora']-base)*1e3:5.1f})   lora_grad_heads {res['lora_heads']*1e3:6.1f} us"
+                 f"   vs lora_grad {res['lora_grad']*1e3:6.1f} us   net {((res['bwd+lora']-base)+res['lora_heads']-res['lora_grad'])*1e3:+6.1f} us per layer")
     print(line, flush=True)
