@@ -33,3 +33,10 @@ print(f"fwd plain {t(lambda: ops.layernorm_fwd(x, g, b, 1e-6, y_bf16=y, stats=st
       f"fwd + LoRA t {t(lambda: ops.layernorm_fwd(x, g, b, 1e-6, y_bf16=y, lora_a=A, stats=st)):.1f} us")
 print(f"bwd plain {t(lambda: ops.layernorm_bwd(x, st, g, 0, g_resid=gr, g_gemm=gg, dx_f32=dx, dx_bf16=dxb)):.1f} us   "
       f"bwd + dt.A {t(lambda: ops.layernorm_bwd(x, st, g, 0, g_resid=gr, g_gemm=gg, dt=dt, lora_a=A, dx_f32=dx, dx_bf16=dxb)):.1f} us")
+# the step's dtypes: bf16 residual stream in, bf16 residual-gradient stream, one bf16 output (profiles/r05_f_serial_kernel_stats.csv:
+# layernorm_fwd_kernel<768, true, true> 35.4 us, <768, true, false> 23.8; layernorm_bwd_kernel<768, true, true> 59.2, <.., false> 45.1)
+xb, grb = x.bfloat16(), gr.bfloat16()
+print(f"bf16 stream: fwd plain {t(lambda: ops.layernorm_fwd(xb, g, b, 1e-6, y_bf16=y, stats=st)):.1f} us   "
+      f"fwd + LoRA t {t(lambda: ops.layernorm_fwd(xb, g, b, 1e-6, y_bf16=y, lora_a=A, stats=st)):.1f} us")
+print(f"bf16 stream: bwd plain {t(lambda: ops.layernorm_bwd(xb, st, g, 0, g_resid=grb, g_gemm=gg, dx_bf16=dxb)):.1f} us   "
+      f"bwd + dt.A {t(lambda: ops.layernorm_bwd(xb, st, g, 0, g_resid=grb, g_gemm=gg, dt=dt, lora_a=A, dx_bf16=dxb)):.1f} us")
