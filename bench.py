@@ -211,13 +211,16 @@ def time_families(B, device, reps=3):
             # with dropout the forward leaves its keep decisions as bit words and the backward reads them: the engines' path (round 5)
             bits = torch.zeros(B * 12 * S * ops.KEEP_WORDS, device=device, dtype=torch.int32) if p else None
             ops.attn_fwd(qkv, B, S, 12, 0.125, ctx, lse, dropout=drop, keep_bits=bits)
-            bufs.append((S, qkv, ctx, lse, dctx, dqkv, drop, bits, cnt))
+            # the backward also leaves the LoRA gradients' dt / dB partial sums (bsclip_attn_bwd_lora): the engines' path (round 5)
+            lora = (torch.randn(B * S, 64, device=device).bfloat16(), torch.randn(2, 768, 4, device=device) * 0.1,
+                    torch.empty(12, B * S, 8, device=device), torch.empty(B * 12, 2, 4, 64, device=device))
+            bufs.append((S, qkv, ctx, lse, dctx, dqkv, drop, bits, lora, cnt))
 
         def mix():
-            for S, qkv, ctx, lse, dctx, dqkv, drop, bits, cnt in bufs:
+            for S, qkv, ctx, lse, dctx, dqkv, drop, bits, lora, cnt in bufs:
                 for _ in range(cnt):
                     if bwd:
-                        ops.attn_bwd(qkv, dctx, lse, B, S, 12, 0.125, dqkv, dropout=drop, keep_bits=bits)
+                        ops.attn_bwd(qkv, dctx, lse, B, S, 12, 0.125, dqkv, dropout=drop, keep_bits=bits, lora=lora)
                     else:
                         ops.attn_fwd(qkv, B, S, 12, 0.125, ctx, lse, dropout=drop, keep_bits=bits)
         n = sum(b[-1] for b in bufs)
@@ -233,7 +236,7 @@ def time_families(B, device, reps=3):
         ("bias-free dX (dfc1, dproj, dqkv)", *gemm_family([(Mv, 768, 3072, 11), (Mv, 768, 768, 11), (Mv, 768, 2304, 11), (Md, 768, 3072, 12),
                                                          (Md, 768, 768, 12), (Md, 768, 2304, 12)], EPI_BF16, False)),
         ("attention forward (S = 197; S = 133 with dropout)", *attn_family(False)),
-        ("attention backward", *attn_family(True)),
+        ("attention backward (+ LoRA dt / dB partial sums)", *attn_family(True)),
     ]
     out = []
     for name, mix, n, flops in fams:
