@@ -16,7 +16,7 @@ it, so the fused [3H, H] operand and its gradient are plain views.
 """
 import torch
 
-from . import ops
+from . import engine, ops
 from .engine import BF16, F32, BertEngine, ViTEngine, split_plan
 from .lib import EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_RESID_F32, KPAD
 
@@ -179,12 +179,17 @@ class ViTEngineFT(_FTMixin, ViTEngine):
                 ops.layernorm_bwd(x[2 * l + 1], ws["st2"][l], lay.ln2[0], 0, g_resid=dx, g_gemm=ws["dh"], dx_f32=dx, dx_bf16=dxb)
                 self._dw(dxb, ws["ctx"][l], M, H, H, f"{l}.proj.w", f"{l}.proj.b")
                 ops.gemm(dxb, lay.w_proj_t, ws["dctx"], EPI_BF16)
-            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"], q_rows=1 if l == L - 1 else 0)
-            self._dw(ws["dqkv"], ws["h1"][l], M, 3 * H, H, f"{l}.qkv.w", f"{l}.qkv.b")
             lb = self.lora_b(l)
+            part = lb is not None and engine.ATTN_LORA    # the LoRA regime's path: dt / dB partial sums out of the attention backward
+            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"], q_rows=1 if l == L - 1 else 0,
+                         lora=(ws["h1"][l][:, H:], lb, ws["dtp"], ws["dbp"]) if part else None)
+            self._dw(ws["dqkv"], ws["h1"][l], M, 3 * H, H, f"{l}.qkv.w", f"{l}.qkv.b")
             if lb is not None:
                 gb = self.lora_b(l, grad=True)
-                ops.lora_grad(ws["dqkv"], ws["h1"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gb[0], gb[1])
+                if part:
+                    ops.lora_grad_heads(ws["h1"][l], M, H, B, ws["dtp"], ws["dbp"], ws["dt"], self.lora_a(l, grad=True), gb[0], gb[1])
+                else:
+                    ops.lora_grad(ws["dqkv"], ws["h1"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gb[0], gb[1])
             # the chain continues through block 0: patch filters, cls token and position table are trained too
             ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
             dt, la = (ws["dt"], self.lora_a(l)) if lb is not None else (None, None)
@@ -306,13 +311,18 @@ class BertEngineFT(_FTMixin, BertEngine):
             self._dw(ws["dsb"], ws["ctx"][l], M, H, H, f"{l}.o.w", f"{l}.o.b")
             ops.gemm(ws["dsb"], lay.w_o_t, ws["dctx"], EPI_BF16)
             drop_p = self._drop(ws, self.p_attn, l, 1)   # the forward (BertEngine.forward) left its keep decisions in ws["kbits"]
-            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"], key_bias=ws["key_bias"],
-                         dropout=drop_p, keep_bits=ws["kbits"][l] if drop_p is not None and ws["kbits"] is not None else None)
-            self._dw(ws["dqkv"], ws["yb"][l], M, 3 * H, H, f"{l}.q.w", f"{l}.q.b", w_n=3 * H * H)
             lb = self.lora_b(l)
+            kb = ws["kbits"][l] if drop_p is not None and ws["kbits"] is not None else None
+            part = lb is not None and engine.ATTN_LORA and (drop_p is None or kb is not None)
+            ops.attn_bwd(ws["qkv"][l], ws["dctx"], ws["lse"][l], B, S, self.heads, scale, ws["dqkv"], key_bias=ws["key_bias"],
+                         dropout=drop_p, keep_bits=kb, lora=(ws["yb"][l][:, H:], lb, ws["dtp"], ws["dbp"]) if part else None)
+            self._dw(ws["dqkv"], ws["yb"][l], M, 3 * H, H, f"{l}.q.w", f"{l}.q.b", w_n=3 * H * H)
             if lb is not None:
                 gbb = self.lora_b(l, grad=True)
-                ops.lora_grad(ws["dqkv"], ws["yb"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gbb[0], gbb[1])
+                if part:
+                    ops.lora_grad_heads(ws["yb"][l], M, H, B, ws["dtp"], ws["dbp"], ws["dt"], self.lora_a(l, grad=True), gbb[0], gbb[1])
+                else:
+                    ops.lora_grad(ws["dqkv"], ws["yb"][l], M, H, lb, ws["dt"], self.lora_a(l, grad=True), gbb[0], gbb[1])
             ops.gemm(ws["dqkv"], lay.wqkv_t, ws["dh"], EPI_BF16)
             g_resid, g_gemm = ws["ds1"], ws["dh"]
             dt_in, a_in = (ws["dt"], self.lora_a(l)) if lb is not None else (None, None)

@@ -20,6 +20,8 @@ from bioscanclip.model.language_encoder import LoRA_bert, load_pre_trained_bert
 _TOWER_STREAMS = __import__("os").environ.get("BSCLIP_TOWER_STREAMS", "1") != "0"
 # host enqueue order of the towers: the longer (image) tower first measured 45.40 vs 45.72 ms/step with DNA first
 _IMAGE_FIRST = __import__("os").environ.get("BSCLIP_IMAGE_FIRST", "1") == "1"
+# debugging: tower indices (0 = DNA, 1 = image, 2 = text) that stay on the caller's stream while the others fork, e.g. "2"
+_SERIAL_TOWERS = {int(i) for i in __import__("os").environ.get("BSCLIP_TOWER_SERIAL", "").split(",") if i.strip()}
 _streams = {}
 
 
@@ -59,7 +61,7 @@ class SimpleCLIP(nn.Module):
             enc, x = towers[k]
             if enc is None:
                 continue
-            if use_streams and not isinstance(enc, Freeze_DNA_Encoder):
+            if use_streams and k not in _SERIAL_TOWERS and not isinstance(enc, Freeze_DNA_Encoder):
                 side = _tower_stream(k, cur.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side), forked_from(cur):

@@ -46,6 +46,22 @@ __device__ __forceinline__ float reduce8(float (&p)[8], int lane) {
 
 constexpr int LG_BLOCK = 256;
 
+// One value in all four elements, in registers of its own (opaque to the compiler): the packed FMAs that follow take plain operands
+// instead of broadcasting one half of a register pair through op_sel.
+// Why (round 5, docs/HISTORY.md "the lost quarter-wave"): in the exact mode's three-tower step the BarcodeBERT tower's first
+// bsclip_lora_grad_f32 of a backward -- and only that launch, the one that runs beside the other towers' first backward kernels --
+// left, once in a few dozen steps, 16-80 words of its dA / dB slabs off by one row's contribution: always lanes 48-63, always the LOW
+// half of a `v_pk_fma_f32 acc, y, d op_sel:[0,1,0]` whose multiplier is the HIGH register of a pair filled by a wave-uniform
+// global_load_dwordx4 (dt[row, 0:8] / a row of dq), identical inputs, never reproducible with the kernel alone under synthetic load
+// (tools/stress_lora_f32.py: 0 of 8 000).  tests/test_30's exact three-tower graph-vs-eager case failed in ~40 % of the suite runs;
+// with the multipliers splatted first (this function) 48 of 48 iterations of tools/debug_graph_flake.py are bit-equal (before: a mismatch
+// within 4 iterations in 9 of 10 runs).  The cause below the ISA is not established; the form that does not show it is kept.
+__device__ __forceinline__ f32x4 splat4(float v) {
+    f32x4 s = {v, v, v, v};
+    asm volatile("" : "+v"(s));
+    return s;
+}
+
 // 4-way transpose-reduce: lane bits (5,4) end up owning index r
 __device__ __forceinline__ float reduce4(float (&p)[4], int lane) {
     float q[2];
@@ -144,8 +160,9 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const void* _
         for (int j = 0; j < NV; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                px += dx[j][i] * bx[j][i];
-                ax[j][i] += dx[j][i] * tx;
+                const f32x4 d4 = splat4(dx[j][i]);
+                px += d4 * bx[j][i];
+                ax[j][i] += d4 * tx;
             }
         float p[4] = {px[0], px[1], px[2], px[3]};
         const float tot = reduce4(p, lane);
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const void* _
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mine[((j * 16 + i * 4 + r) * 64) + lane] += ax[j][i][r];
+                    for (int r = 0; r < 4; ++r) lds_add(&mine[((j * 16 + i * 4 + r) * 64) + lane], ax[j][i][r]);
         }
     }
     __syncthreads();
@@ -230,8 +247,8 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const void* __re
                     y = f32x4{bf2f(yr[p][j].x & 0xffff), bf2f(yr[p][j].x >> 16), bf2f(yr[p][j].y & 0xffff), bf2f(yr[p][j].y >> 16)};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    acc[r][j] += d0[p][r] * y;
-                    acc[4 + r][j] += d1[p][r] * y;
+                    acc[r][j] += splat4(d0[p][r]) * y;
+                    acc[4 + r][j] += splat4(d1[p][r]) * y;
                 }
             }
         }
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const void* __re
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) red[(((r * NV + j) * 4 + i) * 64) + lane] += acc[r][j][i];
+                    for (int i = 0; i < 4; ++i) lds_add(&red[(((r * NV + j) * 4 + i) * 64) + lane], acc[r][j][i]);
         }
     }
     __syncthreads();
