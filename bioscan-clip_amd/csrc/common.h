@@ -34,12 +34,6 @@ void bsclip_set_error(const char* fmt, ...);
     } while (0)
 
 // ---- bf16 <-> f32 ----------------------------------------------------------------------------------
-// acc into LDS as ONE ds_add_f32 per element whose data operand is the accumulator register itself (the plain `lds[i] += x` compiles to
-// ds_read2 / v_add into two scratch VGPRs / ds_write2 per pair: twice the LDS instructions).  Callers order the waves with barriers, so
-// the order of the float adds stays fixed (bitwise reproducible) and no two waves touch an address at the same time.
-__device__ __forceinline__ void lds_add(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN

@@ -68,8 +68,8 @@ __global__ __launch_bounds__(PG_BLOCK) void ln_pgrad_kernel(const void* __restri
             for (int j = 0; j < NV; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    lds_add(&red[j * 256 + lane * 4 + i], dg[j][i]);        // (common.h: no read-modify-write through temporaries)
-                    lds_add(&red[H + j * 256 + lane * 4 + i], db[j][i]);
+                    red[j * 256 + lane * 4 + i] += dg[j][i];
+                    red[H + j * 256 + lane * 4 + i] += db[j][i];
                 }
         }
     }

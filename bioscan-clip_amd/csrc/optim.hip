@@ -54,11 +54,14 @@ constexpr int LG_BLOCK = 256;
 // half of a `v_pk_fma_f32 acc, y, d op_sel:[0,1,0]` whose multiplier is the HIGH register of a pair filled by a wave-uniform
 // global_load_dwordx4 (dt[row, 0:8] / a row of dq), identical inputs, never reproducible with the kernel alone under synthetic load
 // (tools/stress_lora_f32.py: 0 of 8 000).  tests/test_30's exact three-tower graph-vs-eager case failed in ~40 % of the suite runs;
-// with the multipliers splatted first (this function) 48 of 48 iterations of tools/debug_graph_flake.py are bit-equal (before: a mismatch
-// within 4 iterations in 9 of 10 runs).  The cause below the ISA is not established; the form that does not show it is kept.
+// with the multipliers splatted first (this function) 120 of 120 iterations of tools/debug_graph_flake.py are bit-equal (before: a mismatch
+// within 4 iterations in 9 of 10 runs).  The cause below the ISA is not established; the form that does not show it is kept.  (Also
+// tried and NOT the cause: the cross-wave LDS sums as ds_add_f32 instead of ds_read2 / v_add / ds_write2 -- the flake stayed, and LDS
+// float atomics cost the dA pass 111 instead of 23 us.)  The dt / dB pass pays for it (no packed FMAs left: 41 -> ~70 us); it only runs
+// in the fp8 and exact configurations since the attention backward leaves those sums itself.
 __device__ __forceinline__ f32x4 splat4(float v) {
     f32x4 s = {v, v, v, v};
-    asm volatile("" : "+v"(s));
+    asm("" : "+v"(s));   // not volatile: as an ordering point between the row loads it cost the da kernel 111 instead of 23 us
     return s;
 }
 
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_dt_db_kernel(const void* _
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) lds_add(&mine[((j * 16 + i * 4 + r) * 64) + lane], ax[j][i][r]);
+                    for (int r = 0; r < 4; ++r) mine[((j * 16 + i * 4 + r) * 64) + lane] += ax[j][i][r];
         }
     }
     __syncthreads();
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_grad_da_kernel(const void* __re
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) lds_add(&red[(((r * NV + j) * 4 + i) * 64) + lane], acc[r][j][i]);
+                    for (int i = 0; i < 4; ++i) red[(((r * NV + j) * 4 + i) * 64) + lane] += acc[r][j][i];
         }
     }
     __syncthreads();
