@@ -213,7 +213,7 @@ def time_families(B, device, reps=3):
             ops.attn_fwd(qkv, B, S, 12, 0.125, ctx, lse, dropout=drop, keep_bits=bits)
             # the backward also leaves the LoRA gradients' dt / dB partial sums (bsclip_attn_bwd_lora): the engines' path (round 5)
             lora = (torch.randn(B * S, 64, device=device).bfloat16(), torch.randn(2, 768, 4, device=device) * 0.1,
-                    torch.empty(12, B * S, 8, device=device), torch.empty(B * 12, 2, 4, 64, device=device))
+                    torch.empty(12, 2, B * S, 4, device=device), torch.empty(B * 12, 2, 4, 64, device=device))
             bufs.append((S, qkv, ctx, lse, dctx, dqkv, drop, bits, lora, cnt))
 
         def mix():

@@ -437,7 +437,7 @@ class ViTEngine(EncoderEngineBase):
         ws["dctx"] = z(M, H)
         ws["dqkv"] = z(M, 3 * H)
         ws["dt"] = z(M, 8, dt=F32)
-        ws["dtp"], ws["dbp"] = z(self.heads, M, 8, dt=F32), z(B * self.heads, 2, 4, 64, dt=F32)   # LoRA partial sums (ATTN_LORA)
+        ws["dtp"], ws["dbp"] = z(self.heads, 2, M, 4, dt=F32), z(B * self.heads, 2, 4, 64, dt=F32)   # LoRA partial sums (ATTN_LORA)
         Bp = _pad64(B)
         ws["dout_bf"] = torch.zeros(B, self.out_dim, dtype=BF16, device=dev)
         ws["dout_t"] = torch.zeros(self.out_dim, Bp, dtype=BF16, device=dev)
@@ -819,7 +819,7 @@ class BertEngine(EncoderEngineBase):
         ws["dctx"] = z(M, H)
         ws["dqkv"] = z(M, 3 * H)
         ws["dt"] = z(M, 8, dt=F32)
-        ws["dtp"], ws["dbp"] = z(self.heads, M, 8, dt=F32), z(B * self.heads, 2, 4, 64, dt=F32)   # LoRA partial sums (ATTN_LORA)
+        ws["dtp"], ws["dbp"] = z(self.heads, 2, M, 4, dt=F32), z(B * self.heads, 2, 4, 64, dt=F32)   # LoRA partial sums (ATTN_LORA)
         if self.head == "mlm_softmax_mean":
             ws["head_splits"], Mp = split_plan(M, self.out_dim, H)
             if ws["head_splits"] > 1:

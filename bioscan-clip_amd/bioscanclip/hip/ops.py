@@ -282,7 +282,7 @@ def attn_bwd(qkv, dctx, lse, B, S, heads, scale, dqkv, key_bias=None, dropout=No
     """``keep_bits``: the words the forward of the SAME (seed, step) left; None = re-hash the decisions (same masks, slower).
     ``lora`` = (t_aug, lora_b, dt_partial, db_partial): also leave the LoRA gradients' partial sums (``lora_grad_heads`` reduces them):
     t_aug bf16 [>= B S, >= 8] with t in columns 0..7 (a view of the LayerNorm output's t block), lora_b f32 [2, H, 4], dt_partial f32
-    [heads, B S, 8], db_partial f32 [B heads, 2, 4, 64]."""
+    [heads, 2, B S, 4], db_partial f32 [B heads, 2, 4, 64]."""
     ld_qkv, ld_ctx, ld_d = _rowmajor(qkv, "qkv"), _rowmajor(dctx, "dctx"), _rowmajor(dqkv, "dqkv")
     _keep_bits_ok(keep_bits, B, S, heads, "attn_bwd")
     _req(all(t.dtype == BF16 for t in (qkv, dctx, dqkv)) and lse.dtype == F32, "attn_bwd dtypes")
@@ -621,7 +621,7 @@ def lora_grad(dqkv, h_aug, M, H, lora_b, dt, dA, dBq, dBv):
 
 
 def lora_grad_heads(h_aug, M, H, B, dt_partial, db_partial, dt, dA, dBq, dBv):
-    """``lora_grad`` from the partial sums ``attn_bwd(..., lora=...)`` left: dt [M, 8], dBq / dBv and dA accumulate as ``lora_grad``."""
+    """``lora_grad`` from the partial sums ``attn_bwd(..., lora=...)`` left: dt [M, 8], dBq / dBv and dA accumulate as ``lora_grad`` (dt_partial f32 [heads, 2, M, 4], db_partial f32 [B heads, 2, 4, 64])."""
     heads = H // 64
     _req(h_aug.dtype == BF16 and h_aug.shape[0] >= M and h_aug.shape[1] >= H and M % B == 0, "lora_grad_heads: h_aug bf16 [M, >= H]")
     _req(dt_partial.dtype == F32 and dt_partial.is_contiguous() and dt_partial.numel() >= heads * M * 8

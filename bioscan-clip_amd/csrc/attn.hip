@@ -192,7 +192,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_fwd_kernel(const bf16_
 //
 // LORA (round 5): the kernel also leaves what the rank-4 LoRA branches on q and v need from dq / dv while those still sit in the
 // accumulators -- lora_grad's first pass (optim.hip lora_grad_dt_db_kernel) read dq and dv back from HBM for it (155 MB per ViT layer):
-//   dt_partial[head][token][0:4 | 4:8] = dq_head . Bq_head | dv_head . Bv_head   (this head's 64 of the 768 terms; summed over heads later)
+//   dt_partial[head][q | v][token][0:4] = dq_head . Bq_head | dv_head . Bv_head   (this head's 64 of the 768 terms; summed over heads later;
+//                                          a wave's 32 tokens are 512 contiguous bytes: whole lines, written once)
 //   db_partial[item][q | v][j][d]      = sum_token t[token][j] * dq | dv[token][d]  (this item's tokens; summed over the batch later)
 // Both are MFMA products.  dt: the accumulator tile (d on rows, token on the lane) is the B operand as it stands (k = d), the A operand
 // is B^T of the head -- hi + lo bf16 parts of the f32 master, so the product is the f32 one up to accumulation order.  db contracts
@@ -203,7 +204,7 @@ struct LoraPart {
     const bf16_t* t;     // [tokens, ld_t]: t_q at columns 0..3, t_v at 4..7 (the LayerNorm's t block of the QKV GEMM's operand)
     int ld_t;
     const float* b;      // LoRA-B master [2][heads * 64][4]
-    float* dtp;          // [heads][tokens][8]
+    float* dtp;          // [heads][2][tokens][4]
     float* dbp;          // [B * heads][2][4][64]
 };
 constexpr int LORA_TILE = 32 * 72;   // bytes of one wave's transposition tile
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             }
         const int tok = tok0 + (lane & 31);
         if (h == 0 && tok < S)   // accumulator rows 0..3 = j, on lane half 0
-            *reinterpret_cast<f32x4*>(lp.dtp + (((size_t)hd * (gridDim.x / heads) + b) * S + tok) * 8 + 4 * is_v) =
+            *reinterpret_cast<f32x4*>(lp.dtp + ((((size_t)hd * 2 + is_v) * (gridDim.x / heads) + b) * S + tok) * 4) =
                 f32x4{dtacc[0], dtacc[1], dtacc[2], dtacc[3]};
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
             for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(o + 8 * c) = u32x4{0u, 0u, 0u, 0u};
             if constexpr (LORA) {
                 if (lane < 32)
-                    *reinterpret_cast<f32x4*>(lp.dtp + (((size_t)hd * (gridDim.x / heads) + b) * S + q) * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(lp.dtp + (((size_t)hd * 2 * (gridDim.x / heads) + b) * S + q) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }

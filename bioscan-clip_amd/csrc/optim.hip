@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __re
 }
 
 // Sums what bsclip_attn_bwd_lora left (attn.hip LoraPart), in a fixed order:
-//   workgroups [0, nA):  dt[row][0:8] = sum_head dt_partial[head][row][0:8]        (thread = (row, 4-rank half); 12 loads in flight)
+//   workgroups [0, nA):  dt[row][4 half : 4 half + 4] = sum_head dt_partial[head][half][row][0:4]   (thread = (row, half); 12 loads in flight)
 //   the rest:            dB[q | v][head * 64 + d][j] += sum_item db_partial[item][q | v][j][d]   (as lora_grad_reduce_kernel: 32
 //                        consecutive elements x 8 item groups per workgroup, combined in group order through LDS)
 __global__ __launch_bounds__(256) void lora_heads_reduce_kernel(const float* __restrict__ dtp, const float* __restrict__ dbp, int M,
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void lora_heads_reduce_kernel(const float* __r
         for (int hd = 0; hd < heads; hd += 4) {   // heads is a multiple of 4 (8 or 12)
             f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(dtp + ((size_t)(hd + u) * M + row) * 8 + 4 * half);
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(dtp + (((size_t)(hd + u) * 2 + half) * M + row) * 4);
 #pragma unroll
             for (int u = 0; u < 4; ++u) s += v[u];
         }
@@ -565,7 +565,7 @@ extern "C" int bsclip_lora_grad(const void* dqkv, int ld_dqkv, const void* h, in
 }
 
 // bsclip_lora_grad when the attention backward already left dt / dB as partial sums (bsclip_attn_bwd_lora): reduce them, then the dA pass.
-// dt_partial f32 [heads][M][8], db_partial f32 [B * heads][2][4][64] (B sequences of M / B tokens; item = sequence * heads + head).
+// dt_partial f32 [heads][2][M][4], db_partial f32 [B * heads][2][4][64] (B sequences of M / B tokens; item = sequence * heads + head).
 extern "C" int bsclip_lora_grad_heads(const void* h, int ld_h, int M, int H, int B, const float* dt_partial,
                                       const float* db_partial, float* dt, float* dA, float* dBq, float* dBv, float* workspace,
                                       void* stream) {

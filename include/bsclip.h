@@ -233,7 +233,7 @@ int bsclip_attn_bwd(const void* qkv, int ld_qkv, const void* dctx, int ld_ctx, c
                     float dropout_p, uint32_t dropout_seed, void* stream);
 /* bsclip_attn_bwd that also leaves, from dq and dv while they are still in the accumulators, the partial sums of the rank-4 LoRA
  * gradients on q and v (ABI 10; the first pass of bsclip_lora_grad re-read dq and dv from HBM for them):
- *   dt_partial f32 [heads, B*S, 8]:       [h][m][0:4] = dq[m, head h] . B_q[head h],  [h][m][4:8] = dv[m, head h] . B_v[head h]
+ *   dt_partial f32 [heads, 2, B*S, 4]:    [h][0][m][0:4] = dq[m, head h] . B_q[head h],  [h][1][m][0:4] = dv[m, head h] . B_v[head h]
  *   db_partial f32 [B*heads, 2, 4, 64]:   [b*heads+h][q|v][j][d] = sum over the tokens of sequence b of t[m][j (+4 for v)] * dq|dv[m][64 h + d]
  * t_aug: bf16 [B*S, ld_t], t = y A^T in columns 0..7 (the LayerNorm's block of the QKV operand), 16-byte aligned, ld_t % 8 == 0;
  * lora_b f32 [2, heads*64, 4] as bsclip_lora_grad.  With dropout the forward's keep_bits are required.  The products run on the matrix

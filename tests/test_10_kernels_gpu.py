@@ -539,7 +539,7 @@ def test_lora_grad_from_attention_partials(ops, B, S, heads, p, q_rows):
     ops.lora_grad(ref_d, h, M, H, lb, rdt, rdA, rdBq, rdBv)
 
     dqkv = torch.full((M, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
-    dtp = torch.full((heads, M, 8), float("nan"), device="cuda")
+    dtp = torch.full((heads, 2, M, 4), float("nan"), device="cuda")
     dbp = torch.full((B * heads, 2, 4, 64), float("nan"), device="cuda")
     ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv, dropout=drop, q_rows=q_rows, keep_bits=bits, lora=(h[:, H:], lb, dtp, dbp))
     assert torch.equal(dqkv, ref_d)

@@ -38,7 +38,7 @@ for name, S, p in (("vit", 197, 0.0), ("dna", 133, 0.1), ("dna-nodrop", 133, 0.0
         M = B * S
         h = torch.randn(M, H + 64, device="cuda").bfloat16()
         lb = torch.randn(2, H, 4, device="cuda") * 0.1
-        dtp, dbp = torch.empty(heads, M, 8, device="cuda"), torch.empty(B * heads, 2, 4, 64, device="cuda")
+        dtp, dbp = torch.empty(heads, 2, M, 4, device="cuda"), torch.empty(B * heads, 2, 4, 64, device="cuda")
         dt, dA = torch.empty(M, 8, device="cuda"), torch.zeros(8, H, device="cuda")
         dBq, dBv = torch.zeros(H, 4, device="cuda"), torch.zeros(H, 4, device="cuda")
         cases += [("bwd+lora", lambda: ops.attn_bwd(qkv, dctx, lse, B, S, heads, 0.125, dqkv, dropout=drop, keep_bits=bits,
