@@ -308,8 +308,9 @@ __global__ __launch_bounds__(LG_BLOCK) void lora_t_f32_kernel(const float* __res
 
 // Sum the per-workgroup slabs in a fixed order (bitwise reproducible) and accumulate into dBq/dBv/dA.
 // Slab A (8H floats): index k*64 + l, k = [is_v][j][i][r];  slab B (8H floats): index ((r*NV + j)*4 + i)*64 + l.
-// Workgroup = 32 consecutive slab elements x 8 slab-groups; thread (i, p) sums slabs p, p+8, ... and the 8 partial
-// sums are combined in p order through LDS.
+// Workgroup = 32 consecutive slab elements x 32 slab groups: thread (q, p) sums 4 consecutive elements (one 16-byte load per slab) of
+// slabs p, p + 32, ... with four loads in flight; the 32 partial sums are combined in p order through LDS.  (Round 5: 4-byte loads
+// over 8 groups of 96 slabs took 13 us for the step's 19 MB of dA slabs.)
 // first_block = SLAB / 32 with a grid of SLAB / 32 workgroups sums the dA slabs only (bsclip_lora_grad_heads: dB comes from the
 // attention kernel's partials).
 template <int H>
@@ -319,37 +320,43 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __re
                                                                 float* __restrict__ dBv, int first_block = 0) {
     constexpr int NV = H / 256;
     constexpr int SLAB = 8 * H;
-    __shared__ float red[8][32];
-    const int i = threadIdx.x & 31, p = threadIdx.x >> 5;
-    const int idx = (blockIdx.x + first_block) * 32 + i;  // < 2*SLAB by construction (grid = 2*SLAB/32)
+    __shared__ f32x4 red[32][8];
+    const int q = threadIdx.x & 7, p = threadIdx.x >> 3;
+    const int idx = (blockIdx.x + first_block) * 32 + q * 4;  // < 2*SLAB by construction (grid = 2*SLAB/32)
     const bool second = idx >= SLAB;
     const int e = second ? idx - SLAB : idx;
     const float* src = (second ? pb : pa) + e;
-    float s = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     int b = p;
-    for (; b + 56 < nblocks; b += 64) {   // eight loads in flight; the adds keep the slab order
-        float v[8];
+    for (; b + 96 < nblocks; b += 128) {   // four loads in flight; the adds keep the slab order
+        f32x4 v[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + 8 * u) * SLAB];
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(b + 32 * u) * SLAB);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 4; ++u) s += v[u];
     }
-    for (; b < nblocks; b += 8) s += src[(size_t)b * SLAB];
-    red[p][i] = s;
+    for (; b < nblocks; b += 32) s += *reinterpret_cast<const f32x4*>(src + (size_t)b * SLAB);
+    red[p][q] = s;
     __syncthreads();
     if (p != 0) return;
-    s = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + ((red[4][i] + red[5][i]) + (red[6][i] + red[7][i]));
-    const int l = e & 63, k = e >> 6;
-    if (!second) {
-        const bool is_v = k >= NV * 16;
-        const int kk = is_v ? k - NV * 16 : k;
-        const int j = kk >> 4, ii = (kk >> 2) & 3, r = kk & 3;
-        const int c = j * 256 + l * 4 + ii;
-        float* dst = (is_v ? dBv : dBq) + (size_t)c * 4 + r;
-        *dst += s;
-    } else {
-        const int ii = k & 3, j = (k >> 2) % NV, r = (k >> 2) / NV;
-        dA[(size_t)r * H + j * 256 + l * 4 + ii] += s;
+    s = red[0][q];
+#pragma unroll
+    for (int g = 1; g < 32; ++g) s += red[g][q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ec = e + c;
+        const int l = ec & 63, k = ec >> 6;
+        if (!second) {
+            const bool is_v = k >= NV * 16;
+            const int kk = is_v ? k - NV * 16 : k;
+            const int j = kk >> 4, ii = (kk >> 2) & 3, r = kk & 3;
+            const int col = j * 256 + l * 4 + ii;
+            float* dst = (is_v ? dBv : dBq) + (size_t)col * 4 + r;
+            *dst += s[c];
+        } else {
+            const int ii = k & 3, j = (k >> 2) % NV, r = (k >> 2) / NV;
+            dA[(size_t)r * H + j * 256 + l * 4 + ii] += s[c];
+        }
     }
 }
 
