@@ -264,6 +264,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
     bf16_t* dqb = dqkv + (size_t)b * S * ld_d + hd * 64;
     const unsigned bh = (unsigned)(b * heads + hd);
 
+    // LORA: the head's rows of B (16 bytes each: one load per thread of the first two waves) and the item's t rows are requested FIRST, so
+    // that they are in flight under the tile copies issued next and are waited for without waiting for those (loads return in order)
+    [[maybe_unused]] f32x4 b_row = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] u32x4 t_row = {0u, 0u, 0u, 0u};
+    if constexpr (LORA) {
+        static_assert(SP <= ATT_WAVES * 64, "one t row per thread");
+        if (tid < 128) b_row = *reinterpret_cast<const f32x4*>(lp.b + ((size_t)(tid >> 6) * HW + hd * 64 + (tid & 63)) * 4);
+        if (tid < S) t_row = *reinterpret_cast<const u32x4*>(lp.t + (size_t)(b * S + tid) * lp.ld_t);
+    }
     // ---------------- phase 1 staging: K, V row-major, lse, bias ----------------
     stage_tile<SP>(kb, ld, S, sR0, wave, lane);
     stage_tile<SP>(vb, ld, S, sR1, wave, lane);
@@ -273,18 +282,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         sLse[k] = (k < S) ? lse[((size_t)b * heads + hd) * S + k] * LOG2E : INFINITY;  // padded queries -> p = 0
     }
     if constexpr (LORA) {
-        for (int i = tid; i < 2 * 64 * 4; i += ATT_WAVES * 64) {   // i = (is_v * 64 + d) * 4 + j of the master
-            const int is_v = i >> 8, d = (i >> 2) & 63, j = i & 3;
-            const float x = lp.b[((size_t)is_v * HW + hd * 64 + d) * 4 + j];
-            const bf16_t hi = f2bf(x);
-            sBt[((is_v * 2 + 0) * 4 + j) * 64 + d] = hi;
-            sBt[((is_v * 2 + 1) * 4 + j) * 64 + d] = f2bf(x - bf2f(hi));
-        }
-        for (int tok = tid; tok < SP; tok += ATT_WAVES * 64) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (tok < S) v = *reinterpret_cast<const u32x4*>(lp.t + (size_t)(b * S + tok) * lp.ld_t);
+        if (tid < 128) {   // B^T of the head as hi + lo bf16 parts: [q | v][hi | lo][j][d]
+            const int is_v = tid >> 6, d = tid & 63;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sTt[j * SP + tok] = (bf16_t)((v[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+            for (int j = 0; j < 4; ++j) {
+                const bf16_t hi = f2bf(b_row[j]);
+                sBt[((is_v * 2 + 0) * 4 + j) * 64 + d] = hi;
+                sBt[((is_v * 2 + 1) * 4 + j) * 64 + d] = f2bf(b_row[j] - bf2f(hi));
+            }
+        }
+        if (tid < SP) {    // t^T of the item: [8 j][SP tokens], zero past S
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sTt[j * SP + tid] = (bf16_t)((t_row[j >> 1] >> (16 * (j & 1))) & 0xffffu);
         }
     }
     // LoRA partial products of one 32-token block whose dq (is_v = 0) or dv (1) sits in acc (d on rows, token on the lane), already scaled
@@ -292,21 +301,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
         char* tile = sTr + wave * LORA_TILE;
         const bf16_t* bt = sBt + is_v * (2 * 4 * 64);
         const bf16_t* tt = sTt + is_v * 4 * SP;
-        f32x16 dtacc = zero16();
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 xb = pack8(acc[dt], s2);   // k = d = 32 dt + 16 s2 + (pack8 order)
-                dtacc = mfma32(small_frag(bt, 64, 32 * dt + 16 * s2, lane), xb, dtacc);
-                dtacc = mfma32(small_frag(bt + 4 * 64, 64, 32 * dt + 16 * s2, lane), xb, dtacc);
-            }
-        const int tok = tok0 + (lane & 31);
-        if (h == 0 && tok < S)   // accumulator rows 0..3 = j, on lane half 0
-            *reinterpret_cast<f32x4*>(lp.dtp + ((((size_t)hd * 2 + is_v) * (gridDim.x / heads) + b) * S + tok) * 4) =
-                f32x4{dtacc[0], dtacc[1], dtacc[2], dtacc[3]};
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
+        // order: the first half's tile goes to LDS, the dt products (independent of it) run while it lands, then the dB products
+        auto put_tile = [&](int dt) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {   // [token][d - 32 dt] bf16, 72-byte rows
                 uint2 o;
@@ -314,12 +310,31 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void attn_bwd_kernel(const bf16_
                 o.y = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
                 *reinterpret_cast<uint2*>(tile + (lane & 31) * 72 + (8 * g + 4 * h) * 2) = o;
             }
+        };
+        auto db_half = [&](int dt) {   // dB^T[j, d] += t^T[j, token] x[token, d]: the tile read token-strided
             f32x16 dbacc = zero16();
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)   // dB^T[j, d] += t^T[j, token] x[token, d]: the tile read token-strided
+            for (int s2 = 0; s2 < 2; ++s2)
                 dbacc = mfma32(small_frag(tt, SP, tok0 + 16 * s2, lane), frag_tr_lin(tile, 72, 0, 16 * s2, lane), dbacc);
             kacc[dt] += f32x4{dbacc[0], dbacc[1], dbacc[2], dbacc[3]};
-        }
+        };
+        put_tile(0);
+        f32x16 dtacc = zero16(), dtacc2 = zero16();   // two chains: the hi and the lo part of B
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 xb = pack8(acc[dt], s2);   // k = d = 32 dt + 16 s2 + (pack8 order)
+                dtacc = mfma32(small_frag(bt, 64, 32 * dt + 16 * s2, lane), xb, dtacc);
+                dtacc2 = mfma32(small_frag(bt + 4 * 64, 64, 32 * dt + 16 * s2, lane), xb, dtacc2);
+            }
+        db_half(0);
+        put_tile(1);
+        const int tok = tok0 + (lane & 31);
+        if (h == 0 && tok < S)   // accumulator rows 0..3 = j, on lane half 0
+            *reinterpret_cast<f32x4*>(lp.dtp + ((((size_t)hd * 2 + is_v) * (gridDim.x / heads) + b) * S + tok) * 4) =
+                f32x4{dtacc[0] + dtacc2[0], dtacc[1] + dtacc2[1], dtacc[2] + dtacc2[2], dtacc[3] + dtacc2[3]};
+        db_half(1);
     };
     // a phase's dB^T sums of the 4 waves -> db_partial[item][is_v][j][d]; call with all the workgroup's threads
     [[maybe_unused]] auto lora_flush = [&](const f32x4 (&kacc)[2], int is_v) {
